@@ -1,0 +1,411 @@
+"""CPU oracle for the DeFlow hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file.  The product (``deflow_amd``) never imports it and has no CPU fallback.
+
+It is a plain-PyTorch (fp32, CPU) restatement of the reference algorithm.  Pinning status:
+
+* PINNED against the real reference (golden vectors in ``tests/golden`` produced by
+  ``oracle/gen_golden.py`` importing ``/root/reference/decoder.py`` / ``deflow.py``):
+  ``ConvGRU``, ``ConvGRUDecoder``, ``LinearDecoder``, ``ConvWithNorms``, and the
+  ``DeFlow.forward`` orchestration (ego-motion compensation, hand-offs, result dict).
+* PARITY UNPINNED (source lives in the un-vendored ``KTH-RPL/OpenSceneFlow`` submodule,
+  commit unknown; restated from the published ZeroFlow/OpenSceneFlow/mmcv algorithm and
+  anchored on the reference's call sites): ``DynamicVoxelizer``/``DynamicEmbedder``
+  [REF deflow.py:27-30,82-83], ``FastFlow3DUNet`` [REF deflow.py:32,87-88],
+  ``cal_pose0to1`` [REF deflow.py:67], ``deflowLoss`` [REF README.md:66].
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------
+# A2: dynamic voxelisation (mmcv ``dynamic_voxelize`` semantics)            PARITY UNPINNED
+# ----------------------------------------------------------------------------------------
+
+
+def grid_size_of(voxel_size, point_cloud_range) -> Tuple[int, int, int]:
+    """mmcv ``Voxelization.__init__``: grid = round((max - min) / voxel) in fp32 -> (gx, gy, gz)."""
+    r = torch.tensor(point_cloud_range, dtype=torch.float32)
+    v = torch.tensor(voxel_size, dtype=torch.float32)
+    g = torch.round((r[3:] - r[:3]) / v).long()
+    return int(g[0]), int(g[1]), int(g[2])
+
+
+def dynamic_voxelize(points: torch.Tensor, voxel_size, point_cloud_range) -> torch.Tensor:
+    """points [M,3] f32 (no NaN rows) -> coors [M,3] int32 in (z,y,x) order.
+
+    Per axis c = floor((p - min) / voxel) computed in fp32 (IEEE sub, IEEE div, floor).
+    mmcv writes -1 progressively (x fails -> (-1,0,0); y fails -> (-1,-1,0); z -> (-1,-1,-1));
+    the embedder only tests ``(coors != -1).all(1)``, so any out-of-range axis drops the point.
+    """
+    gx, gy, gz = grid_size_of(voxel_size, point_cloud_range)
+    vs = torch.tensor(voxel_size, dtype=torch.float32)
+    mn = torch.tensor(point_cloud_range[:3], dtype=torch.float32)
+    c = torch.floor((points[:, :3].float() - mn) / vs)  # fp32 throughout
+    cx, cy, cz = c[:, 0], c[:, 1], c[:, 2]
+    okx = (cx >= 0) & (cx < gx)
+    oky = (cy >= 0) & (cy < gy)
+    okz = (cz >= 0) & (cz < gz)
+    coors = torch.zeros((points.shape[0], 3), dtype=torch.int32)
+    bad_x = ~okx
+    bad_y = okx & ~oky
+    bad_z = okx & oky & ~okz
+    good = okx & oky & okz
+    coors[bad_x, 0] = -1
+    coors[bad_y, 0] = -1
+    coors[bad_y, 1] = -1
+    coors[bad_z] = -1
+    coors[good, 0] = cz[good].to(torch.int32)
+    coors[good, 1] = cy[good].to(torch.int32)
+    coors[good, 2] = cx[good].to(torch.int32)
+    return coors
+
+
+class DynamicVoxelizer(nn.Module):
+    """Per sample: drop NaN rows, voxelise, drop out-of-range rows, compute centre offsets."""
+
+    def __init__(self, voxel_size, point_cloud_range):
+        super().__init__()
+        self.voxel_size = list(voxel_size)
+        self.point_cloud_range = list(point_cloud_range)
+
+    def _get_point_offsets(self, points, voxel_coords):
+        mn = torch.tensor(self.point_cloud_range[:3], dtype=points.dtype)
+        vs = torch.tensor(self.voxel_size, dtype=points.dtype)
+        vc = voxel_coords[:, [2, 1, 0]]  # (z,y,x) -> (x,y,z)
+        center = vc * vs + mn + vs / 2
+        return points - center
+
+    def forward(self, points: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+        out = []
+        for b in range(points.shape[0]):
+            p = points[b]
+            idx = torch.arange(p.shape[0])
+            keep = ~torch.isnan(p).any(dim=1)
+            p = p[keep]
+            idx = idx[keep]
+            coors = dynamic_voxelize(p, self.voxel_size, self.point_cloud_range)
+            ok = (coors != -1).all(dim=1)
+            coors, p, idx = coors[ok], p[ok], idx[ok]
+            out.append({
+                "points": p,
+                "voxel_coords": coors,
+                "point_idxes": idx,
+                "point_offsets": self._get_point_offsets(p, coors),
+            })
+        return out
+
+
+# ----------------------------------------------------------------------------------------
+# A3: dynamic pillar feature net (mmdet3d DynamicPillarFeatureNet, mode='avg')  UNPINNED
+# ----------------------------------------------------------------------------------------
+
+
+def _scatter_mean(feats: torch.Tensor, coors: torch.Tensor):
+    """mmcv DynamicScatter(average_points=True): unique(coors) (lexicographic z,y,x) + mean.
+
+    Returns (voxel_feats [P,C], voxel_coors [P,3], inverse map [M])."""
+    if coors.shape[0] == 0:
+        return feats.new_zeros((0, feats.shape[1])), coors.new_zeros((0, 3)), coors.new_zeros((0,), dtype=torch.long)
+    uc, inv, cnt = torch.unique(coors, dim=0, return_inverse=True, return_counts=True)
+    summed = torch.zeros((uc.shape[0], feats.shape[1]), dtype=feats.dtype)
+    summed.index_add_(0, inv, feats)
+    return summed / cnt.unsqueeze(1).to(feats.dtype), uc, inv
+
+
+class DynamicPillarFeatureNet(nn.Module):
+    """in_channels=3, feat_channels=(32,), with_cluster_center, with_voxel_center, mode='avg'.
+
+    point feature (9) = [xyz, xyz - mean_xyz(pillar), xyz - pillar_centre];
+    pfn_layers[0] = Sequential(Linear(9,32,bias=False), BatchNorm1d(32, eps=1e-3, momentum=0.01), ReLU);
+    voxel feature = mean over the pillar's points.
+    """
+
+    def __init__(self, in_channels, feat_channels, voxel_size, point_cloud_range, mode="avg"):
+        super().__init__()
+        assert in_channels == 3 and len(feat_channels) == 1
+        self.mode = mode
+        c_in = in_channels + 3 + 3
+        self.pfn_layers = nn.ModuleList([
+            nn.Sequential(nn.Linear(c_in, feat_channels[0], bias=False),
+                          nn.BatchNorm1d(feat_channels[0], eps=1e-3, momentum=0.01),
+                          nn.ReLU(inplace=True))
+        ])
+        self.vx, self.vy, self.vz = [float(v) for v in voxel_size]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.z_offset = self.vz / 2 + point_cloud_range[2]
+
+    def forward(self, features: torch.Tensor, coors: torch.Tensor):
+        voxel_mean, _, inv = _scatter_mean(features, coors)
+        points_mean = voxel_mean[inv]
+        f_cluster = features[:, :3] - points_mean[:, :3]
+        f_center = features.new_zeros((features.shape[0], 3))
+        f_center[:, 0] = features[:, 0] - (coors[:, 2].type_as(features) * self.vx + self.x_offset)
+        f_center[:, 1] = features[:, 1] - (coors[:, 1].type_as(features) * self.vy + self.y_offset)
+        f_center[:, 2] = features[:, 2] - (coors[:, 0].type_as(features) * self.vz + self.z_offset)
+        feats = torch.cat([features, f_cluster, f_center], dim=-1)
+        point_feats = self.pfn_layers[0](feats)
+        if self.mode == "avg":
+            voxel_feats, voxel_coors, _ = _scatter_mean(point_feats, coors)
+        else:  # 'max'
+            uc, inv2 = torch.unique(coors, dim=0, return_inverse=True)
+            voxel_feats = torch.full((uc.shape[0], point_feats.shape[1]), -float("inf"), dtype=point_feats.dtype)
+            voxel_feats = voxel_feats.scatter_reduce(0, inv2[:, None].expand_as(point_feats), point_feats, "amax")
+            voxel_coors = uc
+        return voxel_feats, voxel_coors
+
+
+# ----------------------------------------------------------------------------------------
+# A4: PointPillarsScatter + DynamicEmbedder                                   UNPINNED
+# ----------------------------------------------------------------------------------------
+
+
+class PointPillarsScatter(nn.Module):
+    def __init__(self, in_channels, output_shape):
+        super().__init__()
+        self.in_channels = in_channels
+        self.ny, self.nx = int(output_shape[0]), int(output_shape[1])
+
+    def forward(self, voxel_features, coors):
+        canvas = torch.zeros(self.in_channels, self.nx * self.ny, dtype=voxel_features.dtype)
+        indices = (coors[:, 1].long() * self.nx + coors[:, 2].long())
+        canvas[:, indices] = voxel_features.t()
+        return canvas.view(1, self.in_channels, self.ny, self.nx)
+
+
+class DynamicEmbedder(nn.Module):
+    """[REF deflow.py:27-30] ctor kwargs; [REF deflow.py:82-83] returns (pseudoimage, infos)."""
+
+    def __init__(self, voxel_size, pseudo_image_dims, point_cloud_range, feat_channels: int):
+        super().__init__()
+        self.voxelizer = DynamicVoxelizer(voxel_size, point_cloud_range)
+        self.feature_net = DynamicPillarFeatureNet(3, (feat_channels,), voxel_size, point_cloud_range, mode="avg")
+        self.scatter = PointPillarsScatter(feat_channels, pseudo_image_dims)
+
+    def forward(self, points: torch.Tensor):
+        infos = self.voxelizer(points)
+        imgs = []
+        for info in infos:  # feature_net is called per sample => BN1d batch stats are per sample
+            vf, vc = self.feature_net(info["points"], info["voxel_coords"])
+            imgs.append(self.scatter(vf, vc))
+        return torch.cat(imgs, dim=0), infos
+
+
+# ----------------------------------------------------------------------------------------
+# A5: ConvWithNorms (PINNED, [REF decoder.py:202-220]) and FastFlow3DUNet (UNPINNED)
+# ----------------------------------------------------------------------------------------
+
+
+class ConvWithNorms(nn.Module):
+    def __init__(self, in_num_channels, out_num_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.conv = nn.Conv2d(in_num_channels, out_num_channels, kernel_size, stride, padding)
+        self.batchnorm = nn.BatchNorm2d(out_num_channels)
+        self.nonlinearity = nn.GELU()
+
+    def forward(self, x):
+        y = self.conv(x)
+        if y.shape[2] == 1 and y.shape[3] == 1:  # [REF decoder.py:214-217] BN skipped on 1x1 maps
+            return self.nonlinearity(y)
+        return self.nonlinearity(self.batchnorm(y))
+
+
+class BilinearDecoder(nn.Module):
+    def __init__(self, scale_factor: int, align_corners: bool = False):
+        super().__init__()
+        self.scale_factor = scale_factor
+        self.align_corners = align_corners
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=self.scale_factor, mode="bilinear", align_corners=self.align_corners)
+
+
+class UpsampleSkip(nn.Module):
+    def __init__(self, skip_channels, latent_channels, out_channels, align_corners=False):
+        super().__init__()
+        self.u1_u2 = nn.Sequential(nn.Conv2d(skip_channels, latent_channels, 1, 1, 0),
+                                   BilinearDecoder(2, align_corners))
+        self.u3 = nn.Conv2d(latent_channels, latent_channels, 1, 1, 0)
+        self.u4_u5 = nn.Sequential(nn.Conv2d(2 * latent_channels, out_channels, 3, 1, 1),
+                                   nn.Conv2d(out_channels, out_channels, 3, 1, 1))
+
+    def forward(self, a, b):
+        return self.u4_u5(torch.cat([self.u1_u2(a), self.u3(b)], dim=1))
+
+
+class FastFlow3DUNet(nn.Module):
+    def __init__(self, align_corners: bool = False):
+        super().__init__()
+        C = ConvWithNorms
+        self.encoder_step_1 = nn.Sequential(C(32, 64, 3, 2, 1), *[C(64, 64, 3, 1, 1) for _ in range(3)])
+        self.encoder_step_2 = nn.Sequential(C(64, 128, 3, 2, 1), *[C(128, 128, 3, 1, 1) for _ in range(5)])
+        self.encoder_step_3 = nn.Sequential(C(128, 256, 3, 2, 1), *[C(256, 256, 3, 1, 1) for _ in range(5)])
+        self.decoder_step1 = UpsampleSkip(512, 256, 256, align_corners)
+        self.decoder_step2 = UpsampleSkip(256, 128, 128, align_corners)
+        self.decoder_step3 = UpsampleSkip(128, 64, 64, align_corners)
+        self.decoder_step4 = nn.Conv2d(64, 64, 3, 1, 1)
+
+    def forward(self, pc0_B, pc1_B):
+        pc0_F = self.encoder_step_1(pc0_B)
+        pc0_L = self.encoder_step_2(pc0_F)
+        pc0_R = self.encoder_step_3(pc0_L)
+        pc1_F = self.encoder_step_1(pc1_B)
+        pc1_L = self.encoder_step_2(pc1_F)
+        pc1_R = self.encoder_step_3(pc1_L)
+        Rstar = torch.cat([pc0_R, pc1_R], dim=1)
+        Lstar = torch.cat([pc0_L, pc1_L], dim=1)
+        Fstar = torch.cat([pc0_F, pc1_F], dim=1)
+        Bstar = torch.cat([pc0_B, pc1_B], dim=1)
+        S = self.decoder_step1(Rstar, Lstar)
+        T = self.decoder_step2(S, Fstar)
+        U = self.decoder_step3(T, Bstar)
+        return self.decoder_step4(U)
+
+
+# ----------------------------------------------------------------------------------------
+# A6-A10: decoders (PINNED, [REF decoder.py:72-199])
+# ----------------------------------------------------------------------------------------
+
+
+class ConvGRU(nn.Module):
+    """[REF decoder.py:123-139] Conv1d(k=1) == Linear(192->128) per point."""
+
+    def __init__(self, input_dim=64, hidden_dim=128):
+        super().__init__()
+        self.convz = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+        self.convr = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+        self.convq = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+
+    def forward(self, h, x):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(self.convz(hx))
+        r = torch.sigmoid(self.convr(hx))
+        q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+
+def _gather(before, after, voxel_coords):
+    """[REF decoder.py:160-171] nearest-cell integer gather, before first then after."""
+    vc = voxel_coords.long()
+    a = after[:, vc[:, 1], vc[:, 2]].T
+    b = before[:, vc[:, 1], vc[:, 2]].T
+    return torch.cat([b, a], dim=1)
+
+
+class ConvGRUDecoder(nn.Module):
+    def __init__(self, pseudoimage_channels: int = 64, num_iters: int = 4):
+        super().__init__()
+        self.offset_encoder = nn.Linear(3, pseudoimage_channels)
+        self.gru = ConvGRU(input_dim=pseudoimage_channels, hidden_dim=pseudoimage_channels * 2)
+        self.decoder = nn.Sequential(nn.Linear(pseudoimage_channels * 3, pseudoimage_channels // 2), nn.GELU(),
+                                     nn.Linear(pseudoimage_channels // 2, 3))
+        self.num_iters = num_iters
+
+    def forward_single(self, before, after, point_offsets, voxel_coords):
+        h = _gather(before, after, voxel_coords).unsqueeze(2)
+        x = self.offset_encoder(point_offsets)
+        for _ in range(self.num_iters):
+            h = self.gru(h, x.unsqueeze(2))
+        return self.decoder(torch.cat([h.squeeze(2), x], dim=1))
+
+    def forward(self, before_pseudoimages, after_pseudoimages, voxelizer_infos):
+        return [self.forward_single(b, a, i["point_offsets"], i["voxel_coords"])
+                for b, a, i in zip(before_pseudoimages, after_pseudoimages, voxelizer_infos)]
+
+
+class LinearDecoder(nn.Module):
+    def __init__(self, pseudoimage_channels: int = 64):
+        super().__init__()
+        self.offset_encoder = nn.Linear(3, 128)
+        self.decoder = nn.Sequential(nn.Linear(pseudoimage_channels * 4, 32), nn.GELU(), nn.Linear(32, 3))
+
+    def forward_single(self, before, after, point_offsets, voxel_coords):
+        v = _gather(before, after, voxel_coords)
+        return self.decoder(torch.cat([v, self.offset_encoder(point_offsets)], dim=1))
+
+    def forward(self, before_pseudoimages, after_pseudoimages, voxelizer_infos):
+        return [self.forward_single(b, a, i["point_offsets"], i["voxel_coords"])
+                for b, a, i in zip(before_pseudoimages, after_pseudoimages, voxelizer_infos)]
+
+
+# ----------------------------------------------------------------------------------------
+# A1/A9: DeFlow orchestration (PINNED via G5, [REF deflow.py:49-113])
+# ----------------------------------------------------------------------------------------
+
+
+def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor) -> torch.Tensor:
+    """inv(pose1) @ pose0 (UNPINNED; call site [REF deflow.py:67])."""
+    return torch.linalg.inv(pose1) @ pose0
+
+
+class DeFlow(nn.Module):
+    def __init__(self, voxel_size=[0.2, 0.2, 6], point_cloud_range=[-51.2, -51.2, -3, 51.2, 51.2, 3],
+                 grid_feature_size=[512, 512], decoder_option="gru", num_iters=4, align_corners=False):
+        super().__init__()
+        self.embedder = DynamicEmbedder(voxel_size=voxel_size, pseudo_image_dims=grid_feature_size,
+                                        point_cloud_range=point_cloud_range, feat_channels=32)
+        self.backbone = FastFlow3DUNet(align_corners=align_corners)
+        if decoder_option == "gru":
+            self.head = ConvGRUDecoder(num_iters=num_iters)
+        elif decoder_option == "linear":
+            self.head = LinearDecoder()
+
+    def forward(self, batch):
+        B = len(batch["pose0"])
+        pose_flows, pc0s = [], []
+        for b in range(B):
+            pc0 = batch["pc0"][b]
+            with torch.no_grad():
+                T = batch["ego_motion"][b] if "ego_motion" in batch else cal_pose0to1(batch["pose0"][b], batch["pose1"][b])
+            t_pc0 = pc0 @ T[:3, :3].T + T[:3, 3]
+            pose_flows.append(t_pc0 - pc0)
+            pc0s.append(t_pc0)
+        pc0s = torch.stack(pc0s, dim=0)
+        pc1s = batch["pc1"]
+        img0, infos0 = self.embedder(pc0s)
+        img1, infos1 = self.embedder(pc1s)
+        grid = self.backbone(img0, img1)
+        flows = self.head(torch.cat((img0, img1), dim=1), grid, infos0)
+        return {
+            "flow": flows,
+            "pose_flow": pose_flows,
+            "pc0_valid_point_idxes": [e["point_idxes"] for e in infos0],
+            "pc0_points_lst": [e["points"] for e in infos0],
+            "pc1_valid_point_idxes": [e["point_idxes"] for e in infos1],
+            "pc1_points_lst": [e["points"] for e in infos1],
+        }
+
+
+# ----------------------------------------------------------------------------------------
+# A11: deflowLoss + the trainer's per-sample gt construction                   UNPINNED
+# ----------------------------------------------------------------------------------------
+
+
+def deflow_loss(est_flow: torch.Tensor, gt_flow: torch.Tensor) -> torch.Tensor:
+    """3 speed bins (|gt|/0.1: <0.4, [0.4,1.0], >1.0); sum of per-bin mean L2 error; empty bins skipped."""
+    mask = (~gt_flow.isnan() & ~est_flow.isnan() & ~gt_flow.isinf() & ~est_flow.isinf())
+    pred = est_flow[mask].reshape(-1, 3)
+    gt = gt_flow[mask].reshape(-1, 3)
+    speed = gt.norm(dim=1, p=2) / 0.1
+    err = torch.linalg.vector_norm(pred - gt, dim=-1)
+    total = 0.0
+    for sel in (speed < 0.4, (speed >= 0.4) & (speed <= 1.0), speed > 1.0):
+        if sel.any():
+            total = total + err[sel].mean()
+    return total
+
+
+def training_loss(res: dict, batch: dict) -> torch.Tensor:
+    """OpenSceneFlow trainer ``training_step``: gt = flow[valid] - pose_flow[valid]; summed over samples."""
+    total = 0.0
+    for b in range(len(batch["pose0"])):
+        vi = res["pc0_valid_point_idxes"][b]
+        gt = batch["flow"][b][vi] - res["pose_flow"][b][vi]
+        total = total + deflow_loss(res["flow"][b], gt)
+    return total

@@ -1,0 +1,164 @@
+"""CPU: the oracle (oracle/ref_torch.py) against golden vectors produced by the REAL reference
+(oracle/gen_golden.py importing /root/reference/decoder.py and deflow.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as O
+
+RTOL = 1e-5  # same math, same torch build: only summation-order noise is expected
+ATOL = 1e-6
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _load_w(mod, g, prefix="w."):
+    sd = {k[len(prefix):]: _t(v) for k, v in g.items() if k.startswith(prefix)}
+    mod.load_state_dict(sd)
+
+
+def _close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach() if isinstance(a, torch.Tensor) else _t(a)
+    b = _t(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_g1_convgru(golden_dir):
+    g = _load(golden_dir, "g1_convgru.npz")
+    m = O.ConvGRU(64, 128)
+    _load_w(m, g)
+    h = _t(g["h"]).requires_grad_(True)
+    x = _t(g["x"]).requires_grad_(True)
+    out = m(h, x)
+    _close(out, g["out"])
+    out.backward(_t(g["gout"]))
+    _close(h.grad, g["gh"]); _close(x.grad, g["gx"])
+    for k, p in m.named_parameters():
+        _close(p.grad, g["gw." + k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("iters", [1, 4, 8])
+def test_g2_grudecoder(golden_dir, iters):
+    g = _load(golden_dir, f"g2_grudecoder_it{iters}.npz")
+    m = O.ConvGRUDecoder(num_iters=int(g["num_iters"]))
+    _load_w(m, g)
+    before = _t(g["before"]).requires_grad_(True)
+    after = _t(g["after"]).requires_grad_(True)
+    infos = [{"voxel_coords": _t(g[f"vc{i}"]), "point_offsets": _t(g[f"off{i}"])} for i in range(3)]
+    flows = m(before, after, infos)
+    assert [f.shape[0] for f in flows] == [333, 0, 1]
+    for i, f in enumerate(flows):
+        _close(f, g[f"flow{i}"])
+    sum((f * _t(g[f"gflow{i}"])).sum() for i, f in enumerate(flows)).backward()
+    _close(before.grad, g["gbefore"], rtol=1e-4, atol=1e-5)
+    _close(after.grad, g["gafter"], rtol=1e-4, atol=1e-5)
+    for k, p in m.named_parameters():
+        _close(p.grad, g["gw." + k], rtol=1e-4, atol=1e-5)
+
+
+def test_g3_lineardecoder(golden_dir):
+    g = _load(golden_dir, "g3_lineardecoder.npz")
+    m = O.LinearDecoder()
+    _load_w(m, g)
+    before = _t(g["before"]).requires_grad_(True)
+    after = _t(g["after"]).requires_grad_(True)
+    infos = [{"voxel_coords": _t(g[f"vc{i}"]), "point_offsets": _t(g[f"off{i}"])} for i in range(2)]
+    flows = m(before, after, infos)
+    for i, f in enumerate(flows):
+        _close(f, g[f"flow{i}"])
+    sum((f * _t(g[f"gflow{i}"])).sum() for i, f in enumerate(flows)).backward()
+    _close(before.grad, g["gbefore"], rtol=1e-4, atol=1e-5)
+    for k, p in m.named_parameters():
+        _close(p.grad, g["gw." + k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1", "skip1x1"])
+def test_g4_convwithnorms(golden_dir, tag):
+    g = _load(golden_dir, f"g4_convwithnorms_{tag}.npz")
+    cin, cout = g["w0.conv.weight"].shape[1], g["w0.conv.weight"].shape[0]
+    m = O.ConvWithNorms(cin, cout, int(g["k"]), int(g["s"]), int(g["p"]))
+    _load_w(m, g, "w0.")
+    m.train(bool(g["train"]))
+    x = _t(g["x"]).requires_grad_(True)
+    y = m(x)
+    _close(y, g["y"], rtol=1e-4, atol=1e-5)
+    y.backward(_t(g["gy"]))
+    _close(x.grad, g["gx"], rtol=1e-4, atol=1e-5)
+    for k, v in m.state_dict().items():  # running stats after the call
+        _close(v, g["w1." + k], rtol=1e-5, atol=1e-6)
+    if tag == "skip1x1":  # BN skipped on a 1x1 map: running stats untouched
+        _close(m.batchnorm.running_mean, g["w0.batchnorm.running_mean"])
+
+
+def test_g5_deflow_orchestration(golden_dir):
+    g = _load(golden_dir, "g5_deflow_orchestration.npz")
+    torch.manual_seed(int(g["seed"]))
+    m = O.DeFlow(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-6.4, -6.4, -3, 6.4, 6.4, 3],
+                 grid_feature_size=[64, 64], decoder_option="gru", num_iters=2)
+    for k, v in m.state_dict().items():  # seed + construction order reproduce the golden weights
+        assert abs(float(v.double().sum()) - float(g["wsum." + k])) <= 1e-9 + 1e-9 * abs(float(g["wabs." + k])), k
+    m.eval()
+    batch = {k: _t(g[k]) for k in ("pc0", "pc1", "pose0", "pose1")}
+    with torch.no_grad():
+        res = m(batch)
+    for key in ("flow", "pose_flow", "pc0_valid_point_idxes", "pc0_points_lst", "pc1_valid_point_idxes", "pc1_points_lst"):
+        assert len(res[key]) == 2
+        for b in range(2):
+            want = _t(g[f"{key}.{b}"])
+            got = res[key][b]
+            if want.dtype.is_floating_point:
+                torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5, equal_nan=True)
+            else:
+                assert torch.equal(got, want)
+    g2 = _load(golden_dir, "g5_deflow_egomotion.npz")
+    batch["ego_motion"] = _t(g2["ego_motion"])
+    with torch.no_grad():
+        res2 = m(batch)
+    for b in range(2):
+        torch.testing.assert_close(res2["pose_flow"][b], _t(g2[f"pose_flow.{b}"]), rtol=1e-5, atol=1e-6, equal_nan=True)
+        torch.testing.assert_close(res2["flow"][b], _t(g2[f"flow.{b}"]), rtol=1e-4, atol=1e-5)
+
+
+def test_voxelize_edges():
+    """mmcv dynamic_voxelize boundary semantics (fp32 floor-divide; upper bound exclusive)."""
+    vs, rng = [0.2, 0.2, 6], [-51.2, -51.2, -3, 51.2, 51.2, 3]
+    pts = torch.tensor([
+        [-51.2, -51.2, -3.0],   # exactly on the lower corner -> (0,0,0)
+        [51.2, 0.0, 0.0],       # x == max -> out
+        [51.19999, 0.0, 0.0],   # just inside
+        [0.0, -51.2000001, 0.0],  # rounds to -51.2 in fp32 -> inside row 0
+        [0.0, 0.0, 3.0],        # z == max -> out
+        [-0.0, 0.0, 2.99],
+        [-51.3, 0.0, 0.0],      # x < min
+    ], dtype=torch.float32)
+    c = O.dynamic_voxelize(pts, vs, rng)
+    assert c[0].tolist() == [0, 0, 0]
+    assert c[1, 0].item() == -1
+    assert c[2].tolist() == [0, 256, 511]
+    assert c[3].tolist() == [0, 0, 256]
+    assert (c[4] == -1).all()
+    assert c[5].tolist() == [0, 256, 256]
+    assert c[6, 0].item() == -1
+    ref = np.floor((pts.numpy().astype(np.float64)[:, 0] - np.float64(np.float32(-51.2))) / np.float64(np.float32(0.2)))
+    ok = (ref >= 0) & (ref < 512)
+    assert ((c[:, 0] != -1).numpy() <= ok).all()  # fp32 result never keeps a point fp64 drops on x
+
+
+def test_deflow_loss_hand_example():
+    gt = torch.tensor([[0.0, 0.0, 0.0], [0.03, 0.0, 0.0], [0.05, 0.0, 0.0], [0.5, 0.0, 0.0], [float("nan"), 0.0, 0.0]])
+    est = torch.tensor([[0.1, 0.0, 0.0], [0.03, 0.2, 0.0], [0.0, 0.0, 0.0], [0.5, 0.0, 0.3], [0.0, 0.0, 0.0]])
+    # speeds: 0, 0.3 (<0.4) | 0.5 (mid) | 5 (>1); NaN row removed elementwise
+    want = (0.1 + 0.2) / 2 + 0.05 + 0.3
+    got = O.deflow_loss(est, gt)
+    assert abs(float(got) - want) < 1e-6
+    # empty bins are skipped, not NaN
+    assert abs(float(O.deflow_loss(est[:1], gt[:1])) - 0.1) < 1e-7
