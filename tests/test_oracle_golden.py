@@ -154,9 +154,9 @@ def test_voxelize_edges():
 
 
 def test_deflow_loss_hand_example():
-    gt = torch.tensor([[0.0, 0.0, 0.0], [0.03, 0.0, 0.0], [0.05, 0.0, 0.0], [0.5, 0.0, 0.0], [float("nan"), 0.0, 0.0]])
+    gt = torch.tensor([[0.0, 0.0, 0.0], [0.03, 0.0, 0.0], [0.05, 0.0, 0.0], [0.5, 0.0, 0.0], [float("nan")] * 3])
     est = torch.tensor([[0.1, 0.0, 0.0], [0.03, 0.2, 0.0], [0.0, 0.0, 0.0], [0.5, 0.0, 0.3], [0.0, 0.0, 0.0]])
-    # speeds: 0, 0.3 (<0.4) | 0.5 (mid) | 5 (>1); NaN row removed elementwise
+    # speeds: 0, 0.3 (<0.4) | 0.5 (mid) | 5 (>1); all-NaN row removed
     want = (0.1 + 0.2) / 2 + 0.05 + 0.3
     got = O.deflow_loss(est, gt)
     assert abs(float(got) - want) < 1e-6
