@@ -1,0 +1,137 @@
+"""ctypes binding of libdeflow_amd.so (include/deflow_amd.h).  No fallback: if the HIP library is missing
+or a call is rejected, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeflow_amd.so")
+
+_ERR = {-1: "DF_E_SHAPE", -2: "DF_E_ALIGN", -3: "DF_E_ARG", -4: "DF_E_WORKSPACE"}
+
+
+class DfImg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+                ("ld", C.c_int32), ("grp_size", C.c_int32), ("img_stride", C.c_int64), ("grp_off", C.c_int64)]
+
+
+class DfGeom(C.Structure):
+    _fields_ = [("vx", C.c_float), ("vy", C.c_float), ("vz", C.c_float),
+                ("minx", C.c_float), ("miny", C.c_float), ("minz", C.c_float),
+                ("offx", C.c_float), ("offy", C.c_float), ("offz", C.c_float),
+                ("gx", C.c_int32), ("gy", C.c_int32), ("gz", C.c_int32)]
+
+
+class DfGruWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w_off", "b_off", "w_zr", "b_zr", "w_q", "b_q", "w_1", "b_1", "w_2", "b_2")]
+
+
+class DfGruWeightsT(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("wt_zr", "wt_q", "wt_1")]
+
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (restype int unless listed in _RESTYPE)
+_SIGS = {
+    "df_version": [],
+    "df_pillar_keys": [P, I, I, DfGeom, P, P, P],
+    "df_pillar_scan": [P, I, I, P, P, P],
+    "df_pillar_compact": [P, P, P, I, I, DfGeom, P, P, P, P, P, P],
+    "df_pillar_sort_ws_bytes": [L],
+    "df_pillar_sort": [P, P, P, L, I, P, L, P],
+    "df_pillar_cells": [P, L, L, P, P],
+    "df_pfn_stats": [P, P, P, I, DfGeom, P, P, I, P],
+    "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
+    "df_pfn_canvas": [P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
+    "df_pfn_bwd_stats": [P, P, P, I, DfGeom, P, P, I, DfImg, P, I, P],
+    "df_pfn_bwd_finalize": [P, I, I, P, P, P, I, P, P],
+    "df_pfn_bwd_weights": [P, P, P, I, DfGeom, P, P, I, P, DfImg, P, I, P],
+    "df_conv2d": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
+    "df_conv2d_tile_m": [L, I],
+    "df_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P],
+    "df_bn_gelu_apply": [P, P, I, DfImg, P],
+    "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],
+    "df_bn_bwd_finalize": [P, I, I, I, L, P, P, P, P],
+    "df_bn_gelu_bwd_apply": [DfImg, P, P, P, I, P, P, I, P],
+    "df_colsum_partial": [DfImg, P, I, P],
+    "df_colsum_finalize": [P, I, I, I, P, I, P],
+    "df_weight_transpose": [P, P, I, I, I, P],
+    "df_conv2d_wgrad_splits": [DfImg, DfImg, I, I],
+    "df_conv2d_wgrad": [DfImg, DfImg, I, I, I, P, I, P, I, P],
+    "df_conv2d_wgrad_reduce": [P, I, I, I, I, P, L, I, P],
+    "df_upsample2x": [DfImg, DfImg, I, P],
+    "df_upsample2x_bwd": [DfImg, DfImg, I, P],
+    "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],
+    "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
+    "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
+    "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],
+    "df_linear_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, P, P, P, P, P, P, P, P],
+    "df_ego_transform": [P, P, I, I, P, P, P],
+    "df_deflow_loss_fwd": [P, P, P, I, I, P, I, P],
+    "df_deflow_loss_finalize": [P, I, I, P, P, P],
+    "df_deflow_loss_bwd": [P, P, P, I, I, P, P, F, P, I, P],
+    "df_gather_gt": [P, P, P, P, I, I, P, I, P],
+    "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
+}
+_RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
+_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits"}  # return values, not status
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly if it has not been built (python -m deflow_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build the HIP kernels first (python -m deflow_amd.build). "
+                           "deflow_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        if not hasattr(lib, name):
+            continue  # header/export consistency is checked by tests/test_abi.py
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if name in _RAW:
+        return rc
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")
+    return 0
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
+    """Descriptor of an NHWC-shaped tensor [N,H,W,C'] (stride(3) == 1); optional channel slice [c_off, c_off+c)."""
+    assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2), (t.shape, t.stride())
+    n, h, w, cc = t.shape
+    c = cc - c_off if c is None else c
+    return DfImg(t.data_ptr() + 4 * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0)
+
+
+def img_pair(t: torch.Tensor, c: int) -> DfImg:
+    """A channel-concatenated buffer [B,H,W,2c] viewed as 2B images of c channels: image (g, b) = cloud g of sample b.
+    This is how the shared encoder reads/writes torch.cat((pc0_x, pc1_x), dim=1) without a copy."""
+    assert t.dim() == 4 and t.shape[3] == 2 * c and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+    n, h, w, _ = t.shape
+    return DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c)

@@ -1,0 +1,102 @@
+"""torch.autograd plumbing around the HIP engines.  PyTorch only chains these nodes and owns the memory; every
+forward and backward computation inside them is a HIP kernel launched through the C ABI."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from ._lib import img, call, ptr, stream
+
+
+def _grads_for(params: List[torch.Tensor], grads: dict):
+    return tuple(grads.get(p) for p in params)
+
+
+class GruHeadFn(torch.autograd.Function):
+    """Stand-alone differentiable ConvGRUDecoder call on NCHW images (used by the reference-compatible head API)."""
+
+    @staticmethod
+    def forward(ctx, head, ps, before, after, *params):
+        bh = before.detach().permute(0, 2, 3, 1).contiguous()
+        ah = after.detach().permute(0, 2, 3, 1).contiguous()
+        flow, sv = head.run(img(bh), img(ah), ps, True)
+        ctx.head, ctx.ps, ctx.sv, ctx.shape, ctx.params = head, ps, sv, bh.shape, list(params)
+        return flow
+
+    @staticmethod
+    def backward(ctx, dflow):
+        head, ps = ctx.head, ctx.ps
+        B, H, W, _ = ctx.shape
+        dev = dflow.device
+        db = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+        da = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+        grads: dict = {}
+        head.run_backward(dflow, ps, ctx.sv, img(db), img(da), False, False, grads)
+        ctx.sv = None
+        return (None, None, db.permute(0, 3, 1, 2), da.permute(0, 3, 1, 2)) + _grads_for(ctx.params, grads)
+
+
+class DeFlowFn(torch.autograd.Function):
+    """The whole hot path as one autograd node: pillarise both clouds -> UNet -> decoder, with a hand-sequenced
+    backward (decoder -> UNet -> pillar feature net).  Inputs: the ego-compensated pc0 and pc1 (no gradient) and
+    every parameter; output: padded flow [B,N,3]."""
+
+    @staticmethod
+    def forward(ctx, model, pc0s, pc1s, *params):
+        flow, state = model._run(pc0s, pc1s, train=True, save=True)
+        ctx.model, ctx.state, ctx.params = model, state, list(params)
+        model._state_tmp = state
+        return flow
+
+    @staticmethod
+    def backward(ctx, dflow):
+        model, st = ctx.model, ctx.state
+        grads: dict = {}
+        bstar = st["bstar"]
+        B, H, W, _ = bstar.shape
+        dev = bstar.device
+        dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+        dv = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+        # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
+        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads)
+        st["sv"] = None
+        # UNet: accumulates its own d(bstar) into the same buffer
+        model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads)
+        st["tape"] = None
+        # pillar feature net of both clouds (shared weights -> accumulate)
+        emb = model.embedder
+        g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)
+        g = emb.pillarize_bwd(st["p1"], img(dbstar, 32, 32), g)
+        grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
+        ctx.state = None
+        return (None, None, None) + _grads_for(ctx.params, grads)
+
+
+class DeflowLossFn(torch.autograd.Function):
+    """deflowLoss summed over the batch on the padded flow tensor (rows < counts[b])."""
+
+    @staticmethod
+    def forward(ctx, est, gt, counts):
+        B, N, _ = est.shape
+        dev = est.device
+        nblk = max(1, min(256, (N + 255) // 256))
+        partial = torch.empty(B, nblk, 6, dtype=torch.float32, device=dev)
+        est_c, gt_c = est.contiguous(), gt.contiguous()
+        call("df_deflow_loss_fwd", ptr(est_c), ptr(gt_c), ptr(counts), B, N, ptr(partial), nblk, stream())
+        bins = torch.empty(B, 6, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        call("df_deflow_loss_finalize", ptr(partial), B, nblk, ptr(bins), ptr(loss), stream())
+        ctx.save_for_backward(est_c, gt_c, counts, bins)
+        ctx.nblk = nblk
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        est, gt, counts, bins = ctx.saved_tensors
+        B, N, _ = est.shape
+        dest = torch.empty_like(est)
+        g = gloss.reshape(1).contiguous().float()
+        call("df_deflow_loss_bwd", ptr(est), ptr(gt), ptr(counts), B, N, ptr(bins), ptr(g), 1.0, ptr(dest), ctx.nblk,
+             stream())
+        return dest, None, None

@@ -1,0 +1,48 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64, MFMA f32 32x32x2 / 16x16x4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/deflow_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DF_CHECK_LAUNCH()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+#define DF_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline bool df_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// element offset of image n inside an image set (see include/deflow_amd.h)
+__device__ __forceinline__ int64_t df_img_base(const df_img& d, int n) {
+  return (int64_t)(n % d.grp_size) * d.img_stride + (int64_t)(n / d.grp_size) * d.grp_off;
+}
+
+// XCD-aware, bijective remap of a 1-D grid: block b runs on XCD b % 8 (observed, speed only);
+// give every XCD one contiguous range of logical tiles so neighbouring tiles share an L2.
+__device__ __forceinline__ int df_xcd_swizzle(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + (bid >> 3);
+}
+
+__device__ __forceinline__ float df_gelu(float x) {  // exact-erf GELU [REF decoder.py:209]
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float df_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float df_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -1,0 +1,480 @@
+// BEV convolutions for the FastFlow3D UNet ([REF deflow.py:87-88]; block [REF decoder.py:202-220]).
+//
+// fp32 implicit GEMM on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 (exact f32, 64 cyc / SIMD,
+// 157 TFLOP/s chip peak).  Activations are NHWC so the reduction axis (input channels) is
+// contiguous: a tile row is one 128-byte run of 32 channels of one (shifted) pixel.
+//
+//   conv_kernel   y[m, co] = sum_{tap, ci} x[pix(m, tap), ci] * w[co, tap, ci]      (fwd and dgrad)
+//   wgrad_kernel  dw[co, tap, ci] = sum_m dy[m, co] * x[pix(m, tap), ci]            (split over m)
+//
+// LDS tiles are [row][32 + 4 pad] floats; fragments are fetched with ds_read_b128 (conflict-free
+// with the 144-byte row pitch) by permuting k inside each group of 8: MFMA step s of group g uses
+// k = 8g + s on lanes 0-31 and k = 8g + 4 + s on lanes 32-63 for BOTH operands, so one b128 read
+// feeds four MFMA steps.  Global->LDS goes through registers, issued one stage ahead (T14).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDT = BK + 4;  // LDS row pitch (floats)
+
+struct ConvParams {
+  df_img x, y;
+  const float* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* stats;
+  int ks, stride, pad, mode, epi, accumulate;
+  int M, K, N, tiles_m, tiles_n, hw_y;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
+  constexpr int TM = BM / WM / 32;  // 32x32 MFMA tiles per wave along m
+  constexpr int TN = BN / WN / 32;
+  constexpr int RA = BM / 32;       // A rows staged per thread
+  constexpr int RB = BN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                     // [2][BM][LDT]
+  float* Bs = lds + 2 * BM * LDT;      // [2][BN][LDT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const float* __restrict__ xp = reinterpret_cast<const float*>(p.x.ptr);
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int taps = p.ks * p.ks;
+  const int KC = p.K / BK;
+
+  // per-thread description of the A rows it stages
+  int64_t abase[RA];
+  int ay[RA], ax[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      const int n = m / p.hw_y, rem = m - n * p.hw_y;
+      const int oy = rem / p.y.w, ox = rem - oy * p.y.w;
+      abase[i] = df_img_base(p.x, n);
+      if (p.mode == DF_CONV_FWD) {
+        ay[i] = oy * p.stride - p.pad;
+        ax[i] = ox * p.stride - p.pad;
+      } else {
+        ay[i] = oy + p.pad;
+        ax[i] = ox + p.pad;
+      }
+    } else {
+      abase[i] = -1;
+      ay[i] = ax[i] = 0;
+    }
+  }
+
+  f32x4 areg[RA], breg[RB];
+  auto load_stage = [&](int st) {
+    const int tap = st / KC, kc = st - tap * KC;
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy, ix;
+      bool ok = abase[i] >= 0;
+      if (p.mode == DF_CONV_FWD) {
+        iy = ay[i] + ky;
+        ix = ax[i] + kx;
+      } else {
+        const int ty = ay[i] - ky, tx = ax[i] - kx;
+        if (p.stride == 2) {
+          ok = ok && !((ty | tx) & 1);
+          iy = ty >> 1;
+          ix = tx >> 1;
+        } else {
+          iy = ty;
+          ix = tx;
+        }
+      }
+      ok = ok && iy >= 0 && iy < hx && ix >= 0 && ix < wx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = ld4(xp + abase[i] + ((int64_t)iy * wx + ix) * ldx + kc * BK + c4 * 4);
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int co = n0 + r0 + 32 * i;
+      breg[i] = ld4(p.w + ((int64_t)co * taps + tap) * p.K + kc * BK + c4 * 4);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* a = As + buf * BM * LDT;
+    float* b = Bs + buf * BN * LDT;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) st4(a + (r0 + 32 * i) * LDT + c4 * 4, areg[i]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) st4(b + (r0 + 32 * i) * LDT + c4 * 4, breg[i]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nst = taps * KC;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) load_stage(st + 1);
+    const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT + kh * 4;
+    const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT + kh * 4;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = ld4(a + i * 32 * LDT + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = ld4(b + j * 32 * LDT + g * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nst) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------
+  // LDS is free now: row -> output element offset table, then the stats scratch.
+  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);            // [BM]
+  float* red = lds + 2 * BM;                                    // [WM][BN][2]
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      const int n = m / p.hw_y, rem = m - n * p.hw_y;
+      off = df_img_base(p.y, n) + (int64_t)rem * p.y.ld;
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+  float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + li;
+    const float bia = p.bias ? p.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.epi == DF_EPI_BN_GELU) {
+      sc = p.scale[co];
+      sh = p.shift[co];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int64_t off = rowoff[row];
+        float v = acc[i][j][e] + bia;
+        if (off >= 0) {
+          if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+          if (p.accumulate) v += yp[off + co];
+          yp[off + co] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (p.epi == DF_EPI_STATS) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (kh == 0) {
+        const int cl = (wn * TN + j) * 32 + li;
+        red[(wm * BN + cl) * 2 + 0] = s1;
+        red[(wm * BN + cl) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.epi == DF_EPI_STATS) {
+    __syncthreads();
+    if (tid < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1 += red[(w * BN + tid) * 2 + 0];
+        s2 += red[(w * BN + tid) * 2 + 1];
+      }
+      float* o = p.stats + ((int64_t)tile_m * p.N + n0 + tid) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const ConvParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// ------------------------------------------------------------------------------- wgrad ---
+struct WgradParams {
+  df_img x, dy;
+  float* ws;  // [splits][N][taps][K]
+  const int32_t* row_counts;  // optional (1x1 only): pixel p of a row list is valid iff p % rows_per_seg < row_counts[p / rows_per_seg]
+  int rows_per_seg;
+  int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr int P = 32;                         // output pixels per chunk (one row segment)
+  constexpr int XW = (P - 1) * STRIDE + KS;     // input pixels needed per row
+  constexpr int TAPS = KS * KS;
+  constexpr int LC = 64;                        // channels per tile
+  __shared__ __attribute__((aligned(16))) float dYs[P * LC];
+  __shared__ __attribute__((aligned(16))) float Xs[KS * XW * LC];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int wci = wave & 1, wco = wave >> 1;
+  const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
+  const bool wave_active = (ci0 + wci * 32) < p.K;  // K == 32 leaves half of the ci tile empty
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const float* __restrict__ xp = reinterpret_cast<const float*>(p.x.ptr);
+  const float* __restrict__ dyp = reinterpret_cast<const float*>(p.dy.ptr);
+  const int hy = p.dy.h, wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int rowid = ch / p.chunks_per_row, seg = ch - rowid * p.chunks_per_row;
+    const int n = rowid / hy, oy = rowid - n * hy;
+    const int ox0 = seg * P;
+    const int64_t ybase = df_img_base(p.dy, n) + (int64_t)oy * wy * p.dy.ld;
+    const int64_t xbase = df_img_base(p.x, n);
+    // dY tile
+    for (int f = tid; f < P * (LC / 4); f += 256) {
+      const int px = f / (LC / 4), c4i = f - px * (LC / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok = ox0 + px < wy;
+      if (ok && p.row_counts) {
+        const int pp = ox0 + px, sg = pp / p.rows_per_seg;
+        ok = (pp - sg * p.rows_per_seg) < p.row_counts[sg];
+      }
+      if (ok) v = ld4(dyp + ybase + (int64_t)(ox0 + px) * p.dy.ld + co0 + c4i * 4);
+      st4(dYs + px * LC + c4i * 4, v);
+    }
+    // X patch
+    for (int f = tid; f < KS * XW * (LC / 4); f += 256) {
+      const int c4i = f % (LC / 4);
+      const int q = f / (LC / 4);
+      const int xi = q % XW, ky = q / XW;
+      const int iy = oy * STRIDE + ky - p.pad;
+      const int ix = ox0 * STRIDE + xi - p.pad;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok = iy >= 0 && iy < hx && ix >= 0 && ix < wx && ci0 + c4i * 4 < p.K;
+      if (ok && p.row_counts) {
+        const int sg = ix / p.rows_per_seg;
+        ok = (ix - sg * p.rows_per_seg) < p.row_counts[sg];
+      }
+      if (ok)
+        v = ld4(xp + xbase + ((int64_t)iy * wx + ix) * p.x.ld + ci0 + c4i * 4);
+      st4(Xs + (ky * XW + xi) * LC + c4i * 4, v);
+    }
+    __syncthreads();
+    if (wave_active) {
+#pragma unroll 4
+      for (int ks = 0; ks < P / 2; ++ks) {
+        const int px = 2 * ks + kh;
+        const float a = dYs[px * LC + wco * 32 + li];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float b = Xs[(ky * XW + px * STRIDE + kx) * LC + wci * 32 + li];
+            acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * KS + kx], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave_active) {
+    float* o = p.ws + (int64_t)split * p.N * TAPS * p.K;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * TAPS + t) * p.K + ci] = acc[t][e];
+      }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int64_t per_split, int row_len,
+                                    float* __restrict__ dw, int64_t ld_co, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_split) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * per_split + i];
+  const int64_t co = i / row_len, r = i - co * row_len;
+  float* o = dw + co * ld_co + r;
+  *o = accumulate ? (*o + s) : s;
+}
+
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int taps,
+                                        int cin) {
+  // wt[ci][t][co] = w[co][t][ci]; one thread per output element (co fastest => coalesced writes)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)cout * taps * cin;
+  if (i >= total) return;
+  const int co = (int)(i % cout);
+  const int64_t q = i / cout;
+  const int t = (int)(q % taps), ci = (int)(q / taps);
+  wt[i] = w[((int64_t)co * taps + t) * cin + ci];
+}
+
+bool img_ok(const df_img& d) {
+  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.grp_size > 0 &&
+         (d.n % d.grp_size) == 0 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 && (d.grp_off % 4) == 0;
+}
+
+}  // namespace
+
+extern "C" int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout) {
+  (void)cout;
+  return (rows_per_stat_group % 128 == 0) ? 128 : 64;
+}
+
+extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
+                         int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                         int accumulate, void* stream) {
+  DF_REQUIRE(img_ok(x) && img_ok(y) && w && df_aligned16(w), DF_E_ALIGN);
+  DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
+  DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
+  DF_REQUIRE(mode == DF_CONV_FWD || mode == DF_CONV_DGRAD, DF_E_ARG);
+  DF_REQUIRE(epi >= 0 && epi <= 2, DF_E_ARG);
+  DF_REQUIRE(x.c % BK == 0 && y.c % 32 == 0, DF_E_SHAPE);
+  if (mode == DF_CONV_FWD) {
+    DF_REQUIRE(y.h == (x.h + 2 * pad - ksize) / stride + 1 && y.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
+  } else {
+    DF_REQUIRE(x.h == (y.h + 2 * pad - ksize) / stride + 1 && x.w == (y.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
+  }
+  if (epi == DF_EPI_BN_GELU) DF_REQUIRE(scale && shift, DF_E_ARG);
+  ConvParams p;
+  p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
+  p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
+  p.hw_y = y.h * y.w;
+  const int64_t M = (int64_t)y.n * p.hw_y;
+  DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
+  p.M = (int)M; p.K = x.c; p.N = y.c;
+  const int64_t rows_per_group = (int64_t)y.grp_size * p.hw_y;
+  int bm = 128;
+  if (epi == DF_EPI_STATS) {
+    DF_REQUIRE(stats_partial, DF_E_ARG);
+    bm = df_conv2d_tile_m(rows_per_group, y.c);
+    DF_REQUIRE(rows_per_group % bm == 0, DF_E_SHAPE);
+  } else if (M <= 128 * 256) {
+    bm = 64;  // small problems: more tiles to fill 256 CUs
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((p.N % 64) != 0) {  // 32 output channels (input-gradient of the first encoder conv)
+    DF_REQUIRE(epi != DF_EPI_STATS || rows_per_group % 128 == 0, DF_E_SHAPE);
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 32;
+    return launch_conv<128, 32, 4, 1>(p, s);
+  }
+  if (bm == 128 && (p.N % 128) == 0) {
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 128;
+    return launch_conv<128, 128, 2, 2>(p, s);
+  } else if (bm == 128) {
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 64;
+    return launch_conv<128, 64, 2, 2>(p, s);
+  } else {
+    p.tiles_m = (p.M + 63) / 64; p.tiles_n = p.N / 64;
+    return launch_conv<64, 64, 2, 2>(p, s);
+  }
+}
+
+extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
+  (void)ksize; (void)stride;
+  const int tiles = ((x.c + 63) / 64) * (dy.c / 64);
+  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + 31) / 32);
+  int64_t splits = (1024 + tiles - 1) / tiles;
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  // make every split non-empty
+  const int64_t cps = (chunks + splits - 1) / splits;
+  splits = (chunks + cps - 1) / cps;
+  return (int)splits;
+}
+
+extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
+                               const int32_t* row_counts, int rows_per_seg, void* stream) {
+  DF_REQUIRE(!row_counts || (ksize == 1 && x.h == 1 && rows_per_seg > 0), DF_E_ARG);
+  DF_REQUIRE(img_ok(x) && img_ok(dy) && ws && df_aligned16(ws), DF_E_ALIGN);
+  DF_REQUIRE(x.n == dy.n && x.c % 32 == 0 && dy.c % 64 == 0, DF_E_SHAPE);
+  DF_REQUIRE((ksize == 1 && stride == 1 && pad == 0) || (ksize == 3 && pad == 1 && (stride == 1 || stride == 2)), DF_E_SHAPE);
+  DF_REQUIRE(dy.h == (x.h + 2 * pad - ksize) / stride + 1 && dy.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1; p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
+  p.chunks_per_row = (dy.w + 31) / 32;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
+  else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw,
+                                      int64_t ld_co, int accumulate, void* stream) {
+  DF_REQUIRE(ws && dw && splits >= 1, DF_E_ARG);
+  const int64_t per = (int64_t)cout * taps * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), ws, splits, per, taps * cin, dw, ld_co, accumulate);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, void* stream) {
+  DF_REQUIRE(w && wt, DF_E_ARG);
+  const int64_t total = (int64_t)cout * taps * cin;
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, wt, cout, taps, cin);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

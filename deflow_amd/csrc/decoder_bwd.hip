@@ -1,0 +1,345 @@
+// Backward of the point decoder ([REF decoder.py:123-199] differentiated).
+//
+//   gru_bwd_kernel    data gradients of MLP head + num_iters GRU steps for 64 points per workgroup; same
+//                     structure as the forward (state in C-layout registers, wave-private LDS A operand,
+//                     streamed TRANSPOSED weights).  Gate pre-activation gradients overwrite the saved
+//                     z / r / q planes in place; the weight gradients are then plain split-K GEMMs over
+//                     those planes (df_conv2d_wgrad, 1x1 mode).
+//   gather_bwd_kernel the reference's backward of img[:, y, x] is an atomic scatter-add with duplicate
+//                     indices; here each BEV cell sums the rows of its own points (the pillar sort already
+//                     made them contiguous) -- deterministic, every gradient pixel written exactly once.
+//   small_outer       tiny [na x nb] outer-product reductions over valid rows (offset encoder, last Linear,
+//                     bias gradients).
+#include "common.h"
+#include "gemm_stream.h"
+
+namespace {
+
+using namespace gs;
+
+constexpr int LDA_B = 260;          // [256 | pad] floats; 65 slots of 16 B, 65 mod 16 = 1
+constexpr int BS_B = 192 * LDB;     // B buffer: 192 weight rows
+
+struct GruBwdParams {
+  const float* dflow;
+  const float* offs;
+  const int32_t* counts;
+  int N, T;
+  df_gru_weights w;
+  df_gru_weights_t wt;
+  float* save;
+  int64_t plane_stride, iter_stride;
+  float* dh0;
+  float* dx;
+  float* dpre1;
+  float* hid;
+  float* xout;
+};
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Bs = lds;                 // [2][192][36]
+  float* As = lds + 2 * BS_B;      // [4][16][LDA_B]
+  const int b = blockIdx.y;
+  const int cnt = p.counts[b];
+  const int p0 = blockIdx.x * 64;
+  if (p0 >= cnt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  float* Aw = As + wave * 16 * LDA_B;
+  const int wp0 = p0 + wave * 16;
+  const int64_t grow0 = (int64_t)b * p.N + wp0;
+  const float* a_lane = Aw + li * LDA_B + lq * 4;
+
+  Stager stg;
+  int par = 0;
+  stage_load<32>(stg, p.w.w_1, 192, 0);
+
+  // coalesced 16 x 128 block copies between global rows and LDS columns [col0, col0 + 128)
+  auto rows_to_lds = [&](const float* src, int col0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = lane + 64 * j;
+      const int pt = f >> 5, c4 = f & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wp0 + pt < cnt) v = ld4(src + (grow0 + pt) * 128 + c4 * 4);
+      st4(Aw + pt * LDA_B + col0 + c4 * 4, v);
+    }
+  };
+  auto lds_to_rows = [&](float* dst, int col0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = lane + 64 * j;
+      const int pt = f >> 5, c4 = f & 31;
+      if (wp0 + pt < cnt) st4(dst + (grow0 + pt) * 128 + c4 * 4, ld4(Aw + pt * LDA_B + col0 + c4 * 4));
+    }
+  };
+  auto lds_to_c = [&](f32x4 (&v)[8], int col0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[t][r] = Aw[(4 * lq + r) * LDA_B + col0 + 16 * t + li];
+  };
+  auto c_to_lds = [&](const f32x4 (&v)[8], int col0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Aw[(4 * lq + r) * LDA_B + col0 + 16 * t + li] = v[t][r];
+  };
+
+  // ---- [h_T | x] -> A region; x also to global for the weight-gradient GEMMs -------------------
+  rows_to_lds(p.save + 5 * p.plane_stride, 0);
+  {
+    const float w0 = p.w.w_off[lane * 3 + 0], w1 = p.w.w_off[lane * 3 + 1], w2 = p.w.w_off[lane * 3 + 2];
+    const float bo = p.w.b_off[lane];
+    for (int pt = 0; pt < 16; ++pt) {
+      float x = 0.f;
+      if (wp0 + pt < cnt) {
+        const float* o = p.offs + (grow0 + pt) * 3;
+        x = fmaf(w2, o[2], fmaf(w1, o[1], fmaf(w0, o[0], bo)));
+        p.xout[(grow0 + pt) * 64 + lane] = x;
+      }
+      Aw[pt * LDA_B + 128 + lane] = x;
+    }
+  }
+  stage_store<32>(stg, Bs);
+  __syncthreads();
+
+  // ---- MLP head backward -----------------------------------------------------------------------
+  f32x4 pre1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float bia = p.w.b_1[16 * t + li];
+    pre1[t] = f32x4{bia, bia, bia, bia};
+  }
+  gemm_stream<32, 192, BS_B>(p.w.w_1, 192, 6, p.wt.wt_1, 32, a_lane, Bs, par, pre1, stg);
+  {
+    float df[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) df[r][o] = (wp0 + 4 * lq + r < cnt) ? p.dflow[(grow0 + 4 * lq + r) * 3 + o] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = 16 * t + li;
+      const float w20 = p.w.w_2[0 * 32 + col], w21 = p.w.w_2[1 * 32 + col], w22 = p.w.w_2[2 * 32 + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pre = pre1[t][r];
+        const float dhid = df[r][0] * w20 + df[r][1] * w21 + df[r][2] * w22;
+        const float dp = dhid * df_gelu_grad(pre);
+        if (wp0 + 4 * lq + r < cnt) {
+          p.hid[(grow0 + 4 * lq + r) * 32 + col] = df_gelu(pre);
+          p.dpre1[(grow0 + 4 * lq + r) * 32 + col] = dp;
+        }
+        Aw[(4 * lq + r) * LDA_B + col] = dp;  // A operand of the next GEMM (cols 0..31)
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 dh[8], dxa[4];
+  {
+    f32x4 acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_stream<192, 192, BS_B>(p.wt.wt_1, 32, 1, p.wt.wt_q, 128, a_lane, Bs, par, acc, stg);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dh[t] = acc[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dxa[t] = acc[8 + t];
+  }
+
+  // ---- GRU steps in reverse --------------------------------------------------------------------
+  for (int it = p.T - 1; it >= 0; --it) {
+    float* pl_h = p.save + 0 * p.plane_stride + it * p.iter_stride;
+    float* pl_z = p.save + 1 * p.plane_stride + it * p.iter_stride;
+    float* pl_r = p.save + 2 * p.plane_stride + it * p.iter_stride;
+    float* pl_q = p.save + 3 * p.plane_stride + it * p.iter_stride;
+    f32x4 h[8], z[8], r[8], q[8];
+    rows_to_lds(pl_h, 0);
+    rows_to_lds(pl_z, 128);
+    __syncthreads();
+    lds_to_c(h, 0);
+    lds_to_c(z, 128);
+    __syncthreads();
+    rows_to_lds(pl_r, 0);
+    rows_to_lds(pl_q, 128);
+    __syncthreads();
+    lds_to_c(r, 0);
+    lds_to_c(q, 128);
+    __syncthreads();
+    // h' = (1 - z) h + z q
+    f32x4 dzp[8], dhc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = dh[t][k];
+        dzp[t][k] = d * (q[t][k] - h[t][k]) * z[t][k] * (1.f - z[t][k]);  // dz_pre
+        dhc[t][k] = d * (1.f - z[t][k]);
+        q[t][k] = d * z[t][k] * (1.f - q[t][k] * q[t][k]);                 // dq_pre (q no longer needed)
+      }
+    c_to_lds(q, 0);
+    __syncthreads();
+    lds_to_rows(pl_q, 0);  // dq_pre replaces q
+    f32x4 acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_stream<192, 192, BS_B>(p.wt.wt_q, 128, 4, p.wt.wt_zr, 256, a_lane, Bs, par, acc, stg);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dxa[t] += acc[8 + t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float drh = acc[t][k];
+        dhc[t][k] += drh * r[t][k];
+        r[t][k] = drh * h[t][k] * r[t][k] * (1.f - r[t][k]);  // dr_pre
+      }
+    c_to_lds(dzp, 0);
+    c_to_lds(r, 128);
+    __syncthreads();
+    lds_to_rows(pl_z, 0);    // dz_pre replaces z
+    lds_to_rows(pl_r, 128);  // dr_pre replaces r
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it > 0) gemm_stream<192, 192, BS_B>(p.wt.wt_zr, 256, 8, p.wt.wt_q, 128, a_lane, Bs, par, acc, stg);
+    else gemm_stream<192, 192, BS_B>(p.wt.wt_zr, 256, 8, nullptr, 0, a_lane, Bs, par, acc, stg);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dh[t] = dhc[t] + acc[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dxa[t] += acc[8 + t];
+  }
+  // ---- outputs: dh0 [rows,128], dx [rows,64] -----------------------------------------------------
+  c_to_lds(dh, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Aw[(4 * lq + k) * LDA_B + 128 + 16 * t + li] = dxa[t][k];
+  __syncthreads();
+  lds_to_rows(p.dh0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = lane + 64 * j;
+    const int pt = f >> 4, c4 = f & 15;
+    if (wp0 + pt < cnt) st4(p.dx + (grow0 + pt) * 64 + c4 * 4, ld4(Aw + pt * LDA_B + 128 + c4 * 4));
+  }
+}
+
+// ------------------------------------------------------------------------------ gather bwd ---
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ dh0,
+                                                         const uint32_t* __restrict__ idx_sorted,
+                                                         const int32_t* __restrict__ cell_rng,
+                                                         const int32_t* __restrict__ cpos, int N, int ncell,
+                                                         df_img dbefore, df_img dafter, int acc_before, int acc_after) {
+  const int b = blockIdx.y, sub = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float* __restrict__ bp = reinterpret_cast<float*>(dbefore.ptr) + df_img_base(dbefore, b);
+  float* __restrict__ ap = reinterpret_cast<float*>(dafter.ptr) + df_img_base(dafter, b);
+  for (int cell = blockIdx.x * 8 + grp; cell < ncell; cell += gridDim.x * 8) {
+    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int i = s; i < e; ++i) {
+      const uint32_t flat = idx_sorted[i];  // b * N + n
+      const int cp = cpos[flat];
+      a += ld4(dh0 + ((int64_t)b * N + cp) * 128 + sub * 4);
+    }
+    if (sub < 16) {
+      float* o = bp + (int64_t)cell * dbefore.ld + sub * 4;
+      if (acc_before) a += ld4(o);
+      st4(o, a);
+    } else {
+      float* o = ap + (int64_t)cell * dafter.ld + (sub - 16) * 4;
+      if (acc_after) a += ld4(o);
+      st4(o, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ small outer ---
+// partial[blk][i*nb + j] = sum over the block's valid rows of a[row][i] * (b ? b[row][j] : 1)
+__global__ __launch_bounds__(256) void small_outer_kernel(const float* __restrict__ a, int lda, int na,
+                                                          const float* __restrict__ bmat, int ldb, int nb,
+                                                          const int32_t* __restrict__ counts, int rows_per_seg, int nseg,
+                                                          int64_t rows, int64_t rows_per_blk, float* __restrict__ partial) {
+  const int nout = na * nb;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r_end = min(r_begin + rows_per_blk, rows);
+  // threads beyond nout split the rows further: lanes = 256 / nout row lanes (>= 1)
+  const int row_lanes = max(256 / nout, 1);
+  const int o = threadIdx.x % nout, rl = threadIdx.x / nout;
+  __shared__ float red[256];
+  float acc = 0.f;
+  if (rl < row_lanes) {
+    const int i = o / nb, j = o - i * nb;
+    for (int64_t r = r_begin + rl; r < r_end; r += row_lanes) {
+      const int64_t segi = r / rows_per_seg;
+      const int within = (int)(r - segi * rows_per_seg);
+      if (within >= counts[(int)(segi % nseg)]) continue;
+      const float av = a[r * lda + i];
+      acc += bmat ? av * bmat[r * ldb + j] : av;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < nout) {
+    float s = 0.f;
+    for (int k = 0; k < row_lanes; ++k) s += red[k * nout + threadIdx.x];
+    partial[(int64_t)blockIdx.x * nout + threadIdx.x] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N,
+                                  int num_iters, df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0,
+                                  float* dx, float* dpre1, float* hid, float* xout, void* stream) {
+  DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && hid && xout && B > 0 && N > 0 && num_iters >= 1,
+             DF_E_ARG);
+  DF_REQUIRE(wts.w_off && wts.b_off && wts.w_1 && wts.b_1 && wts.w_2 && wtt.wt_zr && wtt.wt_q && wtt.wt_1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(wts.w_1) && df_aligned16(wtt.wt_zr) && df_aligned16(wtt.wt_q) && df_aligned16(wtt.wt_1) &&
+                 df_aligned16(save) && df_aligned16(dh0) && df_aligned16(dx),
+             DF_E_ALIGN);
+  GruBwdParams p;
+  p.dflow = dflow; p.offs = offs; p.counts = counts; p.N = N; p.T = num_iters; p.w = wts; p.wt = wtt; p.save = save;
+  p.iter_stride = (int64_t)B * N * 128;
+  p.plane_stride = p.iter_stride * num_iters;
+  p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.hid = hid; p.xout = xout;
+  const size_t lds_bytes = (size_t)(2 * BS_B + 4 * 16 * LDA_B) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
+                             int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
+                             int nblk, void* stream) {
+  DF_REQUIRE(dh0 && idx_sorted && cell_rng && cpos && dbefore.ptr && dafter.ptr && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(dbefore.n == B && dafter.n == B && dbefore.c == 64 && dafter.c == 64 && dbefore.h == dafter.h &&
+                 dbefore.w == dafter.w && (dbefore.ld % 4) == 0 && (dafter.ld % 4) == 0,
+             DF_E_SHAPE);
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dh0,
+                     idx_sorted, cell_rng, cpos, N, dbefore.h * dbefore.w, dbefore, dafter, accumulate_before,
+                     accumulate_after);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_small_outer(const float* a, int lda, int na, const float* b, int ldb, int nb, const int32_t* counts,
+                              int rows_per_seg, int nseg, int64_t rows, float* partial, int nblk, void* stream) {
+  DF_REQUIRE(a && counts && partial && na > 0 && nb > 0 && na * nb <= 256 && rows > 0 && nblk > 0 && rows_per_seg > 0 &&
+                 nseg > 0,
+             DF_E_ARG);
+  const int64_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(small_outer_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, lda, na, b,
+                     ldb, nb, counts, rows_per_seg, nseg, rows, rpb, partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

@@ -1,0 +1,428 @@
+// HBM-bound companions of the convolutions: BatchNorm2d statistics / normalise+GELU (forward and
+// backward), per-channel column sums, bilinear x2 resampling.  All NHWC, 16 B per lane, fully
+// coalesced; reductions are two-stage (per-block fp32 partials -> fp64 finalize) and therefore
+// deterministic (no float atomics).  Semantics follow torch.nn.BatchNorm2d / nn.GELU() /
+// F.interpolate(mode="bilinear") as used by ConvWithNorms [REF decoder.py:202-220] and the UNet.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ BN finalize ---------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_per_group,
+                                                          int groups, int C, double count, const float* gamma,
+                                                          const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var,
+                                                          float* __restrict__ bn_ss) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  for (int g = 0; g < groups; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+      for (int t = tl; t < tiles_per_group; t += 8) {
+        const float* q = partial + (((int64_t)g * tiles_per_group + t) * C + c) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
+      }
+    }
+    red[0][tl][cl] = s1;
+    red[1][tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+      for (int k = 1; k < 8; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+      }
+      const double mean = s1 / count;
+      double var = s2 / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)eps);
+      const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+      float* o = bn_ss + (int64_t)g * 4 * C;
+      o[0 * C + c] = (float)(ga * invstd);
+      o[1 * C + c] = (float)(be - mean * ga * invstd);
+      o[2 * C + c] = (float)mean;
+      o[3 * C + c] = (float)invstd;
+      if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ BN+GELU apply -------
+__global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const float* __restrict__ y, const float* __restrict__ bn_ss,
+                                                            int imgs_per_group, df_img z, int64_t total4) {
+  const int C4 = z.c >> 2;
+  const int hw = z.h * z.w;
+  float* __restrict__ zp = reinterpret_cast<float*>(z.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
+    const f32x4 v = ld4(y + m * z.c + c), sc = ld4(ss + c), sh = ld4(ss + z.c + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = df_gelu(v[k] * sc[k] + sh[k]);
+    st4(zp + df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
+  }
+}
+
+// block layout shared by the row-partitioned channel reductions: C/4 channel lanes x 256/(C/4) row lanes
+struct RowPart {
+  int c, row_lane, row_lanes;
+};
+__device__ __forceinline__ RowPart row_part(int C) {
+  const int C4 = C >> 2;
+  RowPart r;
+  r.c = (threadIdx.x % C4) * 4;
+  r.row_lane = threadIdx.x / C4;
+  r.row_lanes = 256 / C4;
+  return r;
+}
+// reduce NV float4 accumulators across the row lanes of the block; result valid on row_lane == 0
+template <int NV>
+__device__ __forceinline__ void block_reduce_rows(f32x4 (&acc)[NV], const RowPart& rp, float* lds /*[256*4*NV]*/) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) st4(lds + (v * 256 + threadIdx.x) * 4, acc[v]);
+  __syncthreads();
+  if (rp.row_lane == 0) {
+    const int C4 = 256 / rp.row_lanes;
+    for (int k = 1; k < rp.row_lanes; ++k)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const f32x4 t = ld4(lds + (v * 256 + k * C4 + threadIdx.x) * 4);
+        acc[v] += t;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ BN+GELU backward ----
+// pass 1: partial[blk][c][2] = sum over the block's rows of (dyh, dyh * xhat)
+__global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, const float* __restrict__ y,
+                                                                 const float* __restrict__ bn_ss, int imgs_per_group,
+                                                                 float* __restrict__ partial, int64_t rows,
+                                                                 int64_t rows_per_blk) {
+  __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 2];
+  const int C = dz.c, hw = dz.h * dz.w;
+  const RowPart rp = row_part(C);
+  const float* __restrict__ dzp = reinterpret_cast<const float*>(dz.ptr);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r_end = min(r_begin + rows_per_blk, rows);
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (r_begin < rows) {
+    const int g = (int)(r_begin / hw) / imgs_per_group;
+    const float* ss = bn_ss + (int64_t)g * 4 * C;
+    const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
+    for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
+      const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+      const f32x4 g4 = ld4(dzp + df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
+      const f32x4 yv = ld4(y + m * C + rp.c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float yh = yv[k] * sc[k] + sh[k];
+        const float d = g4[k] * df_gelu_grad(yh);
+        acc[0][k] += d;
+        acc[1][k] += d * ((yv[k] - mu[k]) * is[k]);
+      }
+    }
+  }
+  block_reduce_rows<2>(acc, rp, lds);
+  if (rp.row_lane == 0) {
+    float* o = partial + ((int64_t)blockIdx.x * C + rp.c) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k * 2 + 0] = acc[0][k];
+      o[k * 2 + 1] = acc[1][k];
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk_per_group, int groups, int C,
+                                       double count, float* dgamma, float* dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk_per_group; ++b) {
+      const float* q = partial + (((int64_t)g * nblk_per_group + b) * C + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+    coef[((int64_t)g * 2 + 0) * C + c] = (float)(s1 / count);
+    coef[((int64_t)g * 2 + 1) * C + c] = (float)(s2 / count);
+    tb += s1;
+    tg += s2;
+  }
+  if (dgamma) dgamma[c] = (float)tg;
+  if (dbeta) dbeta[c] = (float)tb;
+}
+
+// pass 2: dy = scale * (dyh - c1 - xhat * c2); dbias partial = column sums of dy
+__global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const float* __restrict__ y,
+                                                                const float* __restrict__ bn_ss,
+                                                                const float* __restrict__ coef, int imgs_per_group,
+                                                                float* __restrict__ dy, float* __restrict__ dbias_partial,
+                                                                int64_t rows, int64_t rows_per_blk) {
+  __shared__ __attribute__((aligned(16))) float lds[256 * 4];
+  const int C = dz.c, hw = dz.h * dz.w;
+  const RowPart rp = row_part(C);
+  const float* __restrict__ dzp = reinterpret_cast<const float*>(dz.ptr);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r_end = min(r_begin + rows_per_blk, rows);
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  if (r_begin < rows) {
+    const int g = (int)(r_begin / hw) / imgs_per_group;
+    const float* ss = bn_ss + (int64_t)g * 4 * C;
+    const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
+    const f32x4 c1 = ld4(coef + ((int64_t)g * 2 + 0) * C + rp.c), c2 = ld4(coef + ((int64_t)g * 2 + 1) * C + rp.c);
+    for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
+      const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+      const f32x4 g4 = ld4(dzp + df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
+      const f32x4 yv = ld4(y + m * C + rp.c);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float yh = yv[k] * sc[k] + sh[k];
+        const float d = g4[k] * df_gelu_grad(yh);
+        const float xh = (yv[k] - mu[k]) * is[k];
+        o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
+        acc[0][k] += o[k];
+      }
+      st4(dy + m * C + rp.c, o);
+    }
+  }
+  if (dbias_partial) {
+    block_reduce_rows<1>(acc, rp, lds);
+    if (rp.row_lane == 0) st4(dbias_partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
+  }
+}
+
+// ------------------------------------------------------------------ column sums ---------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(df_img x, float* __restrict__ partial, int64_t rows,
+                                                             int64_t rows_per_blk) {
+  __shared__ __attribute__((aligned(16))) float lds[256 * 4];
+  const int C = x.c, hw = x.h * x.w;
+  const RowPart rp = row_part(C);
+  const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+  const int64_t r_end = min(r_begin + rows_per_blk, rows);
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
+    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    acc[0] += ld4(xp + df_img_base(x, n) + (int64_t)pix * x.ld + rp.c);
+  }
+  block_reduce_rows<1>(acc, rp, lds);
+  if (rp.row_lane == 0) st4(partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int total, float* out,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * total + i];
+  out[i] = accumulate ? (float)((double)out[i] + s) : (float)s;
+}
+
+// ------------------------------------------------------------------ bilinear x2 ---------
+// PyTorch area_pixel_compute_source_index: align_corners ? dst*(in-1)/(out-1) : max((dst+0.5)*in/out-0.5, 0)
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_src(int dst, int in, int out, int align_corners) {
+  float src;
+  if (align_corners) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = sc * dst;
+  } else {
+    src = ((float)dst + 0.5f) * ((float)in / (float)out) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  Lerp r;
+  r.i0 = (int)src;
+  if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int align_corners, int64_t total4) {
+  const int C4 = y.c >> 2;
+  const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
+  float* __restrict__ yp = reinterpret_cast<float*>(y.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const int X = (int)(m % y.w);
+    m /= y.w;
+    const int Y = (int)(m % y.h), n = (int)(m / y.h);
+    const Lerp ly = lerp_src(Y, x.h, y.h, align_corners), lx = lerp_src(X, x.w, y.w, align_corners);
+    const float* b = xp + df_img_base(x, n) + c;
+    const f32x4 v00 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld), v01 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld);
+    const f32x4 v10 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i0) * x.ld), v11 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i1) * x.ld);
+    const f32x4 o = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    st4(yp + df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o);
+  }
+}
+
+// gather form of the transpose: every input pixel sums the <= 6x6 output pixels that read it
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(df_img dy, df_img dx, int align_corners, int64_t total4) {
+  const int C4 = dx.c >> 2;
+  const float* __restrict__ dyp = reinterpret_cast<const float*>(dy.ptr);
+  float* __restrict__ dxp = reinterpret_cast<float*>(dx.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const int xx = (int)(m % dx.w);
+    m /= dx.w;
+    const int yy = (int)(m % dx.h), n = (int)(m / dx.h);
+    float wy[6], wx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int Y = 2 * yy - 2 + k, X = 2 * xx - 2 + k;
+      wy[k] = 0.f;
+      wx[k] = 0.f;
+      if (Y >= 0 && Y < dy.h) {
+        const Lerp l = lerp_src(Y, dx.h, dy.h, align_corners);
+        wy[k] = (l.i0 == yy ? l.l0 : 0.f) + (l.i1 == yy ? l.l1 : 0.f);
+      }
+      if (X >= 0 && X < dy.w) {
+        const Lerp l = lerp_src(X, dx.w, dy.w, align_corners);
+        wx[k] = (l.i0 == xx ? l.l0 : 0.f) + (l.i1 == xx ? l.l1 : 0.f);
+      }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* b = dyp + df_img_base(dy, n) + c;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (wy[a] == 0.f) continue;
+      const int Y = 2 * yy - 2 + a;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (wx[k] == 0.f) continue;
+        const int X = 2 * xx - 2 + k;
+        acc += (wy[a] * wx[k]) * ld4(b + ((int64_t)Y * dy.w + X) * dy.ld);
+      }
+    }
+    st4(dxp + df_img_base(dx, n) + ((int64_t)yy * dx.w + xx) * dx.ld + c, acc);
+  }
+}
+
+bool img_ok(const df_img& d) {
+  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && (d.c % 4) == 0 && d.grp_size > 0 &&
+         (d.n % d.grp_size) == 0 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 && (d.grp_off % 4) == 0;
+}
+bool rowpart_ok(int C) { return C >= 4 && C <= 1024 && (C % 4) == 0 && (256 % (C / 4)) == 0; }
+unsigned grid_for(int64_t total, int per_block = 256, unsigned cap = 256 * 16) {
+  int64_t g = (total + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
+                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* bn_ss, void* stream) {
+  DF_REQUIRE(partial && bn_ss && tiles_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, DF_E_ARG);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     partial, tiles_per_group, groups, C, (double)count_per_group, gamma, beta, eps, momentum,
+                     running_mean, running_var, bn_ss);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
+  DF_REQUIRE(y && bn_ss && img_ok(z) && df_aligned16(y) && imgs_per_group > 0, DF_E_ARG);
+  const int64_t total4 = (int64_t)z.n * z.h * z.w * (z.c / 4);
+  hipLaunchKernelGGL(bn_gelu_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     y, bn_ss, imgs_per_group, z, total4);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_bn_gelu_bwd_reduce(df_img dz, const float* y, const float* bn_ss, int imgs_per_group, float* partial,
+                                     int nblk, void* stream) {
+  DF_REQUIRE(img_ok(dz) && y && bn_ss && partial && nblk > 0 && rowpart_ok(dz.c), DF_E_ARG);
+  const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
+  const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
+  DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
+  const int64_t rpb = rows / nblk;
+  DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);  // a block never straddles two stat groups
+  hipLaunchKernelGGL(bn_gelu_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz, y,
+                     bn_ss, imgs_per_group, partial, rows, rpb);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
+                                  float* dgamma, float* dbeta, float* coef, void* stream) {
+  DF_REQUIRE(partial && coef && nblk_per_group > 0 && groups > 0, DF_E_ARG);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                     partial, nblk_per_group, groups, C, (double)count_per_group, dgamma, dbeta, coef);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef,
+                                    int imgs_per_group, float* dy, float* dbias_partial, int nblk, void* stream) {
+  DF_REQUIRE(img_ok(dz) && y && bn_ss && coef && dy && nblk > 0 && rowpart_ok(dz.c), DF_E_ARG);
+  const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
+  const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
+  DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
+  const int64_t rpb = rows / nblk;
+  DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);
+  hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz, y,
+                     bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_colsum_partial(df_img x, float* partial, int nblk, void* stream) {
+  DF_REQUIRE(img_ok(x) && partial && nblk > 0 && rowpart_ok(x.c), DF_E_ARG);
+  const int64_t rows = (int64_t)x.n * x.h * x.w;
+  const int64_t rpb = (rows + nblk - 1) / nblk;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, partial,
+                     rows, rpb);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_colsum_finalize(const float* partial, int nblk, int C, int nvals, float* out, int accumulate,
+                                  void* stream) {
+  DF_REQUIRE(partial && out && nblk > 0 && C > 0 && nvals > 0, DF_E_ARG);
+  const int total = C * nvals;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), partial, nblk, total, out, accumulate);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream) {
+  DF_REQUIRE(img_ok(x) && img_ok(y), DF_E_ARG);
+  DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
+  const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     y, align_corners, total4);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* stream) {
+  DF_REQUIRE(img_ok(dx) && img_ok(dy), DF_E_ARG);
+  DF_REQUIRE(dx.n == dy.n && dx.c == dy.c && dy.h == 2 * dx.h && dy.w == 2 * dx.w, DF_E_SHAPE);
+  const int64_t total4 = (int64_t)dx.n * dx.h * dx.w * (dx.c / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dy, dx, align_corners, total4);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

@@ -1,0 +1,67 @@
+// Weight-streaming GEMM for the per-point decoder kernels (forward and backward).
+//
+// A workgroup of 4 waves multiplies each wave's private A operand (16 rows, resident in LDS) by a weight
+// matrix W[ROWS, K] that is streamed L2 -> registers -> LDS in 32-deep k chunks, double buffered and one
+// chunk ahead -- also across consecutive GEMMs (the last chunk of one GEMM prefetches the first chunk of
+// the next).  v_mfma_f32_16x16x4_f32; k permutation k = 16g + 4*(lane>>4) + s so every fragment fetch is
+// one ds_read_b128.
+#pragma once
+#include "common.h"
+
+namespace gs {
+
+constexpr int LDB = 36;          // B tile pitch (floats)
+constexpr int BROWS = 256;       // B tile rows (max)
+constexpr int BSZ = BROWS * LDB; // one B buffer (floats)
+
+struct Stager {
+  f32x4 r[8];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void stage_load(Stager& s, const float* __restrict__ W, int ldw, int chunk) {
+  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) s.r[i] = ld4(W + (int64_t)(r0 + 32 * i) * ldw + chunk * 32 + c4 * 4);
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_store(const Stager& s, float* Bbuf) {
+  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) st4(Bbuf + (r0 + 32 * i) * LDB + c4 * 4, s.r[i]);
+}
+
+// acc[t] (16 x 16 tile t of the wave's 16 x ROWS output) += A[16, 32*nchunks] * W[ROWS, 32*nchunks]^T.
+// Precondition: chunk 0 of W is in B buffer `par` and a barrier has been passed.  On return the first chunk
+// of Wnext (if any) is in buffer `par` (updated) and a barrier has been passed.
+template <int ROWS, int ROWS_NEXT, int BS = BSZ>
+__device__ __forceinline__ void gemm_stream(const float* __restrict__ W, int ldw, int nchunks,
+                                            const float* __restrict__ Wnext, int ldw_next, const float* a_lane,
+                                            float* Bs, int& par, f32x4 (&acc)[ROWS / 16], Stager& stg) {
+  const int lane = threadIdx.x & 63;
+  const float* b_lane = Bs + (lane & 15) * LDB + (lane >> 4) * 4;
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) stage_load<ROWS>(stg, W, ldw, c + 1);
+    else if (Wnext) stage_load<ROWS_NEXT>(stg, Wnext, ldw_next, 0);
+    const float* bb = b_lane + ((par + c) & 1) * BS;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 a = ld4(a_lane + c * 32 + g * 16);
+#pragma unroll
+      for (int t = 0; t < ROWS / 16; ++t) {
+        const f32x4 b = ld4(bb + t * 16 * LDB + g * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[t], 0, 0, 0);
+      }
+    }
+    float* nb = Bs + ((par + c + 1) & 1) * BS;
+    if (more) stage_store<ROWS>(stg, nb);
+    else if (Wnext) stage_store<ROWS_NEXT>(stg, nb);
+    __syncthreads();
+  }
+  par = (par + nchunks) & 1;
+}
+
+
+}  // namespace gs

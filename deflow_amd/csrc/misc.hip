@@ -1,0 +1,213 @@
+// Small HBM-bound kernels around the hot path: ego-motion compensation [REF deflow.py:60-77], the
+// deflowLoss reduction and its gradient (3 speed bins; OpenSceneFlow lossfuncs, source absent -- see
+// oracle/ref_torch.py), the trainer's gt construction, and Adam over one flat parameter arena.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ego_transform_kernel(const float* __restrict__ pc0, const float* __restrict__ T,
+                                                            int N, float* __restrict__ out, float* __restrict__ pflow) {
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* M = T + b * 16;
+  const float* p = pc0 + ((int64_t)b * N + n) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  float* o = out + ((int64_t)b * N + n) * 3;
+  float* f = pflow + ((int64_t)b * N + n) * 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    // pc0 @ R^T + t : sum_j p[j] * R[i][j], then the translation [REF deflow.py:72]
+    float a = __fmul_rn(x, M[i * 4 + 0]);
+    a = __fadd_rn(a, __fmul_rn(y, M[i * 4 + 1]));
+    a = __fadd_rn(a, __fmul_rn(z, M[i * 4 + 2]));
+    a = __fadd_rn(a, M[i * 4 + 3]);
+    o[i] = a;
+    f[i] = __fsub_rn(a, p[i]);
+  }
+}
+
+__device__ __forceinline__ bool row_finite(const float* a, const float* b) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ok = ok && isfinite(a[k]) && isfinite(b[k]);
+  return ok;
+}
+__device__ __forceinline__ int speed_bin(const float* gt) {
+  const float nrm = sqrtf(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
+  const float speed = __fdiv_rn(nrm, 0.1f);
+  return speed < 0.4f ? 0 : (speed <= 1.0f ? 1 : 2);
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                       const int32_t* __restrict__ counts, int N,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[4][6];
+  const int b = blockIdx.y, cnt = counts[b];
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const float* e = est + ((int64_t)b * N + i) * 3;
+    const float* g = gt + ((int64_t)b * N + i) * 3;
+    if (!row_finite(e, g)) continue;
+    const float dx = e[0] - g[0], dy = e[1] - g[1], dz = e[2] - g[2];
+    const float err = sqrtf(dx * dx + dy * dy + dz * dz);
+    const int bin = speed_bin(g);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (bin == k) {
+        acc[2 * k] += err;
+        acc[2 * k + 1] += 1.f;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[((int64_t)b * gridDim.x + blockIdx.x) * 6 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int B, int nblk, float* __restrict__ bins,
+                                     float* __restrict__ loss) {
+  // single thread: B * nblk * 6 values, deterministic order
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < nblk; ++k)
+      for (int j = 0; j < 6; ++j) s[j] += (double)partial[((int64_t)b * nblk + k) * 6 + j];
+    for (int j = 0; j < 6; ++j) bins[b * 6 + j] = (float)s[j];
+    for (int k = 0; k < 3; ++k)
+      if (s[2 * k + 1] > 0.0) total += s[2 * k] / s[2 * k + 1];
+  }
+  loss[0] = (float)total;
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                       const int32_t* __restrict__ counts, int N,
+                                                       const float* __restrict__ bins, const float* __restrict__ gscale_ptr,
+                                                       float gscale, float* __restrict__ dest) {
+  const int b = blockIdx.y, cnt = counts[b];
+  const float gs = gscale_ptr ? gscale * gscale_ptr[0] : gscale;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const float* e = est + ((int64_t)b * N + i) * 3;
+    const float* g = gt + ((int64_t)b * N + i) * 3;
+    float* d = dest + ((int64_t)b * N + i) * 3;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (row_finite(e, g)) {
+      const float dx = e[0] - g[0], dy = e[1] - g[1], dz = e[2] - g[2];
+      const float err = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float c = bins[b * 6 + 2 * speed_bin(g) + 1];
+      if (err > 0.f && c > 0.f) {
+        const float s = gs / (err * c);
+        o0 = dx * s;
+        o1 = dy * s;
+        o2 = dz * s;
+      }
+    }
+    d[0] = o0;
+    d[1] = o1;
+    d[2] = o2;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_gt_kernel(const float* __restrict__ flow, const float* __restrict__ pflow,
+                                                        const int64_t* __restrict__ idx_c,
+                                                        const int32_t* __restrict__ counts, int N,
+                                                        float* __restrict__ gt) {
+  const int b = blockIdx.y, cnt = counts[b];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const int64_t src = ((int64_t)b * N + idx_c[(int64_t)b * N + i]) * 3;
+    float* o = gt + ((int64_t)b * N + i) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = __fsub_rn(flow[src + k], pflow[src + k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gscale;
+      mm[k] = mm[k] + (gr - mm[k]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+      vv[k] = vv[k] * b2 + (1.f - b2) * gr * gr;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+      pp[k] = pp[k] - (lr / bc1) * (mm[k] / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    st4(p + i * 4, pp);
+    st4(m + i * 4, mm);
+    st4(v + i * 4, vv);
+  }
+}
+
+}  // namespace
+
+extern "C" int df_ego_transform(const float* pc0, const float* T, int B, int N, float* pc0_t, float* pose_flow,
+                                void* stream) {
+  DF_REQUIRE(pc0 && T && pc0_t && pose_flow && B > 0 && N > 0, DF_E_ARG);
+  hipLaunchKernelGGL(ego_transform_kernel, dim3((N + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     pc0, T, N, pc0_t, pose_flow);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_deflow_loss_fwd(const float* est, const float* gt, const int32_t* counts, int B, int N,
+                                  float* bins_partial, int nblk, void* stream) {
+  DF_REQUIRE(est && gt && counts && bins_partial && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), est, gt, counts,
+                     N, bins_partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_deflow_loss_finalize(const float* bins_partial, int B, int nblk, float* bins, float* loss,
+                                       void* stream) {
+  DF_REQUIRE(bins_partial && bins && loss && B > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), bins_partial, B,
+                     nblk, bins, loss);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_deflow_loss_bwd(const float* est, const float* gt, const int32_t* counts, int B, int N,
+                                  const float* bins, const float* gscale_dev, float gscale, float* dest, int nblk,
+                                  void* stream) {
+  DF_REQUIRE(est && gt && counts && bins && dest && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), est, gt, counts,
+                     N, bins, gscale_dev, gscale, dest);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_gather_gt(const float* flow, const float* pose_flow, const int64_t* idx_c, const int32_t* counts,
+                            int B, int N, float* gt, int nblk, void* stream) {
+  DF_REQUIRE(flow && pose_flow && idx_c && counts && gt && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(gather_gt_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), flow,
+                     pose_flow, idx_c, counts, N, gt);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                            float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  DF_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && (n % 4) == 0 && step >= 1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(param) && df_aligned16(grad) && df_aligned16(exp_avg) && df_aligned16(exp_avg_sq), DF_E_ALIGN);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int64_t n4 = n / 4;
+  int64_t grid = (n4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad,
+                     exp_avg, exp_avg_sq, n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_version(void) { return 100; }

@@ -1,0 +1,589 @@
+// Dynamic pillar featurisation: the MI355X replacement for mmcv's dynamic_voxelize +
+// dynamic_point_to_voxel (scatter) CUDA ops and the DynamicPillarFeatureNet / PointPillarsScatter
+// modules behind DynamicEmbedder ([REF deflow.py:27-30,82-83]; sources live in the absent
+// OpenSceneFlow submodule -- the algorithm restated here is documented in oracle/ref_torch.py).
+//
+// Formulation (no float atomics, deterministic):
+//   keys      per point: IEEE fp32 floor-divide voxel coords -> cell key b*H*W + y*W + x   (integer, bit-exact)
+//   compact   stable order-preserving compaction of the kept points (ballot/popcount ranks + block offsets)
+//   sort      stable LSD radix sort of (key, point index): a pillar's points become one contiguous run,
+//             ascending original index inside the run
+//   cells     dense [start, end) table per BEV cell from the sorted keys
+//   canvas    GATHER form of the scatter: 8 lanes own one cell, walk its run, compute the 9-d feature,
+//             Linear(9->32) + BN1d + ReLU, reduce, and write the cell's 32 floats (zeros for empty cells);
+//             every canvas byte is written exactly once, 128 B per cell, fully coalesced.
+// The canvas write (32*H*W*4 B per cloud) is >95 % of the stage's HBM bytes.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool voxelize(const df_pillar_geom& g, float px, float py, float pz, int& cx, int& cy) {
+  if (isnan(px) || isnan(py) || isnan(pz)) return false;
+  const float fx = floorf(__fdiv_rn(__fsub_rn(px, g.minx), g.vx));
+  const float fy = floorf(__fdiv_rn(__fsub_rn(py, g.miny), g.vy));
+  const float fz = floorf(__fdiv_rn(__fsub_rn(pz, g.minz), g.vz));
+  if (!(fx >= 0.f && fx < (float)g.gx)) return false;
+  if (!(fy >= 0.f && fy < (float)g.gy)) return false;
+  if (!(fz >= 0.f && fz < (float)g.gz)) return false;
+  cx = (int)fx;
+  cy = (int)fy;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void pillar_keys_kernel(const float* __restrict__ pts, int N, df_pillar_geom g,
+                                                          uint32_t invalid_key, uint32_t* __restrict__ key,
+                                                          int32_t* __restrict__ blk_cnt) {
+  __shared__ int wcnt[4];
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false;
+  if (n < N) {
+    const float* p = pts + ((int64_t)b * N + n) * 3;
+    int cx = 0, cy = 0;
+    valid = voxelize(g, p[0], p[1], p[2], cx, cy);
+    key[(int64_t)b * N + n] = valid ? (uint32_t)((b * g.gy + cy) * g.gx + cx) : invalid_key;
+  }
+  const unsigned long long bal = __ballot(valid);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[b * gridDim.x + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+__global__ __launch_bounds__(256) void pillar_scan_kernel(const int32_t* __restrict__ blk_cnt, int nblk,
+                                                          int32_t* __restrict__ blk_off, int32_t* __restrict__ counts) {
+  __shared__ int buf[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 256) {
+    const int i = base + t;
+    const int v = i < nblk ? blk_cnt[b * nblk + i] : 0;
+    buf[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
+      const int add = t >= d ? buf[t - d] : 0;
+      __syncthreads();
+      buf[t] += add;
+      __syncthreads();
+    }
+    if (i < nblk) blk_off[b * nblk + i] = carry + buf[t] - v;
+    const int tot = buf[255];
+    __syncthreads();
+    carry += tot;
+  }
+  if (t == 0) counts[b] = carry;
+}
+
+__global__ __launch_bounds__(256) void pillar_compact_kernel(const float* __restrict__ pts,
+                                                             const uint32_t* __restrict__ key,
+                                                             const int32_t* __restrict__ blk_off, int N,
+                                                             df_pillar_geom g, uint32_t invalid_key,
+                                                             float* __restrict__ points_c, int32_t* __restrict__ coords_c,
+                                                             int64_t* __restrict__ idx_c, float* __restrict__ offs_c,
+                                                             int32_t* __restrict__ cpos) {
+  __shared__ int wcnt[4];
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t k = invalid_key;
+  if (n < N) k = key[(int64_t)b * N + n];
+  const bool valid = k != invalid_key;
+  const unsigned long long bal = __ballot(valid);
+  if (lane == 0) wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  int rank = __popcll(bal & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) rank += wcnt[w];
+  if (n >= N) return;
+  if (!valid) {
+    cpos[(int64_t)b * N + n] = -1;
+    return;
+  }
+  const int pos = blk_off[b * gridDim.x + blockIdx.x] + rank;
+  const int cell = (int)(k - (uint32_t)b * (uint32_t)(g.gx * g.gy));
+  const int cy = cell / g.gx, cx = cell - cy * g.gx;
+  const float* p = pts + ((int64_t)b * N + n) * 3;
+  const float px = p[0], py = p[1], pz = p[2];
+  const int64_t o = (int64_t)b * N + pos;
+  points_c[o * 3 + 0] = px;
+  points_c[o * 3 + 1] = py;
+  points_c[o * 3 + 2] = pz;
+  coords_c[o * 3 + 0] = 0;
+  coords_c[o * 3 + 1] = cy;
+  coords_c[o * 3 + 2] = cx;
+  idx_c[o] = n;
+  // centre = c * vs + min + vs / 2, three roundings, no contraction (DynamicVoxelizer._get_point_offsets)
+  const float ctx = __fadd_rn(__fadd_rn(__fmul_rn((float)cx, g.vx), g.minx), g.vx * 0.5f);
+  const float cty = __fadd_rn(__fadd_rn(__fmul_rn((float)cy, g.vy), g.miny), g.vy * 0.5f);
+  const float ctz = __fadd_rn(__fadd_rn(0.f, g.minz), g.vz * 0.5f);
+  offs_c[o * 3 + 0] = __fsub_rn(px, ctx);
+  offs_c[o * 3 + 1] = __fsub_rn(py, cty);
+  offs_c[o * 3 + 2] = __fsub_rn(pz, ctz);
+  cpos[(int64_t)b * N + n] = pos;
+}
+
+__global__ void iota_kernel(uint32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+__global__ void pillar_cells_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t ncells,
+                                    int32_t* __restrict__ cell_rng) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  if (k >= ncells) return;
+  if (i == 0 || key[i - 1] != k) cell_rng[2 * (int64_t)k] = (int32_t)i;
+  if (i == n - 1 || key[i + 1] != k) cell_rng[2 * (int64_t)k + 1] = (int32_t)(i + 1);
+}
+
+// ---- pillar feature net ------------------------------------------------------------------
+// 8 lanes per cell; lane `sub` owns output channels 4*sub .. 4*sub+3 of Linear(9->32).
+struct PfnCtx {
+  float w[4][9];
+  float sc[4], sh[4], mu[4], is[4];
+};
+
+__device__ __forceinline__ void pfn_load_w(PfnCtx& c, const float* __restrict__ w_pfn, int sub) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c.w[k][j] = w_pfn[(4 * sub + k) * 9 + j];
+}
+__device__ __forceinline__ void pfn_load_bn(PfnCtx& c, const float* __restrict__ ss /*[4][32]*/, int sub) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c.sc[k] = ss[0 * 32 + 4 * sub + k];
+    c.sh[k] = ss[1 * 32 + 4 * sub + k];
+    c.mu[k] = ss[2 * 32 + 4 * sub + k];
+    c.is[k] = ss[3 * 32 + 4 * sub + k];
+  }
+}
+// pillar centre as DynamicPillarFeatureNet computes it: c * v + (v/2 + min), two roundings
+__device__ __forceinline__ void pfn_centre(const df_pillar_geom& g, int cell, float& ctx, float& cty, float& ctz) {
+  const int cy = cell / g.gx, cx = cell - cy * g.gx;
+  ctx = __fadd_rn(__fmul_rn((float)cx, g.vx), g.offx);
+  cty = __fadd_rn(__fmul_rn((float)cy, g.vy), g.offy);
+  ctz = __fadd_rn(0.f, g.offz);
+}
+__device__ __forceinline__ void pfn_mean(const float* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
+                                         int s, int e, float& mx, float& my, float& mz) {
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int i = s; i < e; ++i) {
+    const float* p = pts + (int64_t)idx_sorted[i] * 3;
+    sx += p[0];
+    sy += p[1];
+    sz += p[2];
+  }
+  const float inv = (float)(e - s);
+  mx = sx / inv;
+  my = sy / inv;
+  mz = sz / inv;
+}
+__device__ __forceinline__ void pfn_feat(const float* p, float mx, float my, float mz, float ctx, float cty, float ctz,
+                                         float (&f)[9]) {
+  f[0] = p[0]; f[1] = p[1]; f[2] = p[2];
+  f[3] = p[0] - mx; f[4] = p[1] - my; f[5] = p[2] - mz;
+  f[6] = p[0] - ctx; f[7] = p[1] - cty; f[8] = p[2] - ctz;
+}
+__device__ __forceinline__ void pfn_linear(const PfnCtx& c, const float (&f)[9], float (&u)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a = fmaf(c.w[k][j], f[j], a);
+    u[k] = a;
+  }
+}
+
+constexpr int CELLS_PER_BLOCK = 32;
+
+// reduce NV floats per lane across the 32 cell groups of a block (lanes with equal `sub`)
+template <int NV>
+__device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*NV]*/) {
+  const int sub = threadIdx.x & 7;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) lds[k * 256 + threadIdx.x] = v[k];
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    for (int gi = 1; gi < CELLS_PER_BLOCK; ++gi)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] += lds[k * 256 + gi * 8 + sub];
+  }
+}
+
+__global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict__ pts,
+                                                        const uint32_t* __restrict__ idx_sorted,
+                                                        const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                        const float* __restrict__ w_pfn, float* __restrict__ partial) {
+  __shared__ float lds[256 * 8];
+  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int ncell = g.gx * g.gy;
+  PfnCtx c;
+  pfn_load_w(c, w_pfn, sub);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
+    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+    if (e <= s) continue;
+    float mx, my, mz, ctx, cty, ctz;
+    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_centre(g, cell, ctx, cty, ctz);
+    for (int i = s; i < e; ++i) {
+      float f[9], u[4];
+      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_linear(c, f, u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] += u[k];
+        acc[4 + k] += u[k] * u[k];
+      }
+    }
+  }
+  reduce_groups<8>(acc, lds);
+  if (threadIdx.x < 8) {
+    float* o = partial + (((int64_t)b * gridDim.x + blockIdx.x) * 32 + 4 * sub) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k * 2 + 0] = acc[k];
+      o[k * 2 + 1] = acc[4 + k];
+    }
+  }
+}
+
+__global__ void pfn_bn_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
+                                       const int32_t* __restrict__ counts, const float* gamma, const float* beta,
+                                       float eps, float momentum, float* running_mean, float* running_var,
+                                       float* __restrict__ bn_ss) {
+  const int c = threadIdx.x;  // 32 threads
+  for (int b = 0; b < B; ++b) {
+    float* o = bn_ss + (int64_t)b * 128;
+    const int cnt = counts[b];
+    if (cnt <= 0) {
+      o[c] = 0.f; o[32 + c] = 0.f; o[64 + c] = 0.f; o[96 + c] = 0.f;
+      continue;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+    o[c] = (float)(ga * invstd);
+    o[32 + c] = (float)(be - mean * ga * invstd);
+    o[64 + c] = (float)mean;
+    o[96 + c] = (float)invstd;
+    if (running_mean && cnt > 1) {
+      const double unb = var * cnt / (cnt - 1.0);
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict__ pts,
+                                                         const uint32_t* __restrict__ idx_sorted,
+                                                         const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                         const float* __restrict__ w_pfn,
+                                                         const float* __restrict__ bn_ss, int bn_sample_stride,
+                                                         int mode, df_img out) {
+  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int ncell = g.gx * g.gy;
+  PfnCtx c;
+  pfn_load_w(c, w_pfn, sub);
+  pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
+  float* __restrict__ op = reinterpret_cast<float*>(out.ptr) + df_img_base(out, b);
+  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
+    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (e > s) {
+      float mx, my, mz, ctx, cty, ctz;
+      pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+      pfn_centre(g, cell, ctx, cty, ctz);
+      for (int i = s; i < e; ++i) {
+        float f[9], u[4];
+        pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+        pfn_linear(c, f, u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = fmaxf(fmaf(u[k], c.sc[k], c.sh[k]), 0.f);
+          if (mode == 0) r[k] += v;
+          else r[k] = (i == s) ? v : fmaxf(r[k], v);
+        }
+      }
+      if (mode == 0) {
+        const float cnt = (float)(e - s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = r[k] / cnt;
+      }
+    }
+    st4(op + (int64_t)cell * out.ld + 4 * sub, r);
+  }
+}
+
+// backward pass A: per-sample sums of (g_hat, g_hat * xhat) where g_hat = dL/d(BN output) after the ReLU mask
+__global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restrict__ pts,
+                                                            const uint32_t* __restrict__ idx_sorted,
+                                                            const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                            const float* __restrict__ w_pfn,
+                                                            const float* __restrict__ bn_ss, int bn_sample_stride,
+                                                            df_img gout, float* __restrict__ partial) {
+  __shared__ float lds[256 * 8];
+  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int ncell = g.gx * g.gy;
+  PfnCtx c;
+  pfn_load_w(c, w_pfn, sub);
+  pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
+  const float* __restrict__ gp = reinterpret_cast<const float*>(gout.ptr) + df_img_base(gout, b);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
+    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+    if (e <= s) continue;
+    float mx, my, mz, ctx, cty, ctz;
+    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_centre(g, cell, ctx, cty, ctz);
+    const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
+    const float inv = 1.f / (float)(e - s);
+    for (int i = s; i < e; ++i) {
+      float f[9], u[4];
+      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_linear(c, f, u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float yh = fmaf(u[k], c.sc[k], c.sh[k]);
+        const float gh = yh > 0.f ? gc[k] * inv : 0.f;
+        acc[k] += gh;
+        acc[4 + k] += gh * ((u[k] - c.mu[k]) * c.is[k]);
+      }
+    }
+  }
+  reduce_groups<8>(acc, lds);
+  if (threadIdx.x < 8) {
+    float* o = partial + (((int64_t)b * gridDim.x + blockIdx.x) * 32 + 4 * sub) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k * 2 + 0] = acc[k];
+      o[k * 2 + 1] = acc[4 + k];
+    }
+  }
+}
+
+__global__ void pfn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
+                                        const int32_t* __restrict__ counts, float* dgamma, float* dbeta,
+                                        int accumulate, float* __restrict__ coef) {
+  const int c = threadIdx.x;  // 32 threads
+  double tg = 0.0, tb = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+    const int cnt = counts[b];
+    coef[((int64_t)b * 2 + 0) * 32 + c] = cnt > 0 ? (float)(s1 / cnt) : 0.f;
+    coef[((int64_t)b * 2 + 1) * 32 + c] = cnt > 0 ? (float)(s2 / cnt) : 0.f;
+    tb += s1;
+    tg += s2;
+  }
+  dgamma[c] = accumulate ? (float)((double)dgamma[c] + tg) : (float)tg;
+  dbeta[c] = accumulate ? (float)((double)dbeta[c] + tb) : (float)tb;
+}
+
+// backward pass B: dW[32][9] partial sums of du (x) f
+__global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __restrict__ pts,
+                                                              const uint32_t* __restrict__ idx_sorted,
+                                                              const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                              const float* __restrict__ w_pfn,
+                                                              const float* __restrict__ bn_ss, int bn_sample_stride,
+                                                              const float* __restrict__ coef, df_img gout,
+                                                              float* __restrict__ dw_partial) {
+  __shared__ float lds[256 * 36];
+  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int ncell = g.gx * g.gy;
+  PfnCtx c;
+  pfn_load_w(c, w_pfn, sub);
+  pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
+  float c1[4], c2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c1[k] = coef[((int64_t)b * 2 + 0) * 32 + 4 * sub + k];
+    c2[k] = coef[((int64_t)b * 2 + 1) * 32 + 4 * sub + k];
+  }
+  const float* __restrict__ gp = reinterpret_cast<const float*>(gout.ptr) + df_img_base(gout, b);
+  float acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
+    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+    if (e <= s) continue;
+    float mx, my, mz, ctx, cty, ctz;
+    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_centre(g, cell, ctx, cty, ctz);
+    const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
+    const float inv = 1.f / (float)(e - s);
+    for (int i = s; i < e; ++i) {
+      float f[9], u[4];
+      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_linear(c, f, u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float yh = fmaf(u[k], c.sc[k], c.sh[k]);
+        const float gh = yh > 0.f ? gc[k] * inv : 0.f;
+        const float xh = (u[k] - c.mu[k]) * c.is[k];
+        const float du = c.sc[k] * (gh - c1[k] - xh * c2[k]);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[k * 9 + j] = fmaf(du, f[j], acc[k * 9 + j]);
+      }
+    }
+  }
+  reduce_groups<36>(acc, lds);
+  if (threadIdx.x < 8) {
+    float* o = dw_partial + ((int64_t)b * gridDim.x + blockIdx.x) * 288 + 4 * sub * 9;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) o[k] = acc[k];
+  }
+}
+
+bool geom_ok(const df_pillar_geom& g) {
+  return g.gx > 0 && g.gy > 0 && g.gz == 1 && g.vx > 0.f && g.vy > 0.f && g.vz > 0.f;
+}
+
+}  // namespace
+
+extern "C" int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt,
+                              void* stream) {
+  DF_REQUIRE(pts && key && blk_cnt && B > 0 && N > 0, DF_E_ARG);
+  DF_REQUIRE(geom_ok(g) && (int64_t)B * g.gx * g.gy < 0x7fffffffll && (int64_t)B * N < 0x7fffffffll, DF_E_SHAPE);
+  const uint32_t invalid = (uint32_t)((int64_t)B * g.gx * g.gy);
+  hipLaunchKernelGGL(pillar_keys_kernel, dim3((N + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     pts, N, g, invalid, key, blk_cnt);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pillar_scan(const int32_t* blk_cnt, int B, int nblk, int32_t* blk_off, int32_t* counts,
+                              void* stream) {
+  DF_REQUIRE(blk_cnt && blk_off && counts && B > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(pillar_scan_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), blk_cnt, nblk,
+                     blk_off, counts);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pillar_compact(const float* pts, const uint32_t* key, const int32_t* blk_off, int B, int N,
+                                 df_pillar_geom g, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
+                                 int32_t* cpos, void* stream) {
+  DF_REQUIRE(pts && key && blk_off && points_c && coords_c && idx_c && offs_c && cpos, DF_E_ARG);
+  DF_REQUIRE(geom_ok(g), DF_E_SHAPE);
+  const uint32_t invalid = (uint32_t)((int64_t)B * g.gx * g.gy);
+  hipLaunchKernelGGL(pillar_compact_kernel, dim3((N + 255) / 256, B), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), pts, key, blk_off, N, g, invalid, points_c, coords_c, idx_c,
+                     offs_c, cpos);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+static size_t sort_temp_bytes(int64_t n, int bits) {
+  size_t bytes = 0;
+  rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*, const uint32_t*, uint32_t*>(
+      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, bits, 0, false);
+  return bytes;
+}
+
+extern "C" int64_t df_pillar_sort_ws_bytes(int64_t n) {
+  const size_t iota = ((size_t)n * 4 + 255) & ~(size_t)255;
+  return (int64_t)(iota + sort_temp_bytes(n, 32) + 256);
+}
+
+extern "C" int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_t* idx_out, int64_t n, int key_bits,
+                              void* ws, int64_t ws_bytes, void* stream) {
+  DF_REQUIRE(key_in && key_out && idx_out && ws && n > 0 && key_bits > 0 && key_bits <= 32, DF_E_ARG);
+  const size_t iota = ((size_t)n * 4 + 255) & ~(size_t)255;
+  size_t temp = sort_temp_bytes(n, key_bits);
+  DF_REQUIRE((int64_t)(iota + temp) <= ws_bytes, DF_E_WORKSPACE);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  uint32_t* idx_in = reinterpret_cast<uint32_t*>(ws);
+  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx_in, n);
+  DF_CHECK_LAUNCH();
+  hipError_t e = rocprim::radix_sort_pairs(reinterpret_cast<char*>(ws) + iota, temp, key_in, key_out,
+                                           (const uint32_t*)idx_in, idx_out, (size_t)n, 0u, (unsigned)key_bits, s, false);
+  return (int)e;
+}
+
+extern "C" int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream) {
+  DF_REQUIRE(key_sorted && cell_rng && n > 0 && ncells > 0 && ncells < 0x7fffffffll, DF_E_ARG);
+  hipLaunchKernelGGL(pillar_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), key_sorted, n, (uint32_t)ncells, cell_rng);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+                            df_pillar_geom g, const float* w_pfn, float* partial, int nblk_stat, void* stream) {
+  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
+  hipLaunchKernelGGL(pfn_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
+                     idx_sorted, cell_rng, g, w_pfn, partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts,
+                                  const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* bn_ss, void* stream) {
+  DF_REQUIRE(partial && counts && bn_ss && B > 0 && nblk_stat > 0, DF_E_ARG);
+  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
+                     nblk_stat, counts, gamma, beta, eps, momentum, running_mean, running_var, bn_ss);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+                             df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode,
+                             df_img out, int nblk, void* stream) {
+  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
+  DF_REQUIRE(out.n == B && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr),
+             DF_E_SHAPE);
+  DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
+  hipLaunchKernelGGL(pfn_canvas_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
+                     idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+                                df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
+                                df_img gout, float* partial, int nblk_stat, void* stream) {
+  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
+             DF_E_ARG);
+  DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
+  hipLaunchKernelGGL(pfn_bwd_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
+                     idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, float* dgamma,
+                                   float* dbeta, int accumulate, float* coef, void* stream) {
+  DF_REQUIRE(partial && counts && dgamma && dbeta && coef && B > 0 && nblk_stat > 0, DF_E_ARG);
+  hipLaunchKernelGGL(pfn_bwd_finalize_kernel, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
+                     nblk_stat, counts, dgamma, dbeta, accumulate, coef);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+                                  df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
+                                  const float* coef, df_img gout, float* dw_partial, int nblk_stat, void* stream) {
+  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
+                 geom_ok(g),
+             DF_E_ARG);
+  DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
+  hipLaunchKernelGGL(pfn_bwd_weights_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     pts, idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

@@ -1,0 +1,228 @@
+"""Point decoders with the reference's module trees ([REF decoder.py:72-199]): ConvGRU, ConvGRUDecoder,
+LinearDecoder.  state_dict keys are identical to the reference classes (offset_encoder.*, gru.conv{z,r,q}.*,
+decoder.{0,2}.*) so ``deflow_best.ckpt`` loads [REF deflow.py:41-47].  Compute: csrc/decoder.hip,
+csrc/decoder_bwd.hip."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import DfGruWeights, DfGruWeightsT, DfImg, call, img, ptr, stream
+
+
+class ConvGRU(nn.Module):
+    """Parameter container ([REF decoder.py:123-139]); the recurrence itself runs inside the fused decoder kernel."""
+
+    def __init__(self, input_dim: int = 64, hidden_dim: int = 128):
+        super().__init__()
+        self.convz = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+        self.convr = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+        self.convq = nn.Conv1d(input_dim + hidden_dim, hidden_dim, 1)
+
+
+@dataclass
+class PointSet:
+    """Padded per-sample decoder inputs (device-side counts: no host sync to launch)."""
+    coords: torch.Tensor   # [B,N,3] i32 (z,y,x)
+    offs: torch.Tensor     # [B,N,3] f32
+    counts: torch.Tensor   # [B] i32
+    # gather-backward helpers (pillar sort of pc0): original flat index sorted by cell, cell table, original->compact
+    idx_sorted: Optional[torch.Tensor] = None
+    cell_rng: Optional[torch.Tensor] = None
+    cpos: Optional[torch.Tensor] = None
+
+
+def pack_infos(infos: List[Dict[str, torch.Tensor]], H: int, W: int, device, need_bwd: bool) -> PointSet:
+    """List-of-dicts (reference contract [REF decoder.py:185-199]) -> padded PointSet.  Host-side plumbing for the
+    stand-alone head call; the fused DeFlow path never goes through here."""
+    B = len(infos)
+    ns = [int(i["voxel_coords"].shape[0]) for i in infos]
+    N = max(1, max(ns))
+    coords = torch.zeros(B, N, 3, dtype=torch.int32, device=device)
+    offs = torch.zeros(B, N, 3, dtype=torch.float32, device=device)
+    for b, i in enumerate(infos):
+        coords[b, :ns[b]] = i["voxel_coords"].to(device=device, dtype=torch.int32)  # float coords accepted (.long() in ref)
+        offs[b, :ns[b]] = i["point_offsets"].to(device=device, dtype=torch.float32)
+    counts = torch.tensor(ns, dtype=torch.int32, device=device)
+    ps = PointSet(coords, offs, counts)
+    if need_bwd:
+        ncells = B * H * W
+        bidx = torch.arange(B, device=device, dtype=torch.int64)[:, None]
+        key = bidx * (H * W) + coords[..., 1].long() * W + coords[..., 2].long()
+        valid = torch.arange(N, device=device)[None, :] < counts[:, None]
+        key = torch.where(valid, key, torch.full_like(key, ncells)).to(torch.int32).reshape(-1).contiguous()
+        key_sorted = torch.empty_like(key)
+        idx_sorted = torch.empty_like(key)
+        ws_bytes = call("df_pillar_sort_ws_bytes", B * N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        call("df_pillar_sort", ptr(key), ptr(key_sorted), ptr(idx_sorted), B * N, max(1, int(ncells).bit_length()),
+             ptr(ws), ws_bytes, stream())
+        cell_rng = torch.zeros(ncells, 2, dtype=torch.int32, device=device)
+        call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), stream())
+        ps.idx_sorted, ps.cell_rng = idx_sorted, cell_rng
+        ps.cpos = torch.arange(N, device=device, dtype=torch.int32).repeat(B).contiguous()
+    return ps
+
+
+def _adjacent(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.is_contiguous() and b.is_contiguous() and a.data_ptr() + a.numel() * 4 == b.data_ptr()
+
+
+class ConvGRUDecoder(nn.Module):
+    def __init__(self, pseudoimage_channels: int = 64, num_iters: int = 4):
+        super().__init__()
+        assert pseudoimage_channels == 64, "the fused HIP decoder is specialised for 64+64 channels"
+        self.offset_encoder = nn.Linear(3, pseudoimage_channels)
+        self.gru = ConvGRU(input_dim=pseudoimage_channels, hidden_dim=pseudoimage_channels * 2)
+        self.decoder = nn.Sequential(nn.Linear(pseudoimage_channels * 3, pseudoimage_channels // 2), nn.GELU(),
+                                     nn.Linear(pseudoimage_channels // 2, 3))
+        self.num_iters = num_iters
+
+    # -- weights as the kernels want them ------------------------------------------------------------
+    def _weights(self) -> Tuple[DfGruWeights, list]:
+        g = self.gru
+        wz, wr = g.convz.weight.detach(), g.convr.weight.detach()
+        bz, br = g.convz.bias.detach(), g.convr.bias.detach()
+        # [z rows | r rows]: free when the parameter arena lays convz/convr out back to back, else one small cat
+        w_zr = torch.as_strided(wz, (256, 192), (192, 1)) if _adjacent(wz, wr) else torch.cat([wz, wr], 0).view(256, 192)
+        b_zr = torch.as_strided(bz, (256,), (1,)) if _adjacent(bz, br) else torch.cat([bz, br], 0)
+        w_q = g.convq.weight.detach().view(128, 192)
+        keep = [w_zr, b_zr, w_q]
+        W = DfGruWeights(ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(w_zr),
+                         ptr(b_zr), ptr(w_q), ptr(g.convq.bias.detach()), ptr(self.decoder[0].weight.detach()),
+                         ptr(self.decoder[0].bias.detach()), ptr(self.decoder[2].weight.detach()),
+                         ptr(self.decoder[2].bias.detach()))
+        return W, keep
+
+    # -- engine ------------------------------------------------------------------------------------------
+    def run(self, before: DfImg, after: DfImg, ps: PointSet, save: bool):
+        """-> flow [B,N,3] (rows >= counts[b] are not written), save buffer or None."""
+        B, N, _ = ps.coords.shape
+        dev = ps.coords.device
+        flow = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        T = self.num_iters
+        sv = torch.empty((5 * T + 1) * B * N * 128, dtype=torch.float32, device=dev) if save else None
+        W, keep = self._weights()
+        call("df_gru_decoder_fwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
+             ptr(sv), stream())
+        return flow, sv
+
+    def run_backward(self, dflow: torch.Tensor, ps: PointSet, sv: torch.Tensor, dbefore: DfImg, dafter: DfImg,
+                     acc_before: bool, acc_after: bool, grads: dict):
+        B, N, _ = ps.coords.shape
+        dev, T, s = dflow.device, self.num_iters, stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        BN = B * N
+        W, keep = self._weights()
+        w_zr, b_zr, w_q = keep
+        w1 = self.decoder[0].weight.detach()
+        wt_zr = ops.weight_transpose(w_zr.view(256, 1, 1, 192)).view(192, 256)
+        wt_q = ops.weight_transpose(w_q.view(128, 1, 1, 192)).view(192, 128)
+        wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
+        WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
+        dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
+        dpre1, hid, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
+        dflow = dflow.contiguous()
+        call("df_gru_decoder_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
+             ptr(dpre1), ptr(hid), ptr(xbuf), s)
+        # image gradients: per-cell segmented sum (no atomics)
+        ncell = dbefore.h * dbefore.w
+        call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
+             int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
+        # weight gradients: split-K GEMMs over the saved planes (now holding the gate pre-activation gradients)
+        plane = T * BN * 128
+
+        def rows_img(t: torch.Tensor, off: int, n_img: int, c: int, ld: int, img_stride: int) -> DfImg:
+            return DfImg(t.data_ptr() + 4 * off, n_img, 1, BN, c, ld, n_img, img_stride, 0)
+
+        h_in = rows_img(sv, 0 * plane, T, 128, 128, BN * 128)
+        dz = rows_img(sv, 1 * plane, T, 128, 128, BN * 128)
+        dr = rows_img(sv, 2 * plane, T, 128, 128, BN * 128)
+        dq = rows_img(sv, 3 * plane, T, 128, 128, BN * 128)
+        rh = rows_img(sv, 4 * plane, T, 128, 128, BN * 128)
+        hT = rows_img(sv, 5 * plane, 1, 128, 128, BN * 128)
+        x_rep = rows_img(xbuf, 0, T, 64, 64, 0)          # the same x rows for every iteration
+        x_one = rows_img(xbuf, 0, 1, 64, 64, BN * 64)
+        dW_zr = torch.empty(256, 192, **f32)
+        dW_q = torch.empty(128, 192, **f32)
+        kw = dict(row_counts=ps.counts, rows_per_seg=N)
+        ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
+        ops.conv2d_wgrad(x_rep, dz, 1, 1, dW_zr, ld_co=192, dw_off=128, **kw)
+        ops.conv2d_wgrad(h_in, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192, **kw)
+        ops.conv2d_wgrad(x_rep, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192 + 128, **kw)
+        ops.conv2d_wgrad(rh, dq, 1, 1, dW_q, ld_co=192, dw_off=0, **kw)
+        ops.conv2d_wgrad(x_rep, dq, 1, 1, dW_q, ld_co=192, dw_off=128, **kw)
+        # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
+        dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
+        dW1t = torch.empty(192, 32, **f32)
+        ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
+        ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
+        dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
+        g = self.gru
+        grads[g.convz.weight] = dW_zr[:128].unsqueeze(2)
+        grads[g.convr.weight] = dW_zr[128:].unsqueeze(2)
+        grads[g.convq.weight] = dW_q.unsqueeze(2)
+        grads[self.decoder[0].weight] = dW1
+        so = lambda a, lda, na, b, ldb, nb, rows: ops.small_outer(a, lda, na, b, ldb, nb, ps.counts, N, B, rows)
+        pl = sv.view(-1)
+        grads[g.convz.bias] = so(pl[1 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
+        grads[g.convr.bias] = so(pl[2 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
+        grads[g.convq.bias] = so(pl[3 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
+        grads[self.decoder[0].bias] = so(dpre1, 32, 32, None, 0, 1, BN).view(32)
+        dfl = dflow.view(BN, 3)
+        grads[self.decoder[2].weight] = so(dfl, 3, 3, hid, 32, 32, BN)
+        grads[self.decoder[2].bias] = so(dfl, 3, 3, None, 0, 1, BN).view(3)
+        offs = ps.offs.view(BN, 3)
+        grads[self.offset_encoder.weight] = so(dx, 64, 64, offs, 3, 3, BN)
+        grads[self.offset_encoder.bias] = so(dx, 64, 64, None, 0, 1, BN).view(64)
+
+    # -- reference-compatible call ------------------------------------------------------------------------------
+    def forward(self, before_pseudoimages: torch.Tensor, after_pseudoimages: torch.Tensor,
+                voxelizer_infos: List[Dict[str, torch.Tensor]]) -> List[torch.Tensor]:
+        """NCHW images + list of {"point_offsets", "voxel_coords"} -> list of [N_b,3] flows.  Differentiable w.r.t. the
+        images and the parameters (autograd.Function over the HIP forward/backward)."""
+        from .autograd import GruHeadFn
+        H, W = before_pseudoimages.shape[2:]
+        need_bwd = torch.is_grad_enabled() and (before_pseudoimages.requires_grad or after_pseudoimages.requires_grad or
+                                                any(p.requires_grad for p in self.parameters()))
+        ps = pack_infos(voxelizer_infos, H, W, before_pseudoimages.device, need_bwd)
+        ns = [int(i["voxel_coords"].shape[0]) for i in voxelizer_infos]
+        if need_bwd:
+            flow = GruHeadFn.apply(self, ps, before_pseudoimages, after_pseudoimages, *self.parameters())
+        else:
+            bh = before_pseudoimages.permute(0, 2, 3, 1).contiguous()
+            ah = after_pseudoimages.permute(0, 2, 3, 1).contiguous()
+            flow, _ = self.run(img(bh), img(ah), ps, False)
+        return [flow[b, :n] for b, n in enumerate(ns)]
+
+
+class LinearDecoder(nn.Module):
+    def __init__(self, pseudoimage_channels: int = 64):
+        super().__init__()
+        assert pseudoimage_channels == 64
+        self.offset_encoder = nn.Linear(3, 128)
+        self.decoder = nn.Sequential(nn.Linear(pseudoimage_channels * 4, 32), nn.GELU(), nn.Linear(32, 3))
+
+    def run(self, before: DfImg, after: DfImg, ps: PointSet, save: bool = False):
+        assert not save, "LinearDecoder backward is not implemented yet (fastflow3d training is a 'next' row)"
+        B, N, _ = ps.coords.shape
+        flow = torch.empty(B, N, 3, dtype=torch.float32, device=ps.coords.device)
+        d = self.decoder
+        call("df_linear_decoder_fwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N,
+             ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(d[0].weight.detach()),
+             ptr(d[0].bias.detach()), ptr(d[2].weight.detach()), ptr(d[2].bias.detach()), ptr(flow), stream())
+        return flow, None
+
+    def forward(self, before_pseudoimages, after_pseudoimages, voxelizer_infos):
+        H, W = before_pseudoimages.shape[2:]
+        ps = pack_infos(voxelizer_infos, H, W, before_pseudoimages.device, False)
+        ns = [int(i["voxel_coords"].shape[0]) for i in voxelizer_infos]
+        bh = before_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
+        ah = after_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
+        with torch.no_grad():
+            flow, _ = self.run(img(bh), img(ah), ps, False)
+        return [flow[b, :n] for b, n in enumerate(ns)]

@@ -1,0 +1,163 @@
+"""DynamicEmbedder: points -> 32-channel BEV pseudo-image + per-point voxel info.
+
+Mirrors the reference's constructor and return contract ([REF deflow.py:27-30,82-83,97-101]); the state_dict
+keys follow the upstream module tree (``feature_net.pfn_layers.0.{0,1}.*``).  All compute is HIP
+(csrc/pillarize.hip): voxelise -> stable compaction -> stable radix sort by cell -> per-cell gather-reduce.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import DfGeom, DfImg, call, img, ptr, stream
+
+
+def make_geom(voxel_size, point_cloud_range) -> DfGeom:
+    vs = torch.tensor(voxel_size, dtype=torch.float32)
+    rg = torch.tensor(point_cloud_range, dtype=torch.float32)
+    grid = torch.round((rg[3:] - rg[:3]) / vs).long()  # mmcv Voxelization.__init__
+    off = [float(voxel_size[i]) / 2 + float(point_cloud_range[i]) for i in range(3)]  # python doubles, as upstream
+    return DfGeom(float(vs[0]), float(vs[1]), float(vs[2]), float(rg[0]), float(rg[1]), float(rg[2]),
+                  off[0], off[1], off[2], int(grid[0]), int(grid[1]), int(grid[2]))
+
+
+@dataclass
+class PillarState:
+    """Device-side result of pillarising one cloud set [B,N,3]; padded, no host sync needed to use it."""
+    pts: torch.Tensor          # [B,N,3] the (ego-compensated) input
+    counts: torch.Tensor       # [B] i32 valid points per sample
+    points_c: torch.Tensor     # [B,N,3] compacted
+    coords_c: torch.Tensor     # [B,N,3] i32 (z,y,x)
+    idx_c: torch.Tensor        # [B,N] i64 index into the padded input
+    offs_c: torch.Tensor       # [B,N,3]
+    cpos: torch.Tensor         # [B*N] i32 original -> compact
+    idx_sorted: torch.Tensor   # [B*N] u32 (as i32) original flat index, sorted by cell
+    cell_rng: torch.Tensor     # [B*H*W,2] i32
+    bn_ss: torch.Tensor        # [B or 1,4,32]
+    bn_stride: int             # 128 (per-sample stats) or 0
+
+
+class _FeatureNet(nn.Module):
+    """Parameter container with the upstream names (DynamicPillarFeatureNet, feat_channels=(32,), mode='avg')."""
+
+    def __init__(self, feat_channels: int):
+        super().__init__()
+        self.pfn_layers = nn.ModuleList([
+            nn.Sequential(nn.Linear(9, feat_channels, bias=False),
+                          nn.BatchNorm1d(feat_channels, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True))])
+
+
+class DynamicEmbedder(nn.Module):
+    def __init__(self, voxel_size, pseudo_image_dims, point_cloud_range, feat_channels: int = 32, mode: str = "avg"):
+        super().__init__()
+        assert feat_channels == 32, "the HIP pillar feature net is specialised for 32 channels"
+        self.voxel_size = list(voxel_size)
+        self.point_cloud_range = list(point_cloud_range)
+        self.geom = make_geom(voxel_size, point_cloud_range)
+        self.H, self.W = int(pseudo_image_dims[0]), int(pseudo_image_dims[1])
+        assert (self.geom.gy, self.geom.gx) == (self.H, self.W), "pseudo_image_dims must equal the voxel grid"
+        self.mode = 0 if mode == "avg" else 1
+        self.feature_net = _FeatureNet(feat_channels)
+
+    # -- parameters --------------------------------------------------------------------------
+    @property
+    def _lin(self) -> nn.Linear:
+        return self.feature_net.pfn_layers[0][0]
+
+    @property
+    def _bn(self) -> nn.BatchNorm1d:
+        return self.feature_net.pfn_layers[0][1]
+
+    # -- engine ------------------------------------------------------------------------------
+    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
+        """pts [B,N,3] f32 contiguous on the GPU; writes the [B,H,W,32] canvas described by `out`."""
+        assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
+        B, N, _ = pts.shape
+        dev, g, s = pts.device, self.geom, stream()
+        H, W = self.H, self.W
+        nblk = (N + 255) // 256
+        i32 = dict(dtype=torch.int32, device=dev)
+        key = torch.empty(B * N, **i32)
+        blk_cnt = torch.empty(B, nblk, **i32)
+        blk_off = torch.empty(B, nblk, **i32)
+        counts = torch.empty(B, **i32)
+        call("df_pillar_keys", ptr(pts), B, N, g, ptr(key), ptr(blk_cnt), s)
+        call("df_pillar_scan", ptr(blk_cnt), B, nblk, ptr(blk_off), ptr(counts), s)
+        points_c = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        coords_c = torch.empty(B, N, 3, **i32)
+        idx_c = torch.empty(B, N, dtype=torch.int64, device=dev)
+        offs_c = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        cpos = torch.empty(B * N, **i32)
+        call("df_pillar_compact", ptr(pts), ptr(key), ptr(blk_off), B, N, g, ptr(points_c), ptr(coords_c), ptr(idx_c),
+             ptr(offs_c), ptr(cpos), s)
+        key_sorted = torch.empty(B * N, **i32)
+        idx_sorted = torch.empty(B * N, **i32)
+        ws_bytes = call("df_pillar_sort_ws_bytes", B * N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ncells = B * H * W
+        call("df_pillar_sort", ptr(key), ptr(key_sorted), ptr(idx_sorted), B * N, max(1, int(ncells).bit_length()),
+             ptr(ws), ws_bytes, s)
+        cell_rng = torch.zeros(ncells, 2, **i32)
+        call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), s)
+        w = self._lin.weight.detach()
+        bn = self._bn
+        if train:
+            nbs = max(1, min(256, (H * W) // 32))
+            partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
+            call("df_pfn_stats", ptr(pts), ptr(idx_sorted), ptr(cell_rng), B, g, ptr(w), ptr(partial), nbs, s)
+            bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
+            call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                 bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
+            bn.num_batches_tracked.add_(B)
+            bn_stride = 128
+        else:
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+            scale = bn.weight.detach() * invstd
+            bn_ss = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
+            bn_stride = 0
+        nbc = max(1, min(2048, (H * W) // 32))
+        call("df_pfn_canvas", ptr(pts), ptr(idx_sorted), ptr(cell_rng), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
+             out, nbc, s)
+        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, bn_ss, bn_stride)
+
+    def pillarize_bwd(self, st: PillarState, gout: DfImg, grads: Optional[Tuple[torch.Tensor, ...]]):
+        """Accumulates (dW [32,9], dgamma [32], dbeta [32]) for one cloud set; grads=None starts from zero."""
+        assert self.mode == 0, "backward is implemented for mode='avg' (the reference's setting)"
+        B, N, _ = st.pts.shape
+        dev, g, s = st.pts.device, self.geom, stream()
+        w = self._lin.weight.detach()
+        nbs = max(1, min(256, (self.H * self.W) // 32))
+        acc = grads is not None
+        if grads is None:
+            grads = (torch.empty(32, 9, dtype=torch.float32, device=dev), torch.empty(32, dtype=torch.float32, device=dev),
+                     torch.empty(32, dtype=torch.float32, device=dev))
+        dW, dgamma, dbeta = grads
+        partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
+        call("df_pfn_bwd_stats", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), B, g, ptr(w), ptr(st.bn_ss),
+             st.bn_stride, gout, ptr(partial), nbs, s)
+        coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
+        call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
+        dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
+        call("df_pfn_bwd_weights", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), B, g, ptr(w), ptr(st.bn_ss),
+             st.bn_stride, ptr(coef), gout, ptr(dwp), nbs, s)
+        call("df_colsum_finalize", ptr(dwp), B * nbs, 288, 1, ptr(dW), int(acc), s)
+        return grads
+
+    @staticmethod
+    def infos_from_state(st: PillarState, counts_host: List[int]) -> List[Dict[str, torch.Tensor]]:
+        return [{"points": st.points_c[b, :m], "voxel_coords": st.coords_c[b, :m], "point_idxes": st.idx_c[b, :m],
+                 "point_offsets": st.offs_c[b, :m]} for b, m in enumerate(counts_host)]
+
+    # -- reference-compatible call: embedder(points) -> (pseudoimage [B,32,H,W], infos) ---------------
+    def forward(self, points: torch.Tensor):
+        pts = points.contiguous().float()
+        B = pts.shape[0]
+        canvas = torch.empty(B, self.H, self.W, 32, dtype=torch.float32, device=pts.device)
+        with torch.no_grad():
+            st = self.pillarize(pts, img(canvas), self.training)
+        infos = self.infos_from_state(st, st.counts.tolist())
+        return canvas.permute(0, 3, 1, 2), infos

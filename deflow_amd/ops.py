@@ -1,0 +1,120 @@
+"""Thin tensor-level wrappers over the C ABI (include/deflow_amd.h).  Every function launches HIP kernels on
+torch's current stream with raw device pointers; nothing here computes with torch ops."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import DfImg, call, img, img_pair, ptr, stream
+
+CONV_FWD, CONV_DGRAD = 0, 1
+EPI_BIAS, EPI_STATS, EPI_BN_GELU = 0, 1, 2
+
+
+def _f32(*shape, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def ohwi(w: torch.Tensor) -> torch.Tensor:
+    """Conv weight [O,I,kh,kw] -> contiguous [O,kh,kw,I] memory (free when the parameter is channels_last)."""
+    v = w.detach().permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
+           mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False):
+    call("df_conv2d", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+         int(accumulate), stream())
+
+
+def conv_tile_m(rows_per_group: int, cout: int) -> int:
+    return call("df_conv2d_tile_m", rows_per_group, cout)
+
+
+def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss):
+    call("df_bn_finalize", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,
+         ptr(rmean), ptr(rvar), ptr(bn_ss), stream())
+
+
+def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):
+    call("df_bn_gelu_apply", ptr(y), ptr(bn_ss), imgs_per_group, z, stream())
+
+
+def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
+    """largest power of two <= cap dividing rows_per_group with >= 16 rows per block"""
+    n = 1
+    while n * 2 <= cap and rows_per_group % (n * 2) == 0 and rows_per_group // (n * 2) >= 16:
+        n *= 2
+    return n
+
+
+def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> dy [n,h,w,C], dgamma [C], dbeta [C], dbias [C]"""
+    dev = y.device
+    C = dz.c
+    rows_per_group = imgs_per_group * dz.h * dz.w
+    nbg = _pow2_blocks(rows_per_group)
+    nblk = nbg * groups
+    partial = _f32(nblk, C, 2, device=dev)
+    call("df_bn_gelu_bwd_reduce", dz, ptr(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
+    dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
+    coef = _f32(groups, 2, C, device=dev)
+    call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
+    dy = torch.empty_like(y)
+    dbp = _f32(nblk, C, device=dev)
+    call("df_bn_gelu_bwd_apply", dz, ptr(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), ptr(dbp), nblk, stream())
+    dbias = _f32(C, device=dev)
+    call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
+    return dy, dgamma, dbeta, dbias
+
+
+def colsum(x: DfImg, device) -> torch.Tensor:
+    rows = x.n * x.h * x.w
+    nblk = max(1, min(1024, rows // 64))
+    partial = _f32(nblk, x.c, device=device)
+    call("df_colsum_partial", x, ptr(partial), nblk, stream())
+    out = _f32(x.c, device=device)
+    call("df_colsum_finalize", ptr(partial), nblk, x.c, 1, ptr(out), 0, stream())
+    return out
+
+
+def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[Cout,kh,kw,Cin] -> [Cin,kh,kw,Cout]"""
+    co, kh, kw, ci = w_ohwi.shape
+    wt = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=w_ohwi.device)
+    call("df_weight_transpose", ptr(w_ohwi), ptr(wt), co, kh * kw, ci, stream())
+    return wt
+
+
+def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld_co: Optional[int] = None,
+                 accumulate: bool = False, row_counts: Optional[torch.Tensor] = None, rows_per_seg: int = 0, dw_off: int = 0):
+    """dw (float memory [Cout][taps][Cin] with row pitch ld_co, starting dw_off elements in) (+)= dy^T x."""
+    dev = dw.device
+    splits = call("df_conv2d_wgrad_splits", x, dy, ks, stride)
+    taps = ks * ks
+    ws = _f32(splits * dy.c * taps * x.c, device=dev)
+    call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, stream())
+    call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
+         taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
+
+
+def upsample2x(x: DfImg, y: DfImg, align_corners: bool):
+    call("df_upsample2x", x, y, int(align_corners), stream())
+
+
+def upsample2x_bwd(dy: DfImg, dx: DfImg, align_corners: bool):
+    call("df_upsample2x_bwd", dy, dx, int(align_corners), stream())
+
+
+def small_outer(a: torch.Tensor, lda: int, na: int, b: Optional[torch.Tensor], ldb: int, nb: int, counts: torch.Tensor,
+                rows_per_seg: int, nseg: int, rows: int) -> torch.Tensor:
+    nblk = max(1, min(1024, rows // 256))
+    partial = _f32(nblk, na * nb, device=a.device)
+    call("df_small_outer", ptr(a), lda, na, ptr(b), ldb, nb, ptr(counts), rows_per_seg, nseg, rows, ptr(partial), nblk,
+         stream())
+    out = _f32(na, nb, device=a.device)
+    call("df_colsum_finalize", ptr(partial), nblk, na * nb, 1, ptr(out), 0, stream())
+    return out

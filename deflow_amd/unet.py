@@ -1,0 +1,248 @@
+"""FastFlow3DUNet backbone ([REF deflow.py:15,32,87-88]) built from ConvWithNorms ([REF decoder.py:202-220]).
+
+Module tree / state_dict keys follow upstream (encoder_step_{1,2,3}.N.{conv,batchnorm}, decoder_step{1,2,3}.
+{u1_u2.0,u3,u4_u5.{0,1}}, decoder_step4).  Compute is an explicit engine over HIP kernels (csrc/conv.hip,
+csrc/elementwise.hip) with hand-sequenced backward: NHWC activations, the two clouds batched through the
+shared encoder as 2B images with two BatchNorm statistic groups (= the reference's two encoder calls), channel
+concatenations realised by writing into slices of one buffer (no torch.cat copies), gradients that meet at a
+concatenation summed by the producing kernel's `accumulate` epilogue.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import DfImg, img, img_pair, ptr
+
+
+class ConvWithNorms(nn.Module):
+    def __init__(self, in_num_channels: int, out_num_channels: int, kernel_size: int, stride: int, padding: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_num_channels, out_num_channels, kernel_size, stride, padding)
+        self.batchnorm = nn.BatchNorm2d(out_num_channels)
+        self.nonlinearity = nn.GELU()
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Stand-alone call on an NCHW tensor (inference or training statistics; no autograd)."""
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        n, h, w, _ = xh.shape
+        ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+        if ho == 1 and wo == 1:
+            raise NotImplementedError("1x1 output maps (BatchNorm skipped, [REF decoder.py:214-217]) are not on the DeFlow path")
+        z = torch.empty(n, ho, wo, self.conv.out_channels, dtype=torch.float32, device=x.device)
+        with torch.no_grad():
+            _cwn_forward(self, img(xh), img(z), n, 1, self.training, None)
+        return z.permute(0, 3, 1, 2)
+
+
+class UpsampleSkip(nn.Module):
+    def __init__(self, skip_channels: int, latent_channels: int, out_channels: int):
+        super().__init__()
+        self.u1_u2 = nn.Sequential(nn.Conv2d(skip_channels, latent_channels, 1, 1, 0), nn.Identity())
+        self.u3 = nn.Conv2d(latent_channels, latent_channels, 1, 1, 0)
+        self.u4_u5 = nn.Sequential(nn.Conv2d(2 * latent_channels, out_channels, 3, 1, 1),
+                                   nn.Conv2d(out_channels, out_channels, 3, 1, 1))
+
+
+def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int, train: bool, tape: Optional[list]):
+    """z = gelu(bn(conv(x))).  train: batch statistics per group (+ running update); else running stats, fused."""
+    dev = m.conv.weight.device
+    w, b, bn = ops.ohwi(m.conv.weight), m.conv.bias.detach(), m.batchnorm
+    C = m.conv.out_channels
+    if not train:
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight.detach() * invstd).contiguous()
+        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        ops.conv2d(x, w, b, z, 3, m.stride, epi=ops.EPI_BN_GELU, scale=scale, shift=shift)
+        return
+    ipg = n_imgs // groups
+    rows_pg = ipg * z.h * z.w
+    tile_m = ops.conv_tile_m(rows_pg, C)
+    assert rows_pg % tile_m == 0, "BatchNorm statistic groups must be a multiple of the row tile"
+    tiles_pg = rows_pg // tile_m
+    y = torch.empty(n_imgs, z.h, z.w, C, dtype=torch.float32, device=dev)
+    partial = torch.empty(tiles_pg * groups, C, 2, dtype=torch.float32, device=dev)
+    yi = img(y)
+    yi.grp_size = ipg  # stat groups are image groups: tile -> group by its first row
+    yi.grp_off = ipg * y.stride(0)
+    ops.conv2d(x, w, b, yi, 3, m.stride, epi=ops.EPI_STATS, stats=partial)
+    bn_ss = torch.empty(groups, 4, C, dtype=torch.float32, device=dev)
+    ops.bn_finalize(partial, tiles_pg, groups, C, rows_pg, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
+                    bn.running_mean, bn.running_var, bn_ss)
+    bn.num_batches_tracked.add_(groups)
+    ops.bn_gelu_apply(y, bn_ss, ipg, z)
+    if tape is not None:
+        tape.append(("cwn", m, x, y, bn_ss, ipg, groups))
+
+
+class FastFlow3DUNet(nn.Module):
+    def __init__(self, align_corners: bool = False):
+        super().__init__()
+        C = ConvWithNorms
+        self.encoder_step_1 = nn.Sequential(C(32, 64, 3, 2, 1), *[C(64, 64, 3, 1, 1) for _ in range(3)])
+        self.encoder_step_2 = nn.Sequential(C(64, 128, 3, 2, 1), *[C(128, 128, 3, 1, 1) for _ in range(5)])
+        self.encoder_step_3 = nn.Sequential(C(128, 256, 3, 2, 1), *[C(256, 256, 3, 1, 1) for _ in range(5)])
+        self.decoder_step1 = UpsampleSkip(512, 256, 256)
+        self.decoder_step2 = UpsampleSkip(256, 128, 128)
+        self.decoder_step3 = UpsampleSkip(128, 64, 64)
+        self.decoder_step4 = nn.Conv2d(64, 64, 3, 1, 1)
+        self.align_corners = align_corners
+        for p in self.parameters():  # OHWI memory so the kernels read weights with no per-step transform
+            if p.dim() == 4:
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+
+    # ------------------------------------------------------------------------------- forward ----
+    def run(self, bstar: torch.Tensor, train: bool, tape: Optional[list]) -> torch.Tensor:
+        """bstar [B,H,W,64] = cat(pc0 canvas, pc1 canvas) -> [B,H,W,64].  Appends what backward needs to `tape`."""
+        B, H, W, _ = bstar.shape
+        assert H % 8 == 0 and W % 8 == 0
+        dev = bstar.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        x = img_pair(bstar, 32)
+        cats: List[torch.Tensor] = []
+        h, w = H, W
+        for stage in (self.encoder_step_1, self.encoder_step_2, self.encoder_step_3):
+            for i, m in enumerate(stage):
+                if i == 0:
+                    h, w = h // 2, w // 2
+                C = m.conv.out_channels
+                if i == len(stage) - 1:
+                    cat = torch.empty(B, h, w, 2 * C, **f32)
+                    cats.append(cat)
+                    z = img_pair(cat, C)
+                    keep = cat
+                else:
+                    keep = torch.empty(2 * B, h, w, C, **f32)
+                    z = img(keep)
+                _cwn_forward(m, x, z, 2 * B, 2, train, tape)
+                if tape is not None:
+                    tape.append(("keep", keep))
+                x = z
+        fstar, lstar, rstar = cats
+        s = self._upsample_skip(self.decoder_step1, rstar, lstar, tape)
+        t = self._upsample_skip(self.decoder_step2, s, fstar, tape)
+        u = self._upsample_skip(self.decoder_step3, t, bstar, tape)
+        v = torch.empty(B, H, W, 64, **f32)
+        self._conv(self.decoder_step4, u, img(v), 3, tape)
+        return v
+
+    def _conv(self, m: nn.Conv2d, x: torch.Tensor, y: DfImg, ks: int, tape: Optional[list]):
+        ops.conv2d(img(x), ops.ohwi(m.weight), m.bias.detach(), y, ks, 1)
+        if tape is not None:
+            tape.append(("conv", m, x, ks))
+
+    def _upsample_skip(self, m: UpsampleSkip, a: torch.Tensor, b: torch.Tensor, tape: Optional[list]) -> torch.Tensor:
+        B, h, w, _ = a.shape
+        lat, outc = m.u3.out_channels, m.u4_u5[1].out_channels
+        f32 = dict(dtype=torch.float32, device=a.device)
+        t = torch.empty(B, h, w, lat, **f32)
+        self._conv(m.u1_u2[0], a, img(t), 1, tape)
+        cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **f32)
+        ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
+        if tape is not None:
+            tape.append(("up", h, w, lat))
+        self._conv(m.u3, b, img(cat, lat, lat), 1, tape)
+        u4 = torch.empty(B, 2 * h, 2 * w, outc, **f32)
+        self._conv(m.u4_u5[0], cat, img(u4), 3, tape)
+        u5 = torch.empty(B, 2 * h, 2 * w, outc, **f32)
+        self._conv(m.u4_u5[1], u4, img(u5), 3, tape)
+        return u5
+
+    # ------------------------------------------------------------------------------ backward ----
+    @staticmethod
+    def _conv_bwd(m: nn.Conv2d, x: DfImg, dy: DfImg, ks: int, stride: int, dx: Optional[DfImg], acc_dx: bool,
+                  grads: dict, with_bias: bool = True):
+        w = ops.ohwi(m.weight)
+        dev = w.device
+        if dx is not None:
+            ops.conv2d(dy, ops.weight_transpose(w), None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
+        dw = torch.empty_like(w)  # [O,kh,kw,I] memory
+        ops.conv2d_wgrad(x, dy, ks, stride, dw)
+        grads[m.weight] = dw.permute(0, 3, 1, 2)  # logical [O,I,kh,kw], channels_last strides
+        if with_bias:
+            grads[m.bias] = ops.colsum(dy, dev)
+
+    def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict
+                     ) -> torch.Tensor:
+        """Consumes the tape of run(train=True).  dv [B,H,W,64].  Returns d(bstar) [B,H,W,64] (added to `dbstar`
+        if given).  Parameter gradients go to `grads` {param: tensor}."""
+        B, H, W, _ = bstar.shape
+        dev = bstar.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        tape = list(tape)
+
+        def pop(kind):
+            e = tape.pop()
+            assert e[0] == kind, (e[0], kind)
+            return e
+
+        def plain_conv_bwd(dy: torch.Tensor, dx: Optional[DfImg], acc: bool):
+            _, m, x, ks = pop("conv")
+            self._conv_bwd(m, img(x), img(dy), ks, 1, dx, acc, grads)
+
+        def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: DfImg, acc_b: bool):
+            # reverse of: u1(a)->t ; up(t)->cat[:lat] ; u3(b)->cat[lat:] ; u4(cat) ; u5(u4)
+            _, m5, x5, _ = tape[-1]
+            du4 = torch.empty_like(x5)
+            plain_conv_bwd(dout, img(du4), False)
+            _, m4, x4, _ = tape[-1]
+            dcat = torch.empty_like(x4)
+            plain_conv_bwd(du4, img(dcat), False)
+            lat = dcat.shape[3] // 2
+            # u3
+            _, m3, xb, ks = pop("conv")
+            self._conv_bwd(m3, img(xb), img(dcat, lat, lat), 1, 1, db, acc_b, grads)
+            _, h, w, lat_ = pop("up")
+            dt = torch.empty(B, h, w, lat, **f32)
+            ops.upsample2x_bwd(img(dcat, lat, 0), img(dt), self.align_corners)
+            _, m1, xa, ks = pop("conv")
+            self._conv_bwd(m1, img(xa), img(dt), 1, 1, da, acc_a, grads)
+
+        # decoder_step4
+        _, m, xu, _ = tape[-1]
+        du = torch.empty_like(xu)
+        plain_conv_bwd(dv, img(du), False)
+        # decoder_step3: a = T, b = bstar
+        if dbstar is None:
+            dbstar = torch.empty(B, H, W, 64, **f32)
+            acc_b = False
+        else:
+            acc_b = True
+        dT = torch.empty(B, H // 2, W // 2, 128, **f32)
+        upsample_skip_bwd(du, img(dT), False, img(dbstar), acc_b)
+        dF = torch.empty(B, H // 2, W // 2, 128, **f32)   # d(fstar)
+        dS = torch.empty(B, H // 4, W // 4, 256, **f32)
+        upsample_skip_bwd(dT, img(dS), False, img(dF), False)
+        dL = torch.empty(B, H // 4, W // 4, 256, **f32)   # d(lstar)
+        dR = torch.empty(B, H // 8, W // 8, 512, **f32)   # d(rstar)
+        upsample_skip_bwd(dS, img(dR), False, img(dL), False)
+        # encoder, stages 3..1; dz of a stage's last layer lives in the concatenated gradient buffer
+        stage_in_grads = {3: (dL, 128), 2: (dF, 64), 1: (dbstar, 32)}
+        dz = img_pair(dR, 256)
+        for sidx, stage in ((3, self.encoder_step_3), (2, self.encoder_step_2), (1, self.encoder_step_1)):
+            for i in reversed(range(len(stage))):
+                pop("keep")
+                _, m, x, y, bn_ss, ipg, groups = pop("cwn")
+                dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups)
+                grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
+                if i > 0:
+                    dxt = torch.empty(2 * B, x.h, x.w, x.c, **f32)
+                    dx, acc = img(dxt), False
+                else:
+                    buf, c = stage_in_grads[sidx]
+                    dx, acc = img_pair(buf, c), True
+                self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False)
+                dz = dx
+        assert not tape
+        return dbstar
+
+    # -- reference-compatible call: backbone(pc0_img, pc1_img) on NCHW tensors (no autograd) -----------
+    def forward(self, pc0_B: torch.Tensor, pc1_B: torch.Tensor) -> torch.Tensor:
+        bstar = torch.cat([pc0_B, pc1_B], dim=1).permute(0, 2, 3, 1).contiguous()
+        with torch.no_grad():
+            v = self.run(bstar, self.training, None)
+        return v.permute(0, 3, 1, 2)

@@ -1,0 +1,212 @@
+/* deflow_amd.h -- C ABI of the MI355X-native DeFlow hot path (libdeflow_amd.so).
+ *
+ * The reference has no C/FFI plugin interface: its boundary is the Python class contract of
+ * `model=deflow` ([REF deflow.py:20-113]) plus two native CUDA ops it builds from
+ * `assets/cuda/mmcv` ([REF README.md:38]: dynamic voxelize + dynamic scatter).  This header is
+ * what a maintainer binds instead of those ops and instead of the torch/cuDNN calls made by
+ * the model blocks; INTEGRATION.md shows the ctypes stub.  Every entry point
+ *   - takes raw DEVICE pointers, explicit sizes and a hipStream_t (as void*),
+ *   - never allocates, never synchronises, is safe to call from any host thread per stream,
+ *   - returns 0 on success, a negative DF_E_* code for a rejected argument, or a positive
+ *     hipError_t from the launch.
+ * All activations are NHWC ("pixel-major"): element (n,y,x,c) of an image set lives at
+ *   ptr + (n % grp_size) * img_stride + (n / grp_size) * grp_off + (y * w + x) * ld + c.
+ * A plain [N,H,W,C] tensor has grp_size = N, grp_off = 0, ld = C, img_stride = H*W*C.
+ * The (grp_size, grp_off) pair lets the two point clouds' feature maps share one channel-
+ * concatenated buffer ([REF deflow.py:93] torch.cat((pc0_img, pc1_img), dim=1)) with no copy.
+ */
+#ifndef DEFLOW_AMD_H
+#define DEFLOW_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DF_OK 0
+#define DF_E_SHAPE -1    /* unsupported / inconsistent shape */
+#define DF_E_ALIGN -2    /* pointer or stride not 16-byte aligned where required */
+#define DF_E_ARG -3      /* bad enum / null pointer */
+#define DF_E_WORKSPACE -4
+
+typedef struct df_img {
+  void* ptr;
+  int32_t n, h, w, c; /* images, rows, cols, channels addressed */
+  int32_t ld;         /* elements between consecutive pixels */
+  int32_t grp_size;   /* images per group */
+  int64_t img_stride; /* elements between images inside a group */
+  int64_t grp_off;    /* element offset of group g */
+} df_img;
+
+int df_version(void);
+
+/* ---------------------------------------------------------------- pillarise (A2-A4) ----
+ * Replaces mmcv Voxelization(max_num_points=-1) + DynamicScatter + DynamicPillarFeatureNet +
+ * PointPillarsScatter as used by DynamicEmbedder ([REF deflow.py:27-30,82-83]).           */
+typedef struct df_pillar_geom {
+  float vx, vy, vz;          /* voxel size (fp32, as mmcv's tensors hold it)              */
+  float minx, miny, minz;    /* point_cloud_range[:3]                                      */
+  float offx, offy, offz;    /* v/2 + min computed in double then rounded (feature net)    */
+  int32_t gx, gy, gz;        /* grid = round((max-min)/v); gz must be 1 (pillars)          */
+} df_pillar_geom;
+
+/* step 1: per point voxel coords / validity / sort key; per-256-point-block valid counts.
+ * pts [B,N,3] f32 (NaN rows = padding).  key [B*N] u32 = b*gy*gx + y*gx + x, or B*gy*gx if dropped.
+ * blk_cnt [B, ceil(N/256)] i32. */
+int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt, void* stream);
+/* step 2: per-sample exclusive scan of blk_cnt -> blk_off (same shape), counts[b] = M_b. */
+int df_pillar_scan(const int32_t* blk_cnt, int B, int nblk, int32_t* blk_off, int32_t* counts, void* stream);
+/* step 3: stable compaction in original order.  Outputs are padded [B,N,...]; rows >= M_b untouched.
+ * points_c [B,N,3] f32, coords_c [B,N,3] i32 (z,y,x), idx_c [B,N] i64, offs_c [B,N,3] f32,
+ * cpos [B*N] i32 = compact position of each original point (or -1). */
+int df_pillar_compact(const float* pts, const uint32_t* key, const int32_t* blk_off, int B, int N, df_pillar_geom g,
+                      float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c, int32_t* cpos, void* stream);
+/* step 4: stable sort of (key, original flat index b*N+n) by key.  ws: df_pillar_sort_ws_bytes(n). */
+int64_t df_pillar_sort_ws_bytes(int64_t n);
+int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_t* idx_out, int64_t n, int key_bits,
+                   void* ws, int64_t ws_bytes, void* stream);
+/* step 5: dense per-cell [start,end) table from the sorted keys.  cell_rng [B*gy*gx, 2] i32 must be zeroed. */
+int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream);
+/* step 6 (training): BatchNorm1d batch statistics of u = W f per sample.  partial [B, nblk_stat, 32, 2] f32 */
+int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B, df_pillar_geom g,
+                 const float* w_pfn /*[32,9]*/, float* partial, int nblk_stat, void* stream);
+/* finalize: per-sample scale/shift/mean/invstd from the partials, sequential running-stat update (one
+ * update per sample, as the reference calls feature_net once per sample).
+ * counts [B] i32 valid points; bn_ss [B,4,32] f32 = scale, shift, mean, invstd. */
+int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* bn_ss, void* stream);
+/* step 7: canvas.  Every cell of `out` (n=B images, c=32) is written: zeros, or the pillar mean (mode 0) /
+ * max (mode 1) of ReLU(BN(W f)).  bn_sample_stride = 128 (per-sample stats) or 0 (shared: eval). */
+int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B, df_pillar_geom g,
+                  const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, df_img out, int nblk,
+                  void* stream);
+/* backward (mean mode): pass A partial sums [B,nblk_stat,32,2] of (g_hat, g_hat*xhat); finalize -> dgamma, dbeta,
+ * coef [B,2,32] = (S1/M_b, S2/M_b); pass B dW partials [B*nblk_stat,32,9] (sum with df_colsum_finalize). */
+int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B, df_pillar_geom g,
+                     const float* w_pfn, const float* bn_ss, int bn_sample_stride, df_img gout, float* partial,
+                     int nblk_stat, void* stream);
+int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, float* dgamma,
+                        float* dbeta, int accumulate, float* coef, void* stream);
+int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B, df_pillar_geom g,
+                       const float* w_pfn, const float* bn_ss, int bn_sample_stride, const float* coef, df_img gout,
+                       float* dw_partial, int nblk_stat, void* stream);
+
+/* ------------------------------------------------------------- BEV convolutions (A5) ---
+ * Replaces torch.nn.Conv2d / BatchNorm2d / GELU / interpolate inside FastFlow3DUNet and
+ * ConvWithNorms ([REF decoder.py:202-220]).  fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM. */
+
+#define DF_CONV_FWD 0   /* y[p] = sum_k x[p*stride + k - pad] w[.,k,.]                 */
+#define DF_CONV_DGRAD 1 /* y[p] = sum_k x[(p + pad - k)/stride] w[.,k,.] if divisible  */
+#define DF_EPI_BIAS 0   /* y = acc (+ bias)                                            */
+#define DF_EPI_STATS 1  /* + per-tile per-channel (sum, sumsq) partials for BatchNorm  */
+#define DF_EPI_BN_GELU 2 /* y = gelu((acc + bias) * scale[c] + shift[c]) (eval mode)   */
+
+/* w [Cout, k*k, Cin] f32 (OHWI).  bias/scale/shift may be NULL when unused.
+ * stats_partial [tiles_m, Cout, 2] with tile_m = df_conv2d_tile_m(rows per stat group, Cout) rows per tile.
+ * accumulate != 0: y += result (used to sum gradients arriving from two consumers). */
+int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
+              int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+              int accumulate, void* stream);
+int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick */
+/* BatchNorm2d training statistics from the partials. groups = stat groups (the shared encoder is
+ * applied to pc0 then pc1: two calls => two groups, running stats updated in call order).
+ * bn_ss [groups,4,C] = scale, shift, mean, invstd. */
+int df_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, float* bn_ss, void* stream);
+/* z = gelu(y * scale + shift) ; y plain [n,h,w,C]; imgs_per_group images share one stat group */
+int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream);
+/* backward of z = gelu(bn(y)): pass 1 partial sums [nblk, C, 2] of (dyh, dyh*xhat) */
+int df_bn_gelu_bwd_reduce(df_img dz, const float* y, const float* bn_ss, int imgs_per_group,
+                          float* partial, int nblk, void* stream);
+/* finalize: dgamma/dbeta += over groups; coef [groups,2,C] = (S1/N, S2/N). partial rows are per group contiguous */
+int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
+                       float* dgamma, float* dbeta, float* coef, void* stream);
+/* pass 2: dy = scale * (dyh - c1 - xhat * c2) (plain [n,h,w,C]); dbias partial [nblk, C] */
+int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef, int imgs_per_group,
+                         float* dy, float* dbias_partial, int nblk, void* stream);
+/* generic column sums: out[c] = sum over partial rows (used for conv bias grads etc.) */
+int df_colsum_partial(df_img x, float* partial, int nblk, void* stream);
+int df_colsum_finalize(const float* partial, int nblk, int C, int nvals, float* out, int accumulate, void* stream);
+/* weight layout helpers: wt[ci][k][co] = w[co][k][ci] */
+int df_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+/* dW[co][k][ci] (row stride ldw elements between co rows... taps*cin when dense) = sum_p dy[p][co] x[p*s+k-pad][ci].
+ * ws: splits * Cout * taps * Cin floats, splits = df_conv2d_wgrad_splits(...). */
+int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride);
+/* row_counts (optional, 1x1 with h == 1 only): pixel p is summed only if p % rows_per_seg < row_counts[p / rows_per_seg]
+ * (padded per-sample point rows of the decoder). */
+int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
+                    const int32_t* row_counts, int rows_per_seg, void* stream);
+int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
+                           int accumulate, void* stream);
+/* bilinear x2 (PyTorch F.interpolate semantics, align_corners selectable), forward and backward */
+int df_upsample2x(df_img x, df_img y, int align_corners, void* stream);
+int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* stream);
+
+/* ------------------------------------------------------- point decoder (A6-A10) --------
+ * Replaces ConvGRUDecoder / LinearDecoder forward_single ([REF decoder.py:72-199]): integer
+ * gather of the 2x64 pillar vectors, offset encoder, num_iters GRU steps, MLP head.        */
+typedef struct df_gru_weights {
+  const float* w_off; const float* b_off;   /* [64,3], [64]                       */
+  const float* w_zr;  const float* b_zr;    /* [256,192] (z rows then r rows), [256] */
+  const float* w_q;   const float* b_q;     /* [128,192], [128]                   */
+  const float* w_1;   const float* b_1;     /* [32,192], [32]                     */
+  const float* w_2;   const float* b_2;     /* [3,32], [3]                        */
+} df_gru_weights;
+/* before/after: n=B images of 64 channels.  coords [B,N,3] i32 (z,y,x), offs [B,N,3], counts [B] (device).
+ * flow [B,N,3] (rows >= counts[b] untouched).  save (training, may be NULL):
+ *   [5, T, B*N, 128] = h_in, z, r, q, r*h per iteration, then hT [B*N,128]. */
+int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
+                       const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts,
+                       float* flow, float* save, void* stream);
+typedef struct df_gru_weights_t {          /* transposed copies (df_weight_transpose) for the data-gradient GEMMs */
+  const float* wt_zr; /* [192,256] */
+  const float* wt_q;  /* [192,128] */
+  const float* wt_1;  /* [192,32]  */
+} df_gru_weights_t;
+/* backward data pass.  Consumes dflow [B,N,3] and the forward's `save`; overwrites save's z, r, q planes with
+ * dz_pre, dr_pre, dq_pre (inputs of the weight-gradient GEMMs); writes dh0 [B*N,128], dx [B*N,64],
+ * dpre1 [B*N,32], hid [B*N,32], xout [B*N,64] (rows of valid points only). */
+int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
+                       df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
+                       float* hid, float* xout, void* stream);
+/* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
+ * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
+ * with accumulate_* != 0, added to. */
+int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
+                  int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
+                  int nblk, void* stream);
+/* partial[blk][i*nb+j] = sum over valid rows of a[row][i] * (b ? b[row][j] : 1); row r is valid iff
+ * r % rows_per_seg < counts[(r / rows_per_seg) % nseg].  na*nb <= 256.  Sum with df_colsum_finalize. */
+int df_small_outer(const float* a, int lda, int na, const float* b, int ldb, int nb, const int32_t* counts,
+                   int rows_per_seg, int nseg, int64_t rows, float* partial, int nblk, void* stream);
+/* LinearDecoder ([REF decoder.py:72-120]) forward: w_off [128,3], w_1 [32,256], w_2 [3,32] */
+int df_linear_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
+                          const int32_t* counts, int B, int N, const float* w_off, const float* b_off,
+                          const float* w_1, const float* b_1, const float* w_2, const float* b_2,
+                          float* flow, void* stream);
+
+/* ------------------------------------------------------------ ego motion + loss --------*/
+/* [REF deflow.py:60-77]: pc0' = pc0 R^T + t ; pose_flow = pc0' - pc0.  T [B,4,4] row-major. */
+int df_ego_transform(const float* pc0, const float* T, int B, int N, float* pc0_t, float* pose_flow, void* stream);
+/* deflowLoss over padded per-sample rows (rows < counts[b]): partial [B,nblk,3,2] (sum err, count);
+ * finalize -> bins [B,3,2], loss[0] = sum_b sum_bins mean; bwd -> dest = gscale * (*gscale_dev) * dloss/dest. */
+int df_deflow_loss_fwd(const float* est, const float* gt, const int32_t* counts, int B, int N,
+                       float* bins_partial, int nblk, void* stream);
+int df_deflow_loss_finalize(const float* bins_partial, int B, int nblk, float* bins, float* loss, void* stream);
+int df_deflow_loss_bwd(const float* est, const float* gt, const int32_t* counts, int B, int N, const float* bins,
+                       const float* gscale_dev /*nullable*/, float gscale, float* dest, int nblk, void* stream);
+/* trainer gt: gt[b,i] = flow[b, idx_c[b,i]] - pose_flow[b, idx_c[b,i]] for i < counts[b] */
+int df_gather_gt(const float* flow, const float* pose_flow, const int64_t* idx_c, const int32_t* counts,
+                 int B, int N, float* gt, int nblk, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (A12) ----
+ * torch.optim.Adam (defaults: no amsgrad, no weight decay) over ONE flat fp32 arena holding every
+ * parameter; grad/exp_avg/exp_avg_sq are arenas of the same layout.  n % 4 == 0. */
+int df_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
