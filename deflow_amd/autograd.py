@@ -9,8 +9,24 @@ import torch
 from ._lib import img, call, ptr, stream
 
 
-def _grads_for(params: List[torch.Tensor], grads: dict):
-    return tuple(grads.get(p) for p in params)
+class GradDict(dict):
+    """parameter -> gradient, keyed by storage address (robust to autograd re-wrapping tensor objects)"""
+
+    def __setitem__(self, p: torch.Tensor, g: torch.Tensor):
+        super().__setitem__(p.data_ptr(), g)
+
+    def lookup(self, p: torch.Tensor):
+        return super().get(p.data_ptr())
+
+
+def _grads_for(params: List[torch.Tensor], grads: "GradDict"):
+    out = []
+    for p in params:
+        g = grads.lookup(p)
+        if g is not None and g.shape != p.shape:
+            g = g.reshape(p.shape)
+        out.append(g)
+    return tuple(out)
 
 
 class GruHeadFn(torch.autograd.Function):
@@ -31,7 +47,7 @@ class GruHeadFn(torch.autograd.Function):
         dev = dflow.device
         db = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         da = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
-        grads: dict = {}
+        grads = GradDict()
         head.run_backward(dflow, ps, ctx.sv, img(db), img(da), False, False, grads)
         ctx.sv = None
         return (None, None, db.permute(0, 3, 1, 2), da.permute(0, 3, 1, 2)) + _grads_for(ctx.params, grads)
@@ -52,7 +68,7 @@ class DeFlowFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dflow):
         model, st = ctx.model, ctx.state
-        grads: dict = {}
+        grads = GradDict()
         bstar = st["bstar"]
         B, H, W, _ = bstar.shape
         dev = bstar.device

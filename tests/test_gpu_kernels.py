@@ -1,0 +1,345 @@
+"""GPU: every HIP kernel family through the C ABI against a plain fp32 computation of the same op on the CPU
+(torch ops / the oracle).  Tolerance: max |got - want| <= TOL * max |want| (north_star: 1e-4 rel for floating
+point); integer outputs must be bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box (gpurun)"
+    from deflow_amd import _lib
+    _lib.load()
+    return torch.device("cuda")
+
+
+def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), "non-finite values in kernel output"
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def check(name, got, want, tol=TOL):
+    e = rel_err(got, want)
+    print(f"[parity] {name}: rel_err={e:.3e} (tol {tol:.0e})")
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+
+
+def nhwc(x):  # NCHW cpu -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------- conv ----
+CONV_CASES = [  # cin, cout, k, stride, n, h, w
+    (32, 64, 3, 2, 2, 16, 16), (64, 64, 3, 1, 2, 16, 16), (128, 128, 3, 1, 1, 16, 16), (256, 256, 3, 1, 1, 8, 8),
+    (512, 256, 1, 1, 2, 8, 8), (64, 64, 1, 1, 3, 12, 20), (128, 64, 3, 1, 1, 24, 8), (64, 128, 3, 2, 2, 16, 32),
+    (64, 64, 3, 1, 4, 64, 64),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,n,h,w", CONV_CASES)
+def test_conv_fwd(dev, cin, cout, k, s, n, h, w):
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + s)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    want = F.conv2d(x, wt, b, stride=s, padding=k // 2)
+    xd = nhwc(x).to(dev)
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last)
+    y = torch.empty(n, want.shape[2], want.shape[3], cout, device=dev)
+    ops.conv2d(img(xd), ops.ohwi(wd), b.to(dev), img(y), k, s)
+    check(f"conv_fwd {cin}->{cout} k{k} s{s}", nchw(y), want)
+
+
+def test_conv_pair_views_and_accumulate(dev):
+    """input read through the 2-cloud concatenated view, output written into a channel slice, accumulate epilogue"""
+    from deflow_amd import ops
+    from deflow_amd._lib import img, img_pair
+    g = torch.Generator().manual_seed(5)
+    B, h, w = 2, 16, 16
+    cat = torch.randn(B, h, w, 64, generator=g)              # [pc0 32 | pc1 32]
+    wt = torch.randn(64, 32, 3, 3, generator=g) / 17
+    b = torch.randn(64, generator=g)
+    x_pc = torch.cat([cat[..., :32], cat[..., 32:]], 0)       # 2B images
+    want = F.conv2d(nchw(x_pc), wt, b, padding=1)
+    catd = cat.to(dev)
+    out = torch.zeros(B, h, w, 128, device=dev)
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last)
+    ops.conv2d(img_pair(catd, 32), ops.ohwi(wd), b.to(dev), img_pair(out, 64), 3, 1)
+    got = torch.cat([out[..., :64], out[..., 64:]], 0)
+    check("conv pair view", nchw(got), want)
+    base = torch.randn(B, h, w, 128, generator=g)
+    out2 = base.to(dev).clone()
+    ops.conv2d(img_pair(catd, 32), ops.ohwi(wd), b.to(dev), img_pair(out2, 64), 3, 1, accumulate=True)
+    got2 = torch.cat([out2[..., :64], out2[..., 64:]], 0).cpu() - torch.cat([base[..., :64], base[..., 64:]], 0)
+    check("conv accumulate", nchw(got2), want, tol=5e-4)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,n,h,w", [(64, 64, 3, 1, 2, 16, 16), (32, 64, 3, 2, 2, 16, 16), (64, 128, 3, 2, 1, 32, 16),
+                                               (256, 128, 1, 1, 2, 8, 16), (128, 256, 3, 1, 1, 8, 8)])
+def test_conv_dgrad_wgrad(dev, cin, cout, k, s, n, h, w):
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin + 3 * cout + k + s)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=s, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, gyd = nhwc(x.detach()).to(dev), nhwc(gy).to(dev)
+    wd = ops.ohwi(wt.detach().to(dev).contiguous(memory_format=torch.channels_last))
+    dx = torch.empty_like(xd)
+    ops.conv2d(img(gyd), ops.weight_transpose(wd), None, img(dx), k, s, mode=ops.CONV_DGRAD)
+    check(f"conv_dgrad {cin}->{cout} k{k} s{s}", nchw(dx), x.grad)
+    dw = torch.empty_like(wd)
+    ops.conv2d_wgrad(img(xd), img(gyd), k, s, dw)
+    check(f"conv_wgrad {cin}->{cout} k{k} s{s}", dw.permute(0, 3, 1, 2), wt.grad)
+    db = ops.colsum(img(gyd), dev)
+    check("bias grad (colsum)", db, gy.sum((0, 2, 3)))
+
+
+# ---------------------------------------------------------------------------- BN + GELU -----------
+@pytest.mark.parametrize("groups", [1, 2])
+def test_convwithnorms_train_fwd_bwd(dev, groups):
+    """conv + BatchNorm2d(batch stats, per group) + GELU, forward, running stats and full backward"""
+    from deflow_amd import ops
+    from deflow_amd.unet import ConvWithNorms, _cwn_forward
+    from deflow_amd._lib import img
+    from oracle import ref_torch as O
+    torch.manual_seed(11 + groups)
+    n, cin, cout, h, w = 2 * groups, 32, 64, 16, 16
+    ref = O.ConvWithNorms(cin, cout, 3, 1, 1).train()
+    with torch.no_grad():
+        ref.batchnorm.weight.uniform_(0.5, 1.5); ref.batchnorm.bias.uniform_(-0.3, 0.3)
+    mine = ConvWithNorms(cin, cout, 3, 1, 1).train()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    x = torch.randn(n, cin, h, w, requires_grad=True)
+    ipg = n // groups
+    outs = [ref(x[g * ipg:(g + 1) * ipg]) for g in range(groups)]  # one reference call per group, in order
+    want = torch.cat(outs, 0)
+    gz = torch.randn(want.shape)
+    want.backward(gz)
+    xd = nhwc(x.detach()).to(dev)
+    z = torch.empty(n, h, w, cout, device=dev)
+    tape = []
+    _cwn_forward(mine, img(xd), img(z), n, groups, True, tape)
+    check(f"cwn train fwd g{groups}", nchw(z), want)
+    check("running_mean", mine.batchnorm.running_mean, ref.batchnorm.running_mean)
+    check("running_var", mine.batchnorm.running_var, ref.batchnorm.running_var)
+    _, m, xi, y, bn_ss, ipg_, groups_ = tape[0]
+    dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(nhwc(gz).to(dev)), y, bn_ss, ipg_, groups_)
+    wd = ops.ohwi(mine.conv.weight)
+    dx = torch.empty_like(xd)
+    ops.conv2d(img(dy), ops.weight_transpose(wd), None, img(dx), 3, 1, mode=ops.CONV_DGRAD)
+    dw = torch.empty_like(wd)
+    ops.conv2d_wgrad(img(xd), img(dy), 3, 1, dw)
+    check("cwn dx", nchw(dx), x.grad, tol=5e-4)
+    check("cwn dW", dw.permute(0, 3, 1, 2), ref.conv.weight.grad, tol=5e-4)
+    check("cwn dgamma", dgamma, ref.batchnorm.weight.grad, tol=5e-4)
+    check("cwn dbeta", dbeta, ref.batchnorm.bias.grad, tol=5e-4)
+    assert float(dbias.abs().max()) <= 1e-3 * float(gz.abs().sum())  # mathematically zero under BatchNorm
+
+
+@pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1"])
+def test_convwithnorms_golden(dev, golden_dir, tag):
+    """REAL reference vectors ([REF decoder.py:202-220] executed by oracle/gen_golden.py)"""
+    import os
+    from deflow_amd.unet import ConvWithNorms
+    g = dict(np.load(os.path.join(golden_dir, f"g4_convwithnorms_{tag}.npz")))
+    cin, cout = g["w0.conv.weight"].shape[1], g["w0.conv.weight"].shape[0]
+    m = ConvWithNorms(cin, cout, int(g["k"]), int(g["s"]), int(g["p"]))
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w0.")})
+    m = m.to(dev).train(bool(g["train"]))
+    y = m(torch.from_numpy(g["x"]).to(dev))
+    check(f"golden cwn {tag} y", y, torch.from_numpy(g["y"]))
+    check("golden running_mean", m.batchnorm.running_mean, torch.from_numpy(g["w1.batchnorm.running_mean"]))
+    check("golden running_var", m.batchnorm.running_var, torch.from_numpy(g["w1.batchnorm.running_var"]))
+
+
+# ---------------------------------------------------------------------------- upsample ---------------
+@pytest.mark.parametrize("ac", [False, True])
+def test_upsample2x(dev, ac):
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 6, 10, generator=g, requires_grad=True)
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=ac)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    xd = nhwc(x.detach()).to(dev)
+    cat = torch.zeros(2, 12, 20, 128, device=dev)  # write into a channel slice of a concat buffer
+    ops.upsample2x(img(xd), img(cat, 64, 64), ac)
+    check(f"upsample fwd ac={ac}", nchw(cat[..., 64:]), want)
+    assert float(cat[..., :64].abs().max()) == 0.0
+    gcat = torch.zeros(2, 12, 20, 128)
+    gcat[..., 64:] = nhwc(gy)
+    dx = torch.empty_like(xd)
+    ops.upsample2x_bwd(img(gcat.to(dev), 64, 64), img(dx), ac)
+    check(f"upsample bwd ac={ac}", nchw(dx), x.grad)
+
+
+# ---------------------------------------------------------------------------- pillarise -----------
+def _cloud(B, N, seed, extent):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.cat([torch.randn(B, N, 2, generator=g) * extent * 0.4, torch.rand(B, N, 1, generator=g) * 6.6 - 3.3], 2)
+    pts[:, -N // 50:] = float("nan")
+    pts[0, 5] = torch.tensor([-extent, -extent, -3.0])        # exactly on the lower corner
+    pts[0, 6] = torch.tensor([extent, 0.0, 0.0])              # exactly on the (exclusive) upper bound
+    pts[0, 7:12] = torch.tensor([0.31, 0.47, 0.1])            # five points in one pillar
+    return pts
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_pillarize_vs_oracle(dev, train):
+    from deflow_amd.encoder import DynamicEmbedder
+    from oracle import ref_torch as O
+    vs, rng, dims = [0.2, 0.2, 6], [-6.4, -6.4, -3, 6.4, 6.4, 3], [64, 64]
+    torch.manual_seed(21)
+    ref = O.DynamicEmbedder(vs, dims, rng, 32)
+    bn = ref.feature_net.pfn_layers[0][1]
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    mine = DynamicEmbedder(vs, dims, rng, 32)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    ref.train(train); mine.train(train)
+    pts = _cloud(3, 700, 33, 6.4)
+    with torch.no_grad():
+        want_img, want_infos = ref(pts)
+    got_img, got_infos = mine(pts.to(dev))
+    for b in range(3):
+        for k in ("voxel_coords", "point_idxes"):  # integer work: bit exact
+            assert torch.equal(got_infos[b][k].cpu().long(), want_infos[b][k].long()), (b, k)
+        assert torch.equal(got_infos[b]["points"].cpu(), want_infos[b]["points"])
+        assert torch.equal(got_infos[b]["point_offsets"].cpu(), want_infos[b]["point_offsets"]), "offsets are exact fp32 ops"
+    check(f"pseudoimage train={train}", got_img, want_img)
+    if train:
+        check("bn1d running_mean", mine._bn.running_mean, bn.running_mean)
+        check("bn1d running_var", mine._bn.running_var, bn.running_var)
+
+
+def test_pillarize_backward(dev):
+    from deflow_amd.encoder import DynamicEmbedder
+    from deflow_amd._lib import img
+    from oracle import ref_torch as O
+    vs, rng, dims = [0.2, 0.2, 6], [-6.4, -6.4, -3, 6.4, 6.4, 3], [64, 64]
+    torch.manual_seed(22)
+    ref = O.DynamicEmbedder(vs, dims, rng, 32).train()
+    mine = DynamicEmbedder(vs, dims, rng, 32).train()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    pts = _cloud(2, 500, 44, 6.4)
+    out, _ = ref(pts)
+    gout = torch.randn(out.shape)
+    out.backward(gout)
+    canvas = torch.empty(2, 64, 64, 32, device=dev)
+    st = mine.pillarize(pts.to(dev), img(canvas), True)
+    dW, dgamma, dbeta = mine.pillarize_bwd(st, img(nhwc(gout).to(dev)), None)
+    lin, bn = ref.feature_net.pfn_layers[0][0], ref.feature_net.pfn_layers[0][1]
+    check("pfn dW", dW, lin.weight.grad, tol=5e-4)
+    check("pfn dgamma", dgamma, bn.weight.grad, tol=5e-4)
+    check("pfn dbeta", dbeta, bn.bias.grad, tol=5e-4)
+
+
+# ---------------------------------------------------------------------------- decoder -------------
+def _load_head(cls, g, dev, **kw):
+    m = cls(**kw)
+    m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")})
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("iters", [1, 4, 8])
+def test_gru_decoder_golden(dev, golden_dir, iters):
+    """REAL reference vectors: ConvGRUDecoder forward + all gradients ([REF decoder.py:141-199])"""
+    import os
+    from deflow_amd.decoder import ConvGRUDecoder
+    g = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}.npz")))
+    m = _load_head(ConvGRUDecoder, g, dev, num_iters=iters)
+    before = torch.from_numpy(g["before"]).to(dev).requires_grad_(True)
+    after = torch.from_numpy(g["after"]).to(dev).requires_grad_(True)
+    infos = [{"voxel_coords": torch.from_numpy(g[f"vc{i}"]), "point_offsets": torch.from_numpy(g[f"off{i}"])} for i in range(3)]
+    flows = m(before, after, infos)
+    assert [f.shape[0] for f in flows] == [333, 0, 1]
+    for i in (0, 2):
+        check(f"gru it{iters} flow{i}", flows[i], torch.from_numpy(g[f"flow{i}"]))
+    loss = sum((f * torch.from_numpy(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows))
+    loss.backward()
+    check("gru d(before)", before.grad, torch.from_numpy(g["gbefore"]), tol=5e-4)
+    check("gru d(after)", after.grad, torch.from_numpy(g["gafter"]), tol=5e-4)
+    for k, p in m.named_parameters():
+        check(f"gru grad {k}", p.grad, torch.from_numpy(g["gw." + k]), tol=5e-4)
+
+
+def test_linear_decoder_golden(dev, golden_dir):
+    import os
+    from deflow_amd.decoder import LinearDecoder
+    g = dict(np.load(os.path.join(golden_dir, "g3_lineardecoder.npz")))
+    m = _load_head(LinearDecoder, g, dev)
+    infos = [{"voxel_coords": torch.from_numpy(g[f"vc{i}"]), "point_offsets": torch.from_numpy(g[f"off{i}"])} for i in range(2)]
+    flows = m(torch.from_numpy(g["before"]).to(dev), torch.from_numpy(g["after"]).to(dev), infos)
+    for i, f in enumerate(flows):
+        check(f"linear flow{i}", f, torch.from_numpy(g[f"flow{i}"]))
+
+
+# ---------------------------------------------------------------------------- misc ----------------
+def test_ego_transform_loss_adam(dev):
+    from deflow_amd._lib import call, ptr, stream
+    from deflow_amd.autograd import DeflowLossFn
+    from oracle import ref_torch as O
+    g = torch.Generator().manual_seed(8)
+    B, N = 3, 1000
+    pc0 = torch.randn(B, N, 3, generator=g) * 10
+    pc0[:, -20:] = float("nan")
+    T = torch.eye(4).repeat(B, 1, 1)
+    for b in range(B):
+        a = 0.02 * (b + 1)
+        T[b, :2, :2] = torch.tensor([[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]])
+        T[b, :3, 3] = torch.tensor([0.5 * b, 0.1, 0.0])
+    want = torch.stack([pc0[b] @ T[b, :3, :3].T + T[b, :3, 3] for b in range(B)])
+    out, pf = torch.empty(B, N, 3, device=dev), torch.empty(B, N, 3, device=dev)
+    call("df_ego_transform", ptr(pc0.to(dev)), ptr(T.to(dev)), B, N, ptr(out), ptr(pf), stream())
+    ok = ~torch.isnan(want)
+    check("ego transform", out.cpu()[ok], want[ok], tol=1e-6)
+    assert torch.isnan(out.cpu()[~ok]).all()
+    check("pose flow", pf.cpu()[ok], (want - pc0)[ok], tol=1e-5)
+    # loss: padded rows, three bins, against the oracle's per-sample loss
+    counts = torch.tensor([900, 0, 517], dtype=torch.int32)
+    gt = torch.randn(B, N, 3, generator=g) * torch.tensor([0.01, 0.08, 0.3])[:, None, None]
+    est = (gt + torch.randn(B, N, 3, generator=g) * 0.05).requires_grad_(True)
+    want_l = sum(O.deflow_loss(est[b, :counts[b]], gt[b, :counts[b]]) for b in range(B) if counts[b] > 0)
+    want_l.backward()
+    est_d = est.detach().to(dev).requires_grad_(True)
+    got_l = DeflowLossFn.apply(est_d, gt.to(dev), counts.to(dev))
+    (got_l * 1.0).backward()
+    check("deflowLoss", got_l.reshape(1), want_l.detach().reshape(1), tol=1e-5)
+    for b in range(B):
+        c = int(counts[b])
+        if c:
+            check(f"deflowLoss grad b{b}", est_d.grad[b, :c], est.grad[b, :c], tol=1e-4)
+    # Adam over a flat arena vs torch.optim.Adam
+    n = 4096
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4)
+    pd, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        call("df_adam_step", ptr(pd), ptr(gr.to(dev)), ptr(m), ptr(v), n, 2e-4, 0.9, 0.999, 1e-8, step, 1.0, stream())
+    check("adam 3 steps", pd, pr.detach(), tol=1e-6)

@@ -1,0 +1,194 @@
+"""GPU: the model=deflow plugin end to end against the CPU oracle (same weights, same seeded inputs), the
+reference-generated orchestration golden (G5), and size-independent properties at the BASELINE config sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-6.4, -6.4, -3, 6.4, 6.4, 3], grid_feature_size=[64, 64])
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+def rel_err(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def check(name, got, want, tol):
+    e = rel_err(got, want)
+    print(f"[parity] {name}: rel_err={e:.3e} (tol {tol:.0e})")
+    assert e <= tol, f"{name}: {e:.3e} > {tol:.1e}"
+
+
+def make_batch(B, N, seed, grid=64):
+    from deflow_amd.synth import synth_pair
+    pairs = [synth_pair(seed + b, N, grid_hw=(grid, grid)) for b in range(B)]
+    return {"pc0": torch.stack([p[0] for p in pairs]), "pc1": torch.stack([p[1] for p in pairs]),
+            "pose0": torch.stack([torch.eye(4) for _ in pairs]),
+            "pose1": torch.stack([torch.linalg.inv(p[2]) for p in pairs]),
+            "flow": torch.stack([p[3] for p in pairs])}
+
+
+def to_dev(batch, dev):
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+def build_pair(dev, seed=0, **kw):
+    import deflow_amd
+    from oracle import ref_torch as O
+    torch.manual_seed(seed)
+    ref = O.DeFlow(**SMALL, **kw)
+    with torch.no_grad():  # make BN affine / running stats non-trivial
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.6, 1.4); m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.5)
+    mine = deflow_amd.DeFlow(**SMALL, **kw)
+    mine.load_state_dict(ref.state_dict())
+    return ref, mine.to(dev)
+
+
+@pytest.mark.parametrize("opt", [dict(decoder_option="gru", num_iters=4), dict(decoder_option="linear"),
+                                 dict(decoder_option="gru", num_iters=2, align_corners=True)])
+def test_forward_eval_vs_oracle(dev, opt):
+    ref, mine = build_pair(dev, 1, **opt)
+    ref.eval(); mine.eval()
+    batch = make_batch(2, 1500, 100)
+    with torch.no_grad():
+        want = ref(batch)
+        got = mine(to_dev(batch, dev))
+    for b in range(2):
+        assert torch.equal(got["pc0_valid_point_idxes"][b].cpu(), want["pc0_valid_point_idxes"][b])
+        assert torch.equal(got["pc1_valid_point_idxes"][b].cpu(), want["pc1_valid_point_idxes"][b])
+        assert torch.equal(got["pc1_points_lst"][b].cpu(), want["pc1_points_lst"][b])
+        check(f"eval flow b{b} {opt}", got["flow"][b], want["flow"][b], 1e-4)
+        m = ~torch.isnan(want["pose_flow"][b])
+        check(f"pose_flow b{b}", got["pose_flow"][b].cpu()[m], want["pose_flow"][b][m], 1e-5)
+
+
+def test_train_step_vs_oracle(dev):
+    """forward in training mode (batch statistics), deflowLoss, backward: every parameter gradient vs the oracle's
+    autograd; BatchNorm running statistics after the step."""
+    from oracle import ref_torch as O
+    ref, mine = build_pair(dev, 2, decoder_option="gru", num_iters=4)
+    ref.train(); mine.train()
+    batch = make_batch(2, 1500, 200)
+    res_r = ref(batch)
+    loss_r = O.training_loss(res_r, batch)
+    loss_r.backward()
+    bd = to_dev(batch, dev)
+    res_m = mine(bd)
+    for b in range(2):
+        check(f"train flow b{b}", res_m["flow"][b], res_r["flow"][b], 2e-4)
+    loss_m = O.training_loss(res_m, bd)  # the trainer's own torch loss on the drop-in result dict
+    check("loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    loss_m.backward()
+    worst = 0.0
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        assert p.grad is not None, k
+        e = rel_err(p.grad, pr[k].grad)
+        worst = max(worst, e)
+        is_bn_shadowed_bias = k.endswith("conv.bias") and "encoder_step" in k  # exactly cancelled by BatchNorm: noise/noise
+        print(f"[parity] grad {k}: rel_err={e:.3e}")
+        if not is_bn_shadowed_bias:
+            assert e <= 2e-3, (k, e)
+    br = dict(ref.named_buffers())
+    for k, v in mine.named_buffers():
+        if v.dtype.is_floating_point:
+            check(f"buffer {k}", v, br[k], 1e-4)
+        else:
+            assert int(v) == int(br[k]), k
+    print(f"[parity] worst parameter-gradient rel err: {worst:.3e}")
+
+
+def test_fused_loss_path_matches_list_path(dev):
+    """the padded fast path (DeflowLossFn on last_state) == the drop-in list path"""
+    from deflow_amd.autograd import DeflowLossFn
+    from deflow_amd._lib import call, ptr, stream
+    from oracle import ref_torch as O
+    _, mine = build_pair(dev, 3, decoder_option="gru", num_iters=2)
+    mine.train()
+    bd = to_dev(make_batch(2, 1200, 300), dev)
+    res = mine(bd)
+    l1 = O.training_loss(res, bd)
+    st = mine.last_state
+    B, N, _ = st["flow"].shape
+    gt = torch.empty(B, N, 3, device=dev)
+    call("df_gather_gt", ptr(bd["flow"].contiguous()), ptr(st["pose_flow"]), ptr(st["idx_c0"]), ptr(st["counts0"]), B, N,
+         ptr(gt), 8, stream())
+    l2 = DeflowLossFn.apply(st["flow"], gt, st["counts0"])
+    check("fused loss", l2.reshape(1), l1.reshape(1), 1e-5)
+    g1 = torch.autograd.grad(l1, st["flow"], retain_graph=True)[0]
+    g2 = torch.autograd.grad(l2, st["flow"])[0]
+    for b in range(B):
+        c = int(st["counts0"][b])
+        check(f"fused loss grad b{b}", g2[b, :c], g1[b, :c], 1e-5)
+
+
+def test_g5_orchestration_golden(dev, golden_dir):
+    """reference deflow.py executed in the build container (oracle/gen_golden.py): result-dict contract"""
+    import deflow_amd
+    from oracle import ref_torch as O
+    g = dict(np.load(os.path.join(golden_dir, "g5_deflow_orchestration.npz")))
+    torch.manual_seed(int(g["seed"]))
+    ref = O.DeFlow(**SMALL, decoder_option="gru", num_iters=2)
+    mine = deflow_amd.DeFlow(**SMALL, decoder_option="gru", num_iters=2)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).eval()
+    batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc0", "pc1", "pose0", "pose1")}
+    with torch.no_grad():
+        res = mine(batch)
+    assert set(res) == {"flow", "pose_flow", "pc0_valid_point_idxes", "pc0_points_lst", "pc1_valid_point_idxes", "pc1_points_lst"}
+    for b in range(2):
+        assert torch.equal(res["pc0_valid_point_idxes"][b].cpu(), torch.from_numpy(g[f"pc0_valid_point_idxes.{b}"]))
+        assert torch.equal(res["pc1_valid_point_idxes"][b].cpu(), torch.from_numpy(g[f"pc1_valid_point_idxes.{b}"]))
+        check(f"g5 pc0_points b{b}", res["pc0_points_lst"][b], torch.from_numpy(g[f"pc0_points_lst.{b}"]), 1e-5)
+        check(f"g5 flow b{b}", res["flow"][b], torch.from_numpy(g[f"flow.{b}"]), 1e-4)
+        w = torch.from_numpy(g[f"pose_flow.{b}"])
+        m = ~torch.isnan(w)
+        check(f"g5 pose_flow b{b}", res["pose_flow"][b].cpu()[m], w[m], 1e-4)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 shape (512x512, 80k points, 4 iterations): size-independent properties."""
+    import deflow_amd
+    torch.manual_seed(0)
+    m = deflow_amd.DeFlow().to(dev).eval()
+    from deflow_amd.synth import synth_pair
+    p = synth_pair(20240116, 80000)
+    batch = {"pc0": p[0][None].to(dev), "pc1": p[1][None].to(dev), "pose0": torch.eye(4)[None].to(dev),
+             "pose1": torch.linalg.inv(p[2])[None].to(dev)}
+    with torch.no_grad():
+        r1 = m(batch)
+        r2 = m(batch)
+    f = r1["flow"][0]
+    assert torch.isfinite(f).all() and f.shape[1] == 3
+    assert torch.equal(r1["flow"][0], r2["flow"][0]), "the engine is deterministic (no float atomics)"
+    idx = r1["pc0_valid_point_idxes"][0]
+    assert (idx[1:] > idx[:-1]).all(), "valid indices are strictly increasing (stable compaction)"
+    pts = r1["pc0_points_lst"][0]
+    assert f.shape[0] == idx.shape[0] == pts.shape[0] and not torch.isnan(pts).any()
+    assert (pts[:, :2].abs() <= 51.2).all() and (pts[:, 2] >= -3).all() and (pts[:, 2] < 3).all()
+    # permuting the input points permutes the output rows (pillar sums are order-independent up to fp32 rounding)
+    perm = torch.randperm(80000, device=dev)
+    b2 = dict(batch); b2["pc0"] = batch["pc0"][:, perm]
+    with torch.no_grad():
+        r3 = m(b2)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(80000, device=dev)
+    orig_of_r3 = perm[r3["pc0_valid_point_idxes"][0]]
+    order = torch.argsort(orig_of_r3)
+    assert torch.equal(orig_of_r3[order], idx)
+    e = float((r3["flow"][0][order] - f).abs().max() / f.abs().max())
+    print(f"[property] permutation equivariance rel diff {e:.3e}")
+    assert e < 1e-3
