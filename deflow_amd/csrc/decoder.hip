@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
 }
 
 // ------------------------------------------------------------------------- LinearDecoder ---
-// [REF decoder.py:72-120]: flow = W2 gelu(W1 [before | after | offset_enc(128)] + b1) + b2.  K = 384.
+// [REF decoder.py:72-120]: flow = W2 gelu(W1 [before | after | offset_enc(128)] + b1) + b2.  K = 256.
 struct LinFwdParams {
   df_img before, after;
   const int32_t* coords;
@@ -195,7 +195,7 @@ struct LinFwdParams {
   const float *w_off, *b_off, *w_1, *b_1, *w_2, *b_2;
   float* flow;
 };
-constexpr int LDA_L = 388;
+constexpr int LDA_L = 260;
 constexpr int BSZ_L = 32 * LDB;  // B buffer of the 32-row weight tile  // 384 + 4; 97 slots of 16 B, 97 mod 16 = 1
 
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinFwdParams p) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinFwdParams p) {
   const int64_t grow0 = (int64_t)b * p.N + wp0;
   Stager stg;
   int par = 0;
-  stage_load<32>(stg, p.w_1, 384, 0);
+  stage_load<32>(stg, p.w_1, 256, 0);
   const float* bp = reinterpret_cast<const float*>(p.before.ptr) + df_img_base(p.before, b);
   const float* ap = reinterpret_cast<const float*>(p.after.ptr) + df_img_base(p.after, b);
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinFwdParams p) {
         const float* of = p.offs + (grow0 + pt) * 3;
         x = fmaf(w2, of[2], fmaf(w1, of[1], fmaf(w0, of[0], bo)));
       }
-      Aw[pt * LDA_L + 256 + o] = x;
+      Aw[pt * LDA_L + 128 + o] = x;
     }
   }
   stage_store<32>(stg, Bs);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinFwdParams p) {
     const float bia = p.b_1[16 * t + li];
     hid[t] = f32x4{bia, bia, bia, bia};
   }
-  gemm_stream<32, 32, BSZ_L>(p.w_1, 384, 12, nullptr, 0, Aw + li * LDA_L + lq * 4, Bs, par, hid, stg);
+  gemm_stream<32, 32, BSZ_L>(p.w_1, 256, 8, nullptr, 0, Aw + li * LDA_L + lq * 4, Bs, par, hid, stg);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll

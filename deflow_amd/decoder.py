@@ -69,7 +69,10 @@ def pack_infos(infos: List[Dict[str, torch.Tensor]], H: int, W: int, device, nee
 
 
 def _adjacent(a: torch.Tensor, b: torch.Tensor) -> bool:
-    return a.is_contiguous() and b.is_contiguous() and a.data_ptr() + a.numel() * 4 == b.data_ptr()
+    if not (a.is_contiguous() and b.is_contiguous() and a.data_ptr() + a.numel() * 4 == b.data_ptr()):
+        return False
+    sa, sb = a.untyped_storage(), b.untyped_storage()
+    return sa.data_ptr() == sb.data_ptr()  # same arena: a strided view over both stays inside the storage
 
 
 class ConvGRUDecoder(nn.Module):

@@ -312,7 +312,8 @@ def test_ego_transform_loss_adam(dev):
         T[b, :3, 3] = torch.tensor([0.5 * b, 0.1, 0.0])
     want = torch.stack([pc0[b] @ T[b, :3, :3].T + T[b, :3, 3] for b in range(B)])
     out, pf = torch.empty(B, N, 3, device=dev), torch.empty(B, N, 3, device=dev)
-    call("df_ego_transform", ptr(pc0.to(dev)), ptr(T.to(dev)), B, N, ptr(out), ptr(pf), stream())
+    pc0_d, T_d = pc0.to(dev), T.to(dev)
+    call("df_ego_transform", ptr(pc0_d), ptr(T_d), B, N, ptr(out), ptr(pf), stream())
     ok = ~torch.isnan(want)
     check("ego transform", out.cpu()[ok], want[ok], tol=1e-6)
     assert torch.isnan(out.cpu()[~ok]).all()
@@ -341,5 +342,6 @@ def test_ego_transform_loss_adam(dev):
         gr = torch.randn(n, generator=g)
         pr.grad = gr.clone()
         opt.step()
-        call("df_adam_step", ptr(pd), ptr(gr.to(dev)), ptr(m), ptr(v), n, 2e-4, 0.9, 0.999, 1e-8, step, 1.0, stream())
+        gr_d = gr.to(dev)
+        call("df_adam_step", ptr(pd), ptr(gr_d), ptr(m), ptr(v), n, 2e-4, 0.9, 0.999, 1e-8, step, 1.0, stream())
     check("adam 3 steps", pd, pr.detach(), tol=1e-6)
