@@ -71,8 +71,9 @@ class DeFlow(nn.Module):
         self.timer[3].stop()
         return flow, {"bstar": bstar, "v": v, "p0": p0, "p1": p1, "ps": ps, "tape": tape, "sv": sv}
 
-    def forward(self, batch: Dict[str, torch.Tensor]):
-        """input: batch dict [pc0, pc1, pose0, pose1(, ego_motion)]; output: flow, pose_flow and valid indices."""
+    def forward_padded(self, batch: Dict[str, torch.Tensor]) -> dict:
+        """Sync-free forward: returns (and stores in ``last_state``) padded device tensors -- flow [B,N,3],
+        pose_flow [B,N,3], counts0/counts1 [B] i32, idx_c0 [B,N] i64 ... -- without reading anything back to the host."""
         self.timer[0].start("Data Preprocess")
         pc0 = batch["pc0"].contiguous().float()
         pc1s = batch["pc1"].contiguous().float()
@@ -103,7 +104,14 @@ class DeFlow(nn.Module):
                 flow, state = self._run(pc0s, pc1s, train=train, save=False)
         p0, p1 = state["p0"], state["p1"]
         self.last_state = {"flow": flow, "pose_flow": pose_flow, "counts0": p0.counts, "counts1": p1.counts,
-                           "idx_c0": p0.idx_c, "pc0s": pc0s}
+                           "idx_c0": p0.idx_c, "pc0s": pc0s, "p0": p0, "p1": p1}
+        return self.last_state
+
+    def forward(self, batch: Dict[str, torch.Tensor]):
+        """input: batch dict [pc0, pc1, pose0, pose1(, ego_motion)]; output: flow, pose_flow and valid indices."""
+        st = self.forward_padded(batch)
+        flow, pose_flow, p0, p1 = st["flow"], st["pose_flow"], st["p0"], st["p1"]
+        B = flow.shape[0]
         # the single host sync of the forward: per-sample valid-point counts
         m = torch.stack([p0.counts, p1.counts]).tolist()
         m0, m1 = m[0], m[1]

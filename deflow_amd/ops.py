@@ -23,10 +23,54 @@ def ohwi(w: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
+class KernelProfiler:
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline figure).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (kernel name, algorithmic flops, start event, end event)
+
+    def summary(self):
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER: Optional[KernelProfiler] = None
+
+
+def _conv_variant(y: DfImg, epi: int) -> str:
+    """mirror of df_conv2d's tile dispatch (csrc/conv.hip) -> kernel template instance name"""
+    M = y.n * y.h * y.w
+    if y.c % 64:
+        return "conv_kernel<128,32,4,1>"
+    bm = 128
+    if epi == EPI_STATS:
+        bm = 128 if (y.grp_size * y.h * y.w) % 128 == 0 else 64
+    elif M <= 128 * 256:
+        bm = 64
+    if bm == 128 and y.c % 128 == 0:
+        return "conv_kernel<128,128,2,2>"
+    return "conv_kernel<128,64,2,2>" if bm == 128 else "conv_kernel<64,64,2,2>"
+
+
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
            mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False):
+    prof = PROFILER
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("df_conv2d", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
          int(accumulate), stream())
+    if prof is not None:
+        e1.record()
+        small = y if mode == CONV_FWD else x  # the conv-output-sized grid
+        flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
+        prof.records.append((_conv_variant(y, epi), flops, e0, e1))
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:
@@ -96,7 +140,14 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     splits = call("df_conv2d_wgrad_splits", x, dy, ks, stride)
     taps = ks * ks
     ws = _f32(splits * dy.c * taps * x.c, device=dev)
+    prof = PROFILER
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, stream())
+    if prof is not None:
+        e1.record()
+        prof.records.append((f"wgrad_kernel<{ks},{stride}>", 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
 
