@@ -96,7 +96,7 @@ class DeflowLossFn(torch.autograd.Function):
     def forward(ctx, est, gt, counts):
         B, N, _ = est.shape
         dev = est.device
-        nblk = max(1, min(256, (N + 255) // 256))
+        nblk = max(1, min(32, (N + 255) // 256))
         partial = torch.empty(B, nblk, 6, dtype=torch.float32, device=dev)
         est_c, gt_c = est.contiguous(), gt.contiguous()
         call("df_deflow_loss_fwd", ptr(est_c), ptr(gt_c), ptr(counts), B, N, ptr(partial), nblk, stream())

@@ -248,7 +248,7 @@ struct WgradParams {
 };
 
 template <int KS, int STRIDE>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   constexpr int P = 32;                         // output pixels per chunk (one row segment)
   constexpr int XW = (P - 1) * STRIDE + KS;     // input pixels needed per row
   constexpr int TAPS = KS * KS;
@@ -343,8 +343,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, in
                                     float* __restrict__ dw, int64_t ld_co, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per_split) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * per_split + i];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= splits; k += 4) {
+    s0 += ws[(int64_t)k * per_split + i];
+    s1 += ws[(int64_t)(k + 1) * per_split + i];
+    s2 += ws[(int64_t)(k + 2) * per_split + i];
+    s3 += ws[(int64_t)(k + 3) * per_split + i];
+  }
+  for (; k < splits; ++k) s0 += ws[(int64_t)k * per_split + i];
+  const float s = (s0 + s1) + (s2 + s3);
   const int64_t co = i / row_len, r = i - co * row_len;
   float* o = dw + co * ld_co + r;
   *o = accumulate ? (*o + s) : s;

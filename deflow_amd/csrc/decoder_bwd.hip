@@ -34,6 +34,7 @@ struct GruBwdParams {
   float* dpre1;
   float* hid;
   float* xout;
+  float* bias_partial;  // [blocks][416]: column sums of dz_pre, dr_pre, dq_pre (3 x 128) and dpre1 (32)
 };
 
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
   stage_store<32>(stg, Bs);
   __syncthreads();
 
+  float sb[3][8], sb1[2] = {0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sb[g][t] = 0.f;
   // ---- MLP head backward -----------------------------------------------------------------------
   f32x4 pre1[2];
 #pragma unroll
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
           p.dpre1[(grow0 + 4 * lq + r) * 32 + col] = dp;
         }
         Aw[(4 * lq + r) * LDA_B + col] = dp;  // A operand of the next GEMM (cols 0..31)
+        if (r == 0) sb1[t] = dp; else sb1[t] += dp;
       }
     }
   }
@@ -178,6 +185,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
         dzp[t][k] = d * (q[t][k] - h[t][k]) * z[t][k] * (1.f - z[t][k]);  // dz_pre
         dhc[t][k] = d * (1.f - z[t][k]);
         q[t][k] = d * z[t][k] * (1.f - q[t][k] * q[t][k]);                 // dq_pre (q no longer needed)
+        sb[0][t] += dzp[t][k];
+        sb[2][t] += q[t][k];
       }
     c_to_lds(q, 0);
     __syncthreads();
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
         const float drh = acc[t][k];
         dhc[t][k] += drh * r[t][k];
         r[t][k] = drh * h[t][k] * r[t][k] * (1.f - r[t][k]);  // dr_pre
+        sb[1][t] += r[t][k];
       }
     c_to_lds(dzp, 0);
     c_to_lds(r, 128);
@@ -224,6 +234,28 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     const int pt = f >> 4, c4 = f & 15;
     if (wp0 + pt < cnt) st4(p.dx + (grow0 + pt) * 64 + c4 * 4, ld4(Aw + pt * LDA_B + 128 + c4 * 4));
   }
+  // ---- bias-gradient partials (rows beyond cnt contributed exact zeros) --------------------------------
+  float* red = Bs;  // the weight buffers are idle now: [4 waves][416]
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v = sb[g][t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lq == 0) red[wave * 416 + g * 128 + 16 * t + li] = v;
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float v = sb1[t];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lq == 0) red[wave * 416 + 384 + 16 * t + li] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < 416; o += 256)
+    p.bias_partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 416 + o] =
+        red[o] + red[416 + o] + red[832 + o] + red[1248 + o];
 }
 
 // ------------------------------------------------------------------------------ gather bwd ---
@@ -292,8 +324,10 @@ __global__ __launch_bounds__(256) void small_outer_kernel(const float* __restric
 
 extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N,
                                   int num_iters, df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0,
-                                  float* dx, float* dpre1, float* hid, float* xout, void* stream) {
-  DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && hid && xout && B > 0 && N > 0 && num_iters >= 1,
+                                  float* dx, float* dpre1, float* hid, float* xout, float* bias_partial,
+                                  void* stream) {
+  DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && hid && xout && bias_partial && B > 0 && N > 0 &&
+                 num_iters >= 1,
              DF_E_ARG);
   DF_REQUIRE(wts.w_off && wts.b_off && wts.w_1 && wts.b_1 && wts.w_2 && wtt.wt_zr && wtt.wt_q && wtt.wt_1, DF_E_ARG);
   DF_REQUIRE(df_aligned16(wts.w_1) && df_aligned16(wtt.wt_zr) && df_aligned16(wtt.wt_q) && df_aligned16(wtt.wt_1) &&
@@ -303,7 +337,7 @@ extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const i
   p.dflow = dflow; p.offs = offs; p.counts = counts; p.N = N; p.T = num_iters; p.w = wts; p.wt = wtt; p.save = save;
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
-  p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.hid = hid; p.xout = xout;
+  p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.hid = hid; p.xout = xout; p.bias_partial = bias_partial;
   const size_t lds_bytes = (size_t)(2 * BS_B + 4 * 16 * LDA_B) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -8,18 +8,18 @@
 namespace {
 
 // ------------------------------------------------------------------ BN finalize ---------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_per_group,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_per_group,
                                                           int groups, int C, double count, const float* gamma,
                                                           const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           float* __restrict__ bn_ss) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[2][32][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   for (int g = 0; g < groups; ++g) {
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-      for (int t = tl; t < tiles_per_group; t += 8) {
+      for (int t = tl; t < tiles_per_group; t += 32) {
         const float* q = partial + (((int64_t)g * tiles_per_group + t) * C + c) * 2;
         s1 += (double)q[0];
         s2 += (double)q[1];
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     red[1][tl][cl] = s2;
     __syncthreads();
     if (tl == 0 && c < C) {
-      for (int k = 1; k < 8; ++k) {
+      for (int k = 1; k < 32; ++k) {
         s1 += red[0][k][cl];
         s2 += red[1][k][cl];
       }
@@ -142,25 +142,40 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk_per_group, int groups, int C,
-                                       double count, float* dgamma, float* dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk_per_group,
+                                                               int groups, int C, double count, float* dgamma,
+                                                               float* dbeta, float* __restrict__ coef) {
+  __shared__ double red[2][32][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < groups; ++g) {
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk_per_group; ++b) {
-      const float* q = partial + (((int64_t)g * nblk_per_group + b) * C + c) * 2;
-      s1 += (double)q[0];
-      s2 += (double)q[1];
+    if (c < C)
+      for (int b = tl; b < nblk_per_group; b += 32) {
+        const float* q = partial + (((int64_t)g * nblk_per_group + b) * C + c) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
+      }
+    red[0][tl][cl] = s1;
+    red[1][tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+      for (int k = 1; k < 32; ++k) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+      }
+      coef[((int64_t)g * 2 + 0) * C + c] = (float)(s1 / count);
+      coef[((int64_t)g * 2 + 1) * C + c] = (float)(s2 / count);
+      tb += s1;
+      tg += s2;
     }
-    coef[((int64_t)g * 2 + 0) * C + c] = (float)(s1 / count);
-    coef[((int64_t)g * 2 + 1) * C + c] = (float)(s2 / count);
-    tb += s1;
-    tg += s2;
+    __syncthreads();
   }
-  if (dgamma) dgamma[c] = (float)tg;
-  if (dbeta) dbeta[c] = (float)tb;
+  if (tl == 0 && c < C) {
+    if (dgamma) dgamma[c] = (float)tg;
+    if (dbeta) dbeta[c] = (float)tb;
+  }
 }
 
 // pass 2: dy = scale * (dyh - c1 - xhat * c2); dbias partial = column sums of dy
@@ -221,13 +236,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(df_img x, float* __
   if (rp.row_lane == 0) st4(partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int total, float* out,
-                                       int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int total,
+                                                               float* out, int accumulate) {
+  __shared__ double red[32][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * total + i];
-  out[i] = accumulate ? (float)((double)out[i] + s) : (float)s;
+  if (i < total)
+    for (int b = tl; b < nblk; b += 32) s += (double)partial[(int64_t)b * total + i];
+  red[tl][cl] = s;
+  __syncthreads();
+  if (tl == 0 && i < total) {
+    for (int k = 1; k < 32; ++k) s += red[k][cl];
+    out[i] = accumulate ? (float)((double)out[i] + s) : (float)s;
+  }
 }
 
 // ------------------------------------------------------------------ bilinear x2 ---------
@@ -334,7 +356,7 @@ extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int gro
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* bn_ss, void* stream) {
   DF_REQUIRE(partial && bn_ss && tiles_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, DF_E_ARG);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                      partial, tiles_per_group, groups, C, (double)count_per_group, gamma, beta, eps, momentum,
                      running_mean, running_var, bn_ss);
   DF_CHECK_LAUNCH();
@@ -367,7 +389,7 @@ extern "C" int df_bn_gelu_bwd_reduce(df_img dz, const float* y, const float* bn_
 extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
                                   float* dgamma, float* dbeta, float* coef, void* stream) {
   DF_REQUIRE(partial && coef && nblk_per_group > 0 && groups > 0, DF_E_ARG);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                      partial, nblk_per_group, groups, C, (double)count_per_group, dgamma, dbeta, coef);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -401,7 +423,7 @@ extern "C" int df_colsum_finalize(const float* partial, int nblk, int C, int nva
                                   void* stream) {
   DF_REQUIRE(partial && out && nblk > 0 && C > 0 && nvals > 0, DF_E_ARG);
   const int total = C * nvals;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 31) / 32), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), partial, nblk, total, out, accumulate);
   DF_CHECK_LAUNCH();
   return DF_OK;

@@ -72,17 +72,23 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
 
 __global__ void loss_finalize_kernel(const float* __restrict__ partial, int B, int nblk, float* __restrict__ bins,
                                      float* __restrict__ loss) {
-  // single thread: B * nblk * 6 values, deterministic order
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double total = 0.0;
-  for (int b = 0; b < B; ++b) {
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < nblk; ++k)
-      for (int j = 0; j < 6; ++j) s[j] += (double)partial[((int64_t)b * nblk + k) * 6 + j];
-    for (int j = 0; j < 6; ++j) bins[b * 6 + j] = (float)s[j];
-    for (int k = 0; k < 3; ++k)
-      if (s[2 * k + 1] > 0.0) total += s[2 * k] / s[2 * k + 1];
+  // one thread per (sample, bin value); deterministic order; thread 0 combines
+  __shared__ double sums[1024];
+  for (int o = threadIdx.x; o < B * 6; o += blockDim.x) {
+    const int b = o / 6, j = o - b * 6;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)partial[((int64_t)b * nblk + k) * 6 + j];
+    bins[o] = (float)s;
+    if (o < 1024) sums[o] = s;
   }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double total = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < 3; ++k) {
+      const double sm = sums[b * 6 + 2 * k], cn = sums[b * 6 + 2 * k + 1];
+      if (cn > 0.0) total += sm / cn;
+    }
   loss[0] = (float)total;
 }
 
@@ -169,8 +175,8 @@ extern "C" int df_deflow_loss_fwd(const float* est, const float* gt, const int32
 
 extern "C" int df_deflow_loss_finalize(const float* bins_partial, int B, int nblk, float* bins, float* loss,
                                        void* stream) {
-  DF_REQUIRE(bins_partial && bins && loss && B > 0 && nblk > 0, DF_E_ARG);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), bins_partial, B,
+  DF_REQUIRE(bins_partial && bins && loss && B > 0 && nblk > 0 && B * 6 <= 1024, DF_E_ARG);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bins_partial, B,
                      nblk, bins, loss);
   DF_CHECK_LAUNCH();
   return DF_OK;

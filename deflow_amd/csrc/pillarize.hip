@@ -253,19 +253,30 @@ __global__ void pfn_bn_finalize_kernel(const float* __restrict__ partial, int B,
                                        const int32_t* __restrict__ counts, const float* gamma, const float* beta,
                                        float eps, float momentum, float* running_mean, float* running_var,
                                        float* __restrict__ bn_ss) {
-  const int c = threadIdx.x;  // 32 threads
+  __shared__ double red[2][32][32];
+  const int c = threadIdx.x & 31, tl = threadIdx.x >> 5;  // 32 channels x 32 partial lanes
   for (int b = 0; b < B; ++b) {
     float* o = bn_ss + (int64_t)b * 128;
     const int cnt = counts[b];
-    if (cnt <= 0) {
-      o[c] = 0.f; o[32 + c] = 0.f; o[64 + c] = 0.f; o[96 + c] = 0.f;
-      continue;
-    }
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = tl; k < nblk; k += 32) {
       const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
       s1 += (double)q[0];
       s2 += (double)q[1];
+    }
+    red[0][tl][c] = s1;
+    red[1][tl][c] = s2;
+    __syncthreads();
+    if (tl == 0)
+      for (int k = 1; k < 32; ++k) {
+        s1 += red[0][k][c];
+        s2 += red[1][k][c];
+      }
+    __syncthreads();
+    if (tl != 0) continue;
+    if (cnt <= 0) {
+      o[c] = 0.f; o[32 + c] = 0.f; o[64 + c] = 0.f; o[96 + c] = 0.f;
+      continue;
     }
     const double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
@@ -374,21 +385,33 @@ __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restr
 __global__ void pfn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
                                         const int32_t* __restrict__ counts, float* dgamma, float* dbeta,
                                         int accumulate, float* __restrict__ coef) {
-  const int c = threadIdx.x;  // 32 threads
+  __shared__ double red[2][32][32];
+  const int c = threadIdx.x & 31, tl = threadIdx.x >> 5;
   double tg = 0.0, tb = 0.0;
   for (int b = 0; b < B; ++b) {
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = tl; k < nblk; k += 32) {
       const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
       s1 += (double)q[0];
       s2 += (double)q[1];
     }
+    red[0][tl][c] = s1;
+    red[1][tl][c] = s2;
+    __syncthreads();
+    if (tl == 0)
+      for (int k = 1; k < 32; ++k) {
+        s1 += red[0][k][c];
+        s2 += red[1][k][c];
+      }
+    __syncthreads();
+    if (tl != 0) continue;
     const int cnt = counts[b];
     coef[((int64_t)b * 2 + 0) * 32 + c] = cnt > 0 ? (float)(s1 / cnt) : 0.f;
     coef[((int64_t)b * 2 + 1) * 32 + c] = cnt > 0 ? (float)(s2 / cnt) : 0.f;
     tb += s1;
     tg += s2;
   }
+  if (tl != 0) return;
   dgamma[c] = accumulate ? (float)((double)dgamma[c] + tg) : (float)tg;
   dbeta[c] = accumulate ? (float)((double)dbeta[c] + tb) : (float)tb;
 }
@@ -535,7 +558,7 @@ extern "C" int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, co
                                   const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var, float* bn_ss, void* stream) {
   DF_REQUIRE(partial && counts && bn_ss && B > 0 && nblk_stat > 0, DF_E_ARG);
-  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
+  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
                      nblk_stat, counts, gamma, beta, eps, momentum, running_mean, running_var, bn_ss);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -569,7 +592,7 @@ extern "C" int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, co
 extern "C" int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, float* dgamma,
                                    float* dbeta, int accumulate, float* coef, void* stream) {
   DF_REQUIRE(partial && counts && dgamma && dbeta && coef && B > 0 && nblk_stat > 0, DF_E_ARG);
-  hipLaunchKernelGGL(pfn_bwd_finalize_kernel, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
+  hipLaunchKernelGGL(pfn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
                      nblk_stat, counts, dgamma, dbeta, accumulate, coef);
   DF_CHECK_LAUNCH();
   return DF_OK;

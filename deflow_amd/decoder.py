@@ -130,8 +130,12 @@ class ConvGRUDecoder(nn.Module):
         dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
         dpre1, hid, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
         dflow = dflow.contiguous()
+        nblocks = B * ((N + 63) // 64)
+        bias_partial = torch.zeros(nblocks, 416, **f32)
         call("df_gru_decoder_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-             ptr(dpre1), ptr(hid), ptr(xbuf), s)
+             ptr(dpre1), ptr(hid), ptr(xbuf), ptr(bias_partial), s)
+        bias_g = torch.empty(416, **f32)
+        call("df_colsum_finalize", ptr(bias_partial), nblocks, 416, 1, ptr(bias_g), 0, s)
         # image gradients: per-cell segmented sum (no atomics)
         ncell = dbefore.h * dbefore.w
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
@@ -171,11 +175,10 @@ class ConvGRUDecoder(nn.Module):
         grads[g.convq.weight] = dW_q.unsqueeze(2)
         grads[self.decoder[0].weight] = dW1
         so = lambda a, lda, na, b, ldb, nb, rows: ops.small_outer(a, lda, na, b, ldb, nb, ps.counts, N, B, rows)
-        pl = sv.view(-1)
-        grads[g.convz.bias] = so(pl[1 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
-        grads[g.convr.bias] = so(pl[2 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
-        grads[g.convq.bias] = so(pl[3 * plane:], 128, 128, None, 0, 1, T * BN).view(128)
-        grads[self.decoder[0].bias] = so(dpre1, 32, 32, None, 0, 1, BN).view(32)
+        grads[g.convz.bias] = bias_g[0:128]
+        grads[g.convr.bias] = bias_g[128:256]
+        grads[g.convq.bias] = bias_g[256:384]
+        grads[self.decoder[0].bias] = bias_g[384:416]
         dfl = dflow.view(BN, 3)
         grads[self.decoder[2].weight] = so(dfl, 3, 3, hid, 32, 32, BN)
         grads[self.decoder[2].bias] = so(dfl, 3, 3, None, 0, 1, BN).view(3)
