@@ -27,6 +27,29 @@ struct ConvParams {
   float* stats;
   int ks, stride, pad, mode, epi, accumulate;
   int M, K, N, tiles_m, tiles_n, hw_y;
+  // stride-2 dgrad: output pixels are tiled per parity class (y&1, x&1) so that a tile only visits the taps that
+  // can reach it (1, 2, 2 or 4 of 9) instead of multiplying zeros.  cls_tiles = row tiles per class (0 = off).
+  int cls_tiles;
+};
+
+// row m of the (possibly class-ordered) GEMM -> image, output y, output x
+struct RowDecode {
+  int hw, w, cls_mode, py, px, hh, wh;
+  __device__ __forceinline__ void operator()(int m, int& n, int& oy, int& ox) const {
+    if (!cls_mode) {
+      n = m / hw;
+      const int rem = m - n * hw;
+      oy = rem / w;
+      ox = rem - oy * w;
+    } else {
+      const int hwh = hh * wh;
+      n = m / hwh;
+      const int rem = m - n * hwh;
+      const int yy = rem / wh;
+      oy = 2 * yy + py;
+      ox = 2 * (rem - yy * wh) + px;
+    }
+  }
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -47,13 +70,28 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 
   const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
   const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int n0 = tile_n * BN;
 
   const float* __restrict__ xp = reinterpret_cast<const float*>(p.x.ptr);
   const int c4 = tid & 7, r0 = tid >> 3;
   const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
-  const int taps = p.ks * p.ks;
   const int KC = p.K / BK;
+
+  // tile geometry: plain row-major tiles, or one parity class of a stride-2 transposed conv
+  RowDecode dec;
+  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = p.cls_tiles > 0; dec.py = dec.px = 0;
+  dec.hh = p.y.h >> 1; dec.wh = p.y.w >> 1;
+  int m0 = tile_m * BM, m_end = p.M;
+  int ky0 = 0, kx0 = 0, kstep = 1, nky = p.ks, nkx = p.ks;
+  if (dec.cls_mode) {
+    const int cls = tile_m / p.cls_tiles;
+    dec.py = cls >> 1; dec.px = cls & 1;
+    m0 = (tile_m - cls * p.cls_tiles) * BM;
+    m_end = p.y.n * dec.hh * dec.wh;
+    kstep = 2;
+    ky0 = (dec.py + p.pad) & 1; kx0 = (dec.px + p.pad) & 1;
+    nky = (p.ks - ky0 + 1) >> 1; nkx = (p.ks - kx0 + 1) >> 1;
+  }
 
   // per-thread description of the A rows it stages
   int64_t abase[RA];
@@ -61,9 +99,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
-    if (m < p.M) {
-      const int n = m / p.hw_y, rem = m - n * p.hw_y;
-      const int oy = rem / p.y.w, ox = rem - oy * p.y.w;
+    if (m < m_end) {
+      int n, oy, ox;
+      dec(m, n, oy, ox);
       abase[i] = df_img_base(p.x, n);
       if (p.mode == DF_CONV_FWD) {
         ay[i] = oy * p.stride - p.pad;
@@ -80,8 +118,10 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 
   f32x4 areg[RA], breg[RB];
   auto load_stage = [&](int st) {
-    const int tap = st / KC, kc = st - tap * KC;
-    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int t = st / KC, kc = st - t * KC;
+    const int iky = t / nkx;
+    const int ky = ky0 + kstep * iky, kx = kx0 + kstep * (t - iky * nkx);
+    const int tap = ky * p.ks + kx;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int iy, ix;
@@ -108,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int co = n0 + r0 + 32 * i;
-      breg[i] = ld4(p.w + ((int64_t)co * taps + tap) * p.K + kc * BK + c4 * 4);
+      breg[i] = ld4(p.w + ((int64_t)co * p.ks * p.ks + tap) * p.K + kc * BK + c4 * 4);
     }
   };
   auto store_stage = [&](int buf) {
@@ -128,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nst = taps * KC;
+  const int nst = nky * nkx * KC;
   load_stage(0);
   store_stage(0);
   __syncthreads();
@@ -163,9 +203,10 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   if (tid < BM) {
     const int m = m0 + tid;
     int64_t off = -1;
-    if (m < p.M) {
-      const int n = m / p.hw_y, rem = m - n * p.hw_y;
-      off = df_img_base(p.y, n) + (int64_t)rem * p.y.ld;
+    if (m < m_end) {
+      int n, oy, ox;
+      dec(m, n, oy, ox);
+      off = df_img_base(p.y, n) + ((int64_t)oy * p.y.w + ox) * p.y.ld;
     }
     rowoff[tid] = off;
   }
@@ -247,9 +288,8 @@ struct WgradParams {
   int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
 };
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int P /* output pixels per chunk (one row segment) */>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
-  constexpr int P = 32;                         // output pixels per chunk (one row segment)
   constexpr int XW = (P - 1) * STRIDE + KS;     // input pixels needed per row
   constexpr int TAPS = KS * KS;
   constexpr int LC = 64;                        // channels per tile
@@ -377,9 +417,24 @@ bool img_ok(const df_img& d) {
 
 }  // namespace
 
+// tile variant as BM * 1000 + BN.  rows = GEMM rows one tile range covers (per parity class in class mode).
+static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi) {
+  if (cout % 64) return 128032;
+  int bm;
+  if (epi == DF_EPI_STATS) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
+  else bm = (rows <= 128 * 256) ? 64 : 128;  // small problems: more tiles to fill 256 CUs
+  if (bm == 64) return 64064;
+  if (cout % 128 == 0) return 128128;
+  // (a 256x64 tile runs 1 workgroup/CU and measured slower: 60 vs 78 TFLOP/s)
+  return 128064;
+}
+
+extern "C" int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi) {
+  return pick_variant(rows, rows_per_stat_group, cout, epi);
+}
+
 extern "C" int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout) {
-  (void)cout;
-  return (rows_per_stat_group % 128 == 0) ? 128 : 64;
+  return pick_variant(rows_per_stat_group, rows_per_stat_group, cout, DF_EPI_STATS) / 1000;
 }
 
 extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
@@ -397,6 +452,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
     DF_REQUIRE(x.h == (y.h + 2 * pad - ksize) / stride + 1 && x.w == (y.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
   }
   if (epi == DF_EPI_BN_GELU) DF_REQUIRE(scale && shift, DF_E_ARG);
+  if (epi == DF_EPI_STATS) DF_REQUIRE(stats_partial, DF_E_ARG);
   ConvParams p;
   p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
@@ -404,37 +460,38 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
   p.M = (int)M; p.K = x.c; p.N = y.c;
+  p.cls_tiles = 0;
   const int64_t rows_per_group = (int64_t)y.grp_size * p.hw_y;
-  int bm = 128;
-  if (epi == DF_EPI_STATS) {
-    DF_REQUIRE(stats_partial, DF_E_ARG);
-    bm = df_conv2d_tile_m(rows_per_group, y.c);
-    DF_REQUIRE(rows_per_group % bm == 0, DF_E_SHAPE);
-  } else if (M <= 128 * 256) {
-    bm = 64;  // small problems: more tiles to fill 256 CUs
-  }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if ((p.N % 64) != 0) {  // 32 output channels (input-gradient of the first encoder conv)
-    DF_REQUIRE(epi != DF_EPI_STATS || rows_per_group % 128 == 0, DF_E_SHAPE);
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 32;
-    return launch_conv<128, 32, 4, 1>(p, s);
-  }
-  if (bm == 128 && (p.N % 128) == 0) {
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 128;
-    return launch_conv<128, 128, 2, 2>(p, s);
-  } else if (bm == 128) {
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = p.N / 64;
-    return launch_conv<128, 64, 2, 2>(p, s);
+  int64_t rows = M;
+  const bool cls = mode == DF_CONV_DGRAD && stride == 2 && ksize == 3 && epi == DF_EPI_BIAS && (y.h % 2) == 0 && (y.w % 2) == 0;
+  if (cls) rows = M / 4;
+  int var = pick_variant(rows, rows_per_group, p.N, epi);
+  int bm = var / 1000;
+  if (epi == DF_EPI_STATS) DF_REQUIRE(rows_per_group % bm == 0, DF_E_SHAPE);
+  if (cls && rows % bm == 0) {
+    p.cls_tiles = (int)(rows / bm);
+    p.tiles_m = 4 * p.cls_tiles;
   } else {
-    p.tiles_m = (p.M + 63) / 64; p.tiles_n = p.N / 64;
-    return launch_conv<64, 64, 2, 2>(p, s);
+    if (cls) { var = pick_variant(M, rows_per_group, p.N, epi); bm = var / 1000; }
+    p.tiles_m = (int)((M + bm - 1) / bm);
+  }
+  p.tiles_n = p.N / (var % 1000);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (var) {
+    case 128032: return launch_conv<128, 32, 4, 1>(p, s);
+    case 64064: return launch_conv<64, 64, 2, 2>(p, s);
+    case 128128: return launch_conv<128, 128, 2, 2>(p, s);
+    default: return launch_conv<128, 64, 2, 2>(p, s);
   }
 }
 
+static inline int wgrad_chunk(int ksize) { (void)ksize; return 32; }  // 128-pixel chunks for 1x1 measured slower
+
 extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
-  (void)ksize; (void)stride;
+  (void)stride;
+  const int P = wgrad_chunk(ksize);
   const int tiles = ((x.c + 63) / 64) * (dy.c / 64);
-  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + 31) / 32);
+  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
   int64_t splits = (1024 + tiles - 1) / tiles;
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;
@@ -452,8 +509,10 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE((ksize == 1 && stride == 1 && pad == 0) || (ksize == 3 && pad == 1 && (stride == 1 || stride == 2)), DF_E_SHAPE);
   DF_REQUIRE(dy.h == (x.h + 2 * pad - ksize) / stride + 1 && dy.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
   WgradParams p;
-  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1; p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
-  p.chunks_per_row = (dy.w + 31) / 32;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1;
+  p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
+  const int P = wgrad_chunk(ksize);
+  p.chunks_per_row = (dy.w + P - 1) / P;
   const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
   DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
   p.total_chunks = (int)chunks;
@@ -461,9 +520,9 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
-  else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, s, p);
+  if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1, 32>), grid, dim3(256), 0, s, p);
+  else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1, 32>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_kernel<3, 2, 32>), grid, dim3(256), 0, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -43,19 +43,16 @@ class KernelProfiler:
 PROFILER: Optional[KernelProfiler] = None
 
 
-def _conv_variant(y: DfImg, epi: int) -> str:
-    """mirror of df_conv2d's tile dispatch (csrc/conv.hip) -> kernel template instance name"""
-    M = y.n * y.h * y.w
-    if y.c % 64:
-        return "conv_kernel<128,32,4,1>"
-    bm = 128
-    if epi == EPI_STATS:
-        bm = 128 if (y.grp_size * y.h * y.w) % 128 == 0 else 64
-    elif M <= 128 * 256:
-        bm = 64
-    if bm == 128 and y.c % 128 == 0:
-        return "conv_kernel<128,128,2,2>"
-    return "conv_kernel<128,64,2,2>" if bm == 128 else "conv_kernel<64,64,2,2>"
+def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int) -> str:
+    """kernel template instance df_conv2d will launch (asks the library, so it cannot drift from the C dispatch)"""
+    rows = y.n * y.h * y.w
+    cls = mode == CONV_DGRAD and stride == 2 and ks == 3 and epi == EPI_BIAS and y.h % 2 == 0 and y.w % 2 == 0
+    v = call("df_conv2d_variant", rows // 4 if cls else rows, y.grp_size * y.h * y.w, y.c, epi)
+    if cls and (rows // 4) % (v // 1000):
+        v = call("df_conv2d_variant", rows, y.grp_size * y.h * y.w, y.c, epi)
+    bm, bn = v // 1000, v % 1000
+    wm, wn = {(128, 32): (4, 1), (256, 64): (4, 1)}.get((bm, bn), (2, 2))
+    return f"conv_kernel<{bm},{bn},{wm},{wn}>"
 
 
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
@@ -70,7 +67,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
-        prof.records.append((_conv_variant(y, epi), flops, e0, e1))
+        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi), flops, e0, e1))
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:

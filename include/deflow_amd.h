@@ -107,7 +107,9 @@ int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32
 int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
               int mode, int epi, const float* scale, const float* shift, float* stats_partial,
               int accumulate, void* stream);
-int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick */
+int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick for DF_EPI_STATS */
+/* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
+int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);
 /* BatchNorm2d training statistics from the partials. groups = stat groups (the shared encoder is
  * applied to pc0 then pc1: two calls => two groups, running stats updated in call order).
  * bn_ss [groups,4,C] = scale, shift, mean, invstd. */
