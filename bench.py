@@ -76,7 +76,7 @@ def main():
     model = deflow_amd.DeFlow(grid_feature_size=[GRID, GRID], num_iters=NUM_ITERS).to(dev).train()
     trainer = Trainer(model, lr=2e-4)
     # weak scaling: every rank owns its own shard of frame pairs (seeded by global sample index), resident in HBM
-    batch = synth_batch(args.batch, N_POINTS, seed=20240116 + rank * args.batch, device=dev)
+    batch = synth_batch(args.batch, N_POINTS, seed=Trainer.shard_seed(20240116, rank, args.batch), device=dev)
 
     def barrier():
         if world > 1:

@@ -118,12 +118,22 @@ class Trainer:
              stream())
         return DeflowLossFn.apply(flow, gt, st["counts0"])
 
+    def reduce_gradients(self) -> float:
+        """Sum the gradient arena over the data-parallel ranks (ONE collective over 27.6 MB); returns the scale that
+        turns the sum into DDP's mean (folded into the Adam kernel instead of a separate divide pass)."""
+        if self.world > 1:
+            self.dist.all_reduce(self.flat.grad, group=self.pg)
+        return 1.0 / self.world
+
+    @staticmethod
+    def shard_seed(base_seed: int, rank: int, per_rank_batch: int) -> int:
+        """frame pairs are sharded by global sample index: rank r owns samples [r*b, (r+1)*b)"""
+        return base_seed + rank * per_rank_batch
+
     def step(self, batch) -> torch.Tensor:
         self.flat.zero_grad()
         self.model.forward_padded(batch)
         loss = self.loss_on_last_forward(batch)
         loss.backward()
-        if self.world > 1:
-            self.dist.all_reduce(self.flat.grad, group=self.pg)  # sum; the mean is folded into Adam's grad_scale
-        self.opt.step(grad_scale=1.0 / self.world)
+        self.opt.step(grad_scale=self.reduce_gradients())
         return loss.detach()
