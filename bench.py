@@ -126,8 +126,14 @@ def main():
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"] if args.batch == PER_GPU_BATCH else None
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom,
+                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": dom,
                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": d["ms"] / d["launches"],
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
