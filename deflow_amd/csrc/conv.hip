@@ -7,16 +7,18 @@
 //   conv_kernel   y[m, co] = sum_{tap, ci} x[pix(m, tap), ci] * w[co, tap, ci]      (fwd and dgrad)
 //   wgrad_kernel  dw[co, tap, ci] = sum_m dy[m, co] * x[pix(m, tap), ci]            (split over m)
 //
-// LDS tiles are [row][32 + 4 pad] floats; fragments are fetched with ds_read_b128 (conflict-free
-// with the 144-byte row pitch) by permuting k inside each group of 8: MFMA step s of group g uses
-// k = 8g + s on lanes 0-31 and k = 8g + 4 + s on lanes 32-63 for BOTH operands, so one b128 read
-// feeds four MFMA steps.  Global->LDS goes through registers, issued one stage ahead (T14).
+// LDS tiles are [row][32] floats, unpadded, with the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7:
+// ds_read_b128 fragments are conflict-free (each 16-lane service group hits 16 distinct (row parity, slot)
+// pairs = all 64 banks) and a 256x64 tile double-buffers in 80 KB, i.e. two workgroups per CU.  k is
+// permuted inside each group of 8: MFMA step s of group g uses k = 8g + s on lanes 0-31 and k = 8g + 4 + s
+// on lanes 32-63 for BOTH operands, so one b128 read feeds four MFMA steps.  Global->LDS goes through
+// registers, issued one stage ahead (T14).
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDT = BK + 4;  // LDS row pitch (floats)
+constexpr int LDT = BK;  // LDS row pitch (floats); slots swizzled instead of padded
 
 struct ConvParams {
   df_img x, y;
@@ -151,13 +153,17 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
       breg[i] = ld4(p.w + ((int64_t)co * p.ks * p.ks + tap) * p.K + kc * BK + c4 * 4);
     }
   };
+  const int wslot = (c4 ^ ((r0 >> 1) & 7)) * 4;   // swizzled slot of this thread's float4 (rows r0 + 32 i share it)
+  int rslot[BK / 8];                              // swizzled slots of this lane's fragments
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) rslot[g] = ((2 * g + kh) ^ ((li >> 1) & 7)) * 4;
   auto store_stage = [&](int buf) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) st4(a + (r0 + 32 * i) * LDT + c4 * 4, areg[i]);
+    for (int i = 0; i < RA; ++i) st4(a + (r0 + 32 * i) * LDT + wslot, areg[i]);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) st4(b + (r0 + 32 * i) * LDT + c4 * 4, breg[i]);
+    for (int i = 0; i < RB; ++i) st4(b + (r0 + 32 * i) * LDT + wslot, breg[i]);
   };
 
   f32x16 acc[TM][TN];
@@ -175,15 +181,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   for (int st = 0; st < nst; ++st) {
     const int buf = st & 1;
     if (st + 1 < nst) load_stage(st + 1);
-    const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT + kh * 4;
-    const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT + kh * 4;
+    const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
+    const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ld4(a + i * 32 * LDT + g * 8);
+      for (int i = 0; i < TM; ++i) af[i] = ld4(a + i * 32 * LDT + rslot[g]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = ld4(b + j * 32 * LDT + g * 8);
+      for (int j = 0; j < TN; ++j) bf[j] = ld4(b + j * 32 * LDT + rslot[g]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -425,8 +431,8 @@ static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int
   else bm = (rows <= 128 * 256) ? 64 : 128;  // small problems: more tiles to fill 256 CUs
   if (bm == 64) return 64064;
   if (cout % 128 == 0) return 128128;
-  // (a 256x64 tile runs 1 workgroup/CU and measured slower: 60 vs 78 TFLOP/s)
-  return 128064;
+  const bool ok256 = (epi == DF_EPI_STATS) ? (rows_per_stat_group % 256 == 0) : (rows >= 256 * 512 && rows % 256 == 0);
+  return ok256 ? 256064 : 128064;
 }
 
 extern "C" int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi) {
@@ -481,6 +487,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
     case 64064: return launch_conv<64, 64, 2, 2>(p, s);
     case 128128: return launch_conv<128, 128, 2, 2>(p, s);
+    case 256064: return launch_conv<256, 64, 4, 1>(p, s);
     default: return launch_conv<128, 64, 2, 2>(p, s);
   }
 }

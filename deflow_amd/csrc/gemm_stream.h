@@ -48,11 +48,17 @@ __device__ __forceinline__ void gemm_stream(const float* __restrict__ W, int ldw
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const f32x4 a = ld4(a_lane + c * 32 + g * 16);
+      // two accumulators interleaved: back-to-back MFMAs never depend on each other (16x16x4 f32: 32-cycle issue,
+      // 40-cycle dependent latency)
 #pragma unroll
-      for (int t = 0; t < ROWS / 16; ++t) {
-        const f32x4 b = ld4(bb + t * 16 * LDB + g * 16);
+      for (int t = 0; t < ROWS / 16; t += 2) {
+        const f32x4 b0 = ld4(bb + t * 16 * LDB + g * 16);
+        const f32x4 b1 = ld4(bb + (t + 1) * 16 * LDB + g * 16);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[t], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
+        }
       }
     }
     float* nb = Bs + ((par + c + 1) & 1) * BS;
