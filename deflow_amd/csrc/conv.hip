@@ -95,16 +95,21 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
     nky = (p.ks - ky0 + 1) >> 1; nkx = (p.ks - kx0 + 1) >> 1;
   }
 
-  // per-thread description of the A rows it stages
-  int64_t abase[RA];
+  // per-thread description of the A rows it stages: row pointer (image base + this thread's 16-byte column),
+  // and the top-left input coordinate.  Invalid rows point at element 0 and are masked at the LDS store.
+  const float* arow[RA];
   int ay[RA], ax[RA];
+  unsigned rowok = 0;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
+    arow[i] = xp + c4 * 4;
+    ay[i] = ax[i] = -(1 << 28);  // never in range
     if (m < m_end) {
       int n, oy, ox;
       dec(m, n, oy, ox);
-      abase[i] = df_img_base(p.x, n);
+      arow[i] += df_img_base(p.x, n);
+      rowok |= 1u << i;
       if (p.mode == DF_CONV_FWD) {
         ay[i] = oy * p.stride - p.pad;
         ax[i] = ox * p.stride - p.pad;
@@ -112,45 +117,48 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
         ay[i] = oy + p.pad;
         ax[i] = ox + p.pad;
       }
-    } else {
-      abase[i] = -1;
-      ay[i] = ax[i] = 0;
     }
   }
+  const float* brow[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) brow[i] = p.w + (int64_t)(n0 + r0 + 32 * i) * p.ks * p.ks * p.K + c4 * 4;
 
+  // Stage loads are UNCONDITIONAL (clamped address, select at the LDS store) so the 2 * (RA + RB) global loads of a
+  // stage issue back to back with no exec-mask branches or intermediate vmcnt waits.  (tap, k-chunk) advance
+  // incrementally: load_stage is called for stages 0, 1, 2, ... in order.
   f32x4 areg[RA], breg[RB];
-  auto load_stage = [&](int st) {
-    const int t = st / KC, kc = st - t * KC;
-    const int iky = t / nkx;
-    const int ky = ky0 + kstep * iky, kx = kx0 + kstep * (t - iky * nkx);
-    const int tap = ky * p.ks + kx;
+  unsigned amask = 0;
+  int l_kc = 0, l_iky = 0, l_ikx = 0;
+  const bool fwd = p.mode == DF_CONV_FWD;
+  const bool half = !fwd && p.stride == 2;
+  auto load_stage = [&]() {
+    const int ky = ky0 + kstep * l_iky, kx = kx0 + kstep * l_ikx;
+    const int koff = l_kc * BK;
+    amask = 0;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      int iy, ix;
-      bool ok = abase[i] >= 0;
-      if (p.mode == DF_CONV_FWD) {
-        iy = ay[i] + ky;
-        ix = ax[i] + kx;
-      } else {
-        const int ty = ay[i] - ky, tx = ax[i] - kx;
-        if (p.stride == 2) {
-          ok = ok && !((ty | tx) & 1);
-          iy = ty >> 1;
-          ix = tx >> 1;
-        } else {
-          iy = ty;
-          ix = tx;
-        }
+      int iy = fwd ? ay[i] + ky : ay[i] - ky;
+      int ix = fwd ? ax[i] + kx : ax[i] - kx;
+      bool ok = true;
+      if (half) {
+        ok = !((iy | ix) & 1);
+        iy >>= 1;
+        ix >>= 1;
       }
-      ok = ok && iy >= 0 && iy < hx && ix >= 0 && ix < wx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = ld4(xp + abase[i] + ((int64_t)iy * wx + ix) * ldx + kc * BK + c4 * 4);
-      areg[i] = v;
+      ok = ok && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx;
+      const int poff = ok ? (iy * wx + ix) * ldx : 0;
+      areg[i] = ld4(arow[i] + poff + koff);
+      amask |= (unsigned)ok << i;
     }
+    const int woff = (ky * p.ks + kx) * p.K + koff;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int co = n0 + r0 + 32 * i;
-      breg[i] = ld4(p.w + ((int64_t)co * p.ks * p.ks + tap) * p.K + kc * BK + c4 * 4);
+    for (int i = 0; i < RB; ++i) breg[i] = ld4(brow[i] + woff);
+    if (++l_kc == KC) {
+      l_kc = 0;
+      if (++l_ikx == nkx) {
+        l_ikx = 0;
+        ++l_iky;
+      }
     }
   };
   const int wslot = (c4 ^ ((r0 >> 1) & 7)) * 4;   // swizzled slot of this thread's float4 (rows r0 + 32 i share it)
@@ -160,8 +168,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   auto store_stage = [&](int buf) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < RA; ++i) st4(a + (r0 + 32 * i) * LDT + wslot, areg[i]);
+    for (int i = 0; i < RA; ++i) st4(a + (r0 + 32 * i) * LDT + wslot, ((amask >> i) & 1) ? areg[i] : zero);
 #pragma unroll
     for (int i = 0; i < RB; ++i) st4(b + (r0 + 32 * i) * LDT + wslot, breg[i]);
   };
@@ -175,12 +184,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nst = nky * nkx * KC;
-  load_stage(0);
+  load_stage();
   store_stage(0);
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     const int buf = st & 1;
-    if (st + 1 < nst) load_stage(st + 1);
+    if (st + 1 < nst) load_stage();
     const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
     const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
 #pragma unroll
@@ -294,11 +303,34 @@ struct WgradParams {
   int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
 };
 
+// chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
+struct WgChunk {
+  int n, oy, ox0;
+};
+__device__ __forceinline__ WgChunk wg_chunk(const WgradParams& p, int ch, int P) {
+  WgChunk c;
+  const int rowid = ch / p.chunks_per_row, seg = ch - rowid * p.chunks_per_row;
+  c.n = rowid / p.dy.h;
+  c.oy = rowid - c.n * p.dy.h;
+  c.ox0 = seg * P;
+  return c;
+}
+__device__ __forceinline__ bool wg_row_ok(const WgradParams& p, int pix) {
+  if (!p.row_counts) return true;
+  const int sg = pix / p.rows_per_seg;
+  return (pix - sg * p.rows_per_seg) < p.row_counts[sg];
+}
+
+// Generic k x k weight gradient: 64 co x 64 ci x all taps per workgroup.  Loads are unconditional (clamped address +
+// select) and the NEXT chunk is fetched into registers while the current one is multiplied (T14).
 template <int KS, int STRIDE, int P /* output pixels per chunk (one row segment) */>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   constexpr int XW = (P - 1) * STRIDE + KS;     // input pixels needed per row
   constexpr int TAPS = KS * KS;
   constexpr int LC = 64;                        // channels per tile
+  constexpr int NLY = P * (LC / 4) / 256;       // float4 loads per thread: dY tile
+  constexpr int NXF = KS * XW * (LC / 4);       // float4 elements of the X patch
+  constexpr int NLX = (NXF + 255) / 256;
   __shared__ __attribute__((aligned(16))) float dYs[P * LC];
   __shared__ __attribute__((aligned(16))) float Xs[KS * XW * LC];
 
@@ -316,46 +348,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 
   const float* __restrict__ xp = reinterpret_cast<const float*>(p.x.ptr);
   const float* __restrict__ dyp = reinterpret_cast<const float*>(p.dy.ptr);
-  const int hy = p.dy.h, wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
   const int c_begin = split * p.chunks_per_split;
   const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
 
-  for (int ch = c_begin; ch < c_end; ++ch) {
-    const int rowid = ch / p.chunks_per_row, seg = ch - rowid * p.chunks_per_row;
-    const int n = rowid / hy, oy = rowid - n * hy;
-    const int ox0 = seg * P;
-    const int64_t ybase = df_img_base(p.dy, n) + (int64_t)oy * wy * p.dy.ld;
-    const int64_t xbase = df_img_base(p.x, n);
-    // dY tile
-    for (int f = tid; f < P * (LC / 4); f += 256) {
+  f32x4 ry[NLY], rx[NLX];
+  unsigned my = 0, mx = 0;
+  auto fetch = [&](int ch) {
+    const WgChunk c = wg_chunk(p, ch, P);
+    const float* yb = dyp + df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0;
+    const float* xb = xp + df_img_base(p.x, c.n) + ci0;
+    my = mx = 0;
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int f = tid + 256 * j;
       const int px = f / (LC / 4), c4i = f - px * (LC / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      bool ok = ox0 + px < wy;
-      if (ok && p.row_counts) {
-        const int pp = ox0 + px, sg = pp / p.rows_per_seg;
-        ok = (pp - sg * p.rows_per_seg) < p.row_counts[sg];
-      }
-      if (ok) v = ld4(dyp + ybase + (int64_t)(ox0 + px) * p.dy.ld + co0 + c4i * 4);
-      st4(dYs + px * LC + c4i * 4, v);
+      const bool ok = (c.ox0 + px < wy) && wg_row_ok(p, c.ox0 + px);
+      ry[j] = ld4(yb + (ok ? (c.ox0 + px) * p.dy.ld : 0) + c4i * 4);
+      my |= (unsigned)ok << j;
     }
-    // X patch
-    for (int f = tid; f < KS * XW * (LC / 4); f += 256) {
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int f = tid + 256 * j;
       const int c4i = f % (LC / 4);
       const int q = f / (LC / 4);
       const int xi = q % XW, ky = q / XW;
-      const int iy = oy * STRIDE + ky - p.pad;
-      const int ix = ox0 * STRIDE + xi - p.pad;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      bool ok = iy >= 0 && iy < hx && ix >= 0 && ix < wx && ci0 + c4i * 4 < p.K;
-      if (ok && p.row_counts) {
-        const int sg = ix / p.rows_per_seg;
-        ok = (ix - sg * p.rows_per_seg) < p.row_counts[sg];
-      }
-      if (ok)
-        v = ld4(xp + xbase + ((int64_t)iy * wx + ix) * p.x.ld + ci0 + c4i * 4);
-      st4(Xs + (ky * XW + xi) * LC + c4i * 4, v);
+      const int iy = c.oy * STRIDE + ky - p.pad;
+      const int ix = c.ox0 * STRIDE + xi - p.pad;
+      const bool ok = (f < NXF) && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx && (ci0 + c4i * 4 < p.K) &&
+                      wg_row_ok(p, ix);
+      rx[j] = ld4(xb + (ok ? (iy * wx + ix) * p.x.ld + c4i * 4 : -ci0));
+      mx |= (unsigned)ok << j;
     }
-    __syncthreads();
+  };
+  auto stash = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) st4(dYs + (tid + 256 * j) * 4, ((my >> j) & 1) ? ry[j] : zero);
+#pragma unroll
+    for (int j = 0; j < NLX; ++j)
+      if (tid + 256 * j < NXF) st4(Xs + (tid + 256 * j) * 4, ((mx >> j) & 1) ? rx[j] : zero);
+  };
+
+  if (c_begin < c_end) {
+    fetch(c_begin);
+    stash();
+  }
+  __syncthreads();
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    if (ch + 1 < c_end) fetch(ch + 1);
     if (wave_active) {
 #pragma unroll 4
       for (int ks = 0; ks < P / 2; ++ks) {
@@ -371,6 +412,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       }
     }
     __syncthreads();
+    if (ch + 1 < c_end) stash();
+    __syncthreads();
   }
   if (wave_active) {
     float* o = p.ws + (int64_t)split * p.N * TAPS * p.K;
@@ -381,6 +424,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
         const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         const int ci = ci0 + wci * 32 + li;
         o[((int64_t)co * TAPS + t) * p.K + ci] = acc[t][e];
+      }
+  }
+}
+
+// 1x1 weight gradient (= row GEMM dW[co, ci] = sum_p dy[p, co] x[p, ci]) with a 128 co x CIT ci tile per workgroup:
+// every operand row is read once per tile instead of once per 64x64 tile -- the decoder's weight-gradient GEMMs
+// stream 2.6 GB planes and were HBM-bound on re-reads with the generic kernel.
+template <int CIT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
+  constexpr int P = 32, COT = 128;
+  constexpr int TCI = CIT / 64;               // 32-wide ci tiles per wave
+  constexpr int NLY = P * (COT / 4) / 256;    // 4
+  constexpr int NLX = P * (CIT / 4) / 256;    // 2 or 4
+  __shared__ __attribute__((aligned(16))) float dYs[P * COT];
+  __shared__ __attribute__((aligned(16))) float Xs[P * CIT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int ci0 = blockIdx.x * CIT, co0 = blockIdx.y * COT, split = blockIdx.z;
+  const int ciw = ci0 + wci * (CIT / 2);      // first ci of this wave
+
+  f32x16 acc[2][TCI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const float* __restrict__ xp = reinterpret_cast<const float*>(p.x.ptr);
+  const float* __restrict__ dyp = reinterpret_cast<const float*>(p.dy.ptr);
+  const int wy = p.dy.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+
+  f32x4 ry[NLY], rx[NLX];
+  unsigned my = 0, mx = 0;
+  auto fetch = [&](int ch) {
+    const WgChunk c = wg_chunk(p, ch, P);
+    const float* yb = dyp + df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0;
+    const float* xb = xp + df_img_base(p.x, c.n) + (int64_t)c.oy * wy * p.x.ld + ci0;
+    my = mx = 0;
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int f = tid + 256 * j;
+      const int px = f / (COT / 4), c4i = f - px * (COT / 4);
+      const bool ok = (c.ox0 + px < wy) && wg_row_ok(p, c.ox0 + px);
+      ry[j] = ld4(yb + (ok ? (c.ox0 + px) * p.dy.ld : 0) + c4i * 4);
+      my |= (unsigned)ok << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int f = tid + 256 * j;
+      const int px = f / (CIT / 4), c4i = f - px * (CIT / 4);
+      const bool ok = (c.ox0 + px < wy) && (ci0 + c4i * 4 < p.K) && wg_row_ok(p, c.ox0 + px);
+      rx[j] = ld4(xb + (ok ? (c.ox0 + px) * p.x.ld + c4i * 4 : -ci0));
+      mx |= (unsigned)ok << j;
+    }
+  };
+  auto stash = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) st4(dYs + (tid + 256 * j) * 4, ((my >> j) & 1) ? ry[j] : zero);
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) st4(Xs + (tid + 256 * j) * 4, ((mx >> j) & 1) ? rx[j] : zero);
+  };
+  if (c_begin < c_end) {
+    fetch(c_begin);
+    stash();
+  }
+  __syncthreads();
+  const bool wave_active = ciw < p.K;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    if (ch + 1 < c_end) fetch(ch + 1);
+    if (wave_active) {
+#pragma unroll 4
+      for (int ks = 0; ks < P / 2; ++ks) {
+        const int px = 2 * ks + kh;
+        float a[2], b[TCI];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = dYs[px * COT + wco * 64 + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) b[j] = Xs[px * CIT + wci * (CIT / 2) + j * 32 + li];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (ch + 1 < c_end) stash();
+    __syncthreads();
+  }
+  if (wave_active) {
+    float* o = p.ws + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TCI; ++j) {
+        const int ci = ciw + j * 32 + li;
+        if (ci < p.K) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            o[(int64_t)co * p.K + ci] = acc[i][j][e];
+          }
+        }
       }
   }
 }
@@ -492,12 +642,15 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   }
 }
 
+static inline bool wgrad_use_1x1(int ksize, int cout) { return ksize == 1 && (cout % 128) == 0; }
+static inline int wgrad_cit(int cin) { return cin >= 128 ? 128 : 64; }
 static inline int wgrad_chunk(int ksize) { (void)ksize; return 32; }  // 128-pixel chunks for 1x1 measured slower
 
 extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
   (void)stride;
   const int P = wgrad_chunk(ksize);
-  const int tiles = ((x.c + 63) / 64) * (dy.c / 64);
+  const int tiles = wgrad_use_1x1(ksize, dy.c) ? ((x.c + wgrad_cit(x.c) - 1) / wgrad_cit(x.c)) * (dy.c / 128)
+                                               : ((x.c + 63) / 64) * (dy.c / 64);
   const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
   int64_t splits = (1024 + tiles - 1) / tiles;
   if (splits > chunks) splits = chunks;
@@ -527,7 +680,12 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1, 32>), grid, dim3(256), 0, s, p);
+  if (wgrad_use_1x1(ksize, dy.c)) {
+    const int cit = wgrad_cit(x.c);
+    dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);
+    if (cit == 128) hipLaunchKernelGGL((wgrad1x1_kernel<128>), g1, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad1x1_kernel<64>), g1, dim3(256), 0, s, p);
+  } else if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1, 32>), grid, dim3(256), 0, s, p);
   else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1, 32>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_kernel<3, 2, 32>), grid, dim3(256), 0, s, p);
   DF_CHECK_LAUNCH();
