@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zr[t][r] = df_sigmoid(zr[t][r]);
+      for (int r = 0; r < 4; ++r) zr[t][r] = df_sigmoid_fast(zr[t][r]);
     if (p.save) {
       save_regs(1, it, zr);
       save_regs(2, it, zr + 8);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        q[t][r] = tanhf(q[t][r]);
+        q[t][r] = df_tanh_fast(q[t][r]);
         h[t][r] = (1.f - zr[t][r]) * h[t][r] + zr[t][r] * q[t][r];
         Aw[(4 * lq + r) * LDA_F + 16 * t + li] = h[t][r];
       }
