@@ -13,6 +13,8 @@
 // permuted inside each group of 8: MFMA step s of group g uses k = 8g + s on lanes 0-31 and k = 8g + 4 + s
 // on lanes 32-63 for BOTH operands, so one b128 read feeds four MFMA steps.  Global->LDS goes through
 // registers, issued one stage ahead (T14).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -32,6 +34,8 @@ struct ConvParams {
   // stride-2 dgrad: output pixels are tiled per parity class (y&1, x&1) so that a tile only visits the taps that
   // can reach it (1, 2, 2 or 4 of 9) instead of multiplying zeros.  cls_tiles = row tiles per class (0 = off).
   int cls_tiles;
+  unsigned x_bytes, w_bytes, dshift;  // DMA path: buffer extents (bytes) and the base shift that keeps offsets >= 0
+  int dbg;  // ablation switch (env DF_CONV_DBG): 1 = no global loads after the prologue, 2 = also no LDS stores
 };
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
@@ -53,6 +57,81 @@ struct RowDecode {
     }
   }
 };
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* lds,
+                                              const RowDecode& dec, int m0, int m_end, int n0, int tile_m) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  // ---- epilogue ------------------------------------------------------------------------
+  // LDS is free now: row -> output element offset table, then the stats scratch.
+  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);            // [BM]
+  float* red = lds + 2 * BM;                                    // [WM][BN][2]
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < m_end) {
+      int n, oy, ox;
+      dec(m, n, oy, ox);
+      off = df_img_base(p.y, n) + ((int64_t)oy * p.y.w + ox) * p.y.ld;
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+  float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + li;
+    const float bia = p.bias ? p.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.epi == DF_EPI_BN_GELU) {
+      sc = p.scale[co];
+      sh = p.shift[co];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int64_t off = rowoff[row];
+        float v = acc[i][j][e] + bia;
+        if (off >= 0) {
+          if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+          if (p.accumulate) v += yp[off + co];
+          yp[off + co] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (p.epi == DF_EPI_STATS) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (kh == 0) {
+        const int cl = (wn * TN + j) * 32 + li;
+        red[(wm * BN + cl) * 2 + 0] = s1;
+        red[(wm * BN + cl) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.epi == DF_EPI_STATS) {
+    __syncthreads();
+    if (tid < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1 += red[(w * BN + tid) * 2 + 0];
+        s2 += red[(w * BN + tid) * 2 + 1];
+      }
+      float* o = p.stats + ((int64_t)tile_m * p.N + n0 + tid) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
@@ -189,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     const int buf = st & 1;
-    if (st + 1 < nst) load_stage();
+    if (st + 1 < nst && p.dbg == 0) load_stage();
     const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
     const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
 #pragma unroll
@@ -207,76 +286,165 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < nst) store_stage(buf ^ 1);
+    if (st + 1 < nst && p.dbg < 2) store_stage(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------
-  // LDS is free now: row -> output element offset table, then the stats scratch.
-  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);            // [BM]
-  float* red = lds + 2 * BM;                                    // [WM][BN][2]
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int64_t off = -1;
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, m_end, n0, tile_m);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default): every stage's A and B tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds`
+// (no VGPR staging, no ds_write pass).  gfx950 semantics used (probed on hardware, tools/dma_probe.hip): the wave's
+// 64 lanes land at LDS base + lane * 16 (so one instruction fills 8 tile rows of 128 B); the per-lane SOURCE is free,
+// so the XOR slot swizzle is applied to the source column; a lane whose voffset + soffset is outside the buffer
+// writes ZEROS -- padding taps and out-of-tile rows cost one v_cndmask instead of a branch; the (tap, k-chunk)
+// offset of a stage is wave-uniform and rides in soffset (SGPR), so per stage a thread only recomputes validity.
+constexpr unsigned DMA_BAD = 0xFFFFFFFFu - (8u << 20);  // + soffset (< 8 MB) never wraps, always out of range
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                     // [2][BM][LDT]
+  float* Bs = lds + 2 * BM * LDT;      // [2][BN][LDT]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN;
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BK;
+
+  RowDecode dec;
+  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = p.cls_tiles > 0; dec.py = dec.px = 0;
+  dec.hh = p.y.h >> 1; dec.wh = p.y.w >> 1;
+  int m0 = tile_m * BM, m_end = p.M;
+  // tap enumeration: address taps (ty, tx) add (ty * wx + tx) pixels to the row's origin; weight tap index per mode
+  int nky = p.ks, nkx = p.ks, ky0 = 0, kx0 = 0;
+  const bool fwd = p.mode == DF_CONV_FWD;
+  if (dec.cls_mode) {
+    const int cls = tile_m / p.cls_tiles;
+    dec.py = cls >> 1; dec.px = cls & 1;
+    m0 = (tile_m - cls * p.cls_tiles) * BM;
+    m_end = p.y.n * dec.hh * dec.wh;
+    ky0 = (dec.py + p.pad) & 1; kx0 = (dec.px + p.pad) & 1;
+    nky = (p.ks - ky0 + 1) >> 1; nkx = (p.ks - kx0 + 1) >> 1;
+  }
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  const int c4s = c4 ^ ((r0 >> 1) & 7);  // logical 16-B slot this lane fetches (it lands in physical slot c4)
+  unsigned aoff[RA], boff[RB];
+  int ay[RA], ax[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    ay[i] = ax[i] = -(1 << 28);
+    aoff[i] = DMA_BAD;
     if (m < m_end) {
       int n, oy, ox;
       dec(m, n, oy, ox);
-      off = df_img_base(p.y, n) + ((int64_t)oy * p.y.w + ox) * p.y.ld;
+      if (dec.cls_mode) {          // stride-2 transposed conv: input row = y' + dyt, dyt in {0, 1}
+        ay[i] = oy >> 1;
+        ax[i] = ox >> 1;
+      } else if (fwd) {
+        ay[i] = oy * p.stride - p.pad;
+        ax[i] = ox * p.stride - p.pad;
+      } else {                     // stride-1 dgrad = correlation with flipped taps
+        ay[i] = oy - p.pad;
+        ax[i] = ox - p.pad;
+      }
+      aoff[i] = (unsigned)((df_img_base(p.x, n) + ((int64_t)ay[i] * wx + ax[i]) * ldx + c4s * 4) * 4 + p.dshift);
     }
-    rowoff[tid] = off;
   }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + 32 * i) * p.ks * p.ks * p.K + c4s * 4) * 4);
+
+  int l_kc = 0, l_iky = 0, l_ikx = 0;
+  auto load_stage = [&](int buf) {
+    int ty, tx, wtap;  // address tap, weight tap
+    if (dec.cls_mode) {
+      const int ky = ky0 + 2 * l_iky, kx = kx0 + 2 * l_ikx;
+      ty = (dec.py + p.pad - ky) >> 1;
+      tx = (dec.px + p.pad - kx) >> 1;
+      wtap = ky * p.ks + kx;
+    } else {
+      ty = l_iky; tx = l_ikx;
+      wtap = fwd ? ty * p.ks + tx : (p.ks - 1 - ty) * p.ks + (p.ks - 1 - tx);
+    }
+    const unsigned soffA = (unsigned)(((ty * wx + tx) * ldx + l_kc * BK) * 4);
+    const unsigned soffB = (unsigned)((wtap * p.K + l_kc * BK) * 4);
+    float* a = As + buf * BM * LDT + wave * 8 * LDT;
+    float* b = Bs + buf * BN * LDT + wave * 8 * LDT;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const bool ok = (unsigned)(ay[i] + ty) < (unsigned)hx && (unsigned)(ax[i] + tx) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * 32 * LDT), 16, ok ? aoff[i] : DMA_BAD, soffA, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 32 * LDT), 16, boff[i], soffB, 0, 0);
+    if (++l_kc == KC) {
+      l_kc = 0;
+      if (++l_ikx == nkx) {
+        l_ikx = 0;
+        ++l_iky;
+      }
+    }
+  };
+  int rslot[BK / 8];
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) rslot[g] = ((2 * g + kh) ^ ((li >> 1) & 7)) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nst = nky * nkx * KC;
+  load_stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) load_stage(buf ^ 1);   // buf^1 was last read in stage st-1; every wave has passed that barrier
+    const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
+    const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + (wn * TN + j) * 32 + li;
-    const float bia = p.bias ? p.bias[co] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (p.epi == DF_EPI_BN_GELU) {
-      sc = p.scale[co];
-      sh = p.shift[co];
-    }
-    float s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[TM], bf[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) af[i] = ld4(a + i * 32 * LDT + rslot[g]);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int64_t off = rowoff[row];
-        float v = acc[i][j][e] + bia;
-        if (off >= 0) {
-          if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-          if (p.accumulate) v += yp[off + co];
-          yp[off + co] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
+      for (int j = 0; j < TN; ++j) bf[j] = ld4(b + j * 32 * LDT + rslot[g]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (p.epi == DF_EPI_STATS) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (kh == 0) {
-        const int cl = (wn * TN + j) * 32 + li;
-        red[(wm * BN + cl) * 2 + 0] = s1;
-        red[(wm * BN + cl) * 2 + 1] = s2;
-      }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for the next stage has landed
+    __syncthreads();                                     // ... and everyone's
   }
-  if (p.epi == DF_EPI_STATS) {
-    __syncthreads();
-    if (tid < BN) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s1 += red[(w * BN + tid) * 2 + 0];
-        s2 += red[(w * BN + tid) * 2 + 1];
-      }
-      float* o = p.stats + ((int64_t)tile_m * p.N + n0 + tid) * 2;
-      o[0] = s1;
-      o[1] = s2;
-    }
-  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, m_end, n0, tile_m);
+#endif
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -289,7 +457,17 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
+  static bool attr_set_dma = false;
+  if (!attr_set_dma) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set_dma = true;
+  }
+  if (p.x_bytes)
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
+  else
+    hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -617,6 +795,8 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
   p.M = (int)M; p.K = x.c; p.N = y.c;
   p.cls_tiles = 0;
+  static const int dbg_env = getenv("DF_CONV_DBG") ? atoi(getenv("DF_CONV_DBG")) : 0;
+  p.dbg = dbg_env;
   const int64_t rows_per_group = (int64_t)y.grp_size * p.hw_y;
   int64_t rows = M;
   const bool cls = mode == DF_CONV_DGRAD && stride == 2 && ksize == 3 && epi == DF_EPI_BIAS && (y.h % 2) == 0 && (y.w % 2) == 0;
@@ -632,6 +812,22 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
     p.tiles_m = (int)((M + bm - 1) / bm);
   }
   p.tiles_n = p.N / (var % 1000);
+  // LDS-DMA path needs 32-bit byte offsets: extent of x (+ the shift that keeps the top-left tap offset >= 0)
+  p.x_bytes = p.w_bytes = p.dshift = 0;
+  {
+    static const int no_dma = getenv("DF_CONV_NO_DMA") ? atoi(getenv("DF_CONV_NO_DMA")) : 0;
+    const int64_t groups = x.n / x.grp_size;
+    const int64_t ext = ((int64_t)(x.grp_size - 1) * x.img_stride + (groups - 1) * x.grp_off + (int64_t)x.h * x.w * x.ld) * 4;
+    const int64_t dsh = (p.cls_tiles > 0) ? 0 : (int64_t)pad * ((int64_t)x.w + 1) * x.ld * 4;
+    const int64_t wb = (int64_t)p.N * ksize * ksize * p.K * 4;
+    const bool geom_ok = !(mode == DF_CONV_DGRAD && stride == 2 && p.cls_tiles == 0);  // generic s2 dgrad: register path
+    if (!no_dma && geom_ok && x.img_stride >= 0 && x.grp_off >= 0 && ext + dsh < (int64_t)DMA_BAD - (16 << 20) && wb < (1ll << 31) &&
+        ((int64_t)2 * x.w + 2) * x.ld * 4 + (int64_t)p.K * 4 < (8 << 20)) {
+      p.x_bytes = (unsigned)(ext + dsh);
+      p.w_bytes = (unsigned)wb;
+      p.dshift = (unsigned)dsh;
+    }
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);

@@ -45,20 +45,26 @@ __device__ __forceinline__ void gemm_stream(const float* __restrict__ W, int ldw
     if (more) stage_load<ROWS>(stg, W, ldw, c + 1);
     else if (Wnext) stage_load<ROWS_NEXT>(stg, Wnext, ldw_next, 0);
     const float* bb = b_lane + ((par + c) & 1) * BS;
+    // Fragment reads are software-pipelined one tile pair ahead: with one wave per SIMD nothing else hides the LDS
+    // latency, so the reads for pair j+1 are issued before the 8 MFMAs of pair j.  Two accumulators alternate, so
+    // back-to-back MFMAs never depend on each other (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency).
+    constexpr int NPAIR = ROWS / 32;  // tile pairs per 16-wide k group
+    const f32x4 a0 = ld4(a_lane + c * 32), a1 = ld4(a_lane + c * 32 + 16);
+    f32x4 nb0 = ld4(bb), nb1 = ld4(bb + 16 * LDB);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const f32x4 a = ld4(a_lane + c * 32 + g * 16);
-      // two accumulators interleaved: back-to-back MFMAs never depend on each other (16x16x4 f32: 32-cycle issue,
-      // 40-cycle dependent latency)
+    for (int j = 0; j < 2 * NPAIR; ++j) {
+      const int g = j / NPAIR, t = 2 * (j % NPAIR);
+      const f32x4 b0 = nb0, b1 = nb1;
+      if (j + 1 < 2 * NPAIR) {
+        const int gn = (j + 1) / NPAIR, tn = 2 * ((j + 1) % NPAIR);
+        nb0 = ld4(bb + tn * 16 * LDB + gn * 16);
+        nb1 = ld4(bb + (tn + 1) * 16 * LDB + gn * 16);
+      }
+      const f32x4 a = g ? a1 : a0;
 #pragma unroll
-      for (int t = 0; t < ROWS / 16; t += 2) {
-        const f32x4 b0 = ld4(bb + t * 16 * LDB + g * 16);
-        const f32x4 b1 = ld4(bb + (t + 1) * 16 * LDB + g * 16);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
-        }
+      for (int s = 0; s < 4; ++s) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
       }
     }
     float* nb = Bs + ((par + c + 1) & 1) * BS;

@@ -1,0 +1,34 @@
+"""micro-benchmark of the fused decoder kernels at the bench shape (B=16, N=80000, 512x512)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deflow_amd.decoder import ConvGRUDecoder, PointSet
+from deflow_amd._lib import img
+
+dev = torch.device("cuda")
+B, N, H = 16, 80000, 512
+torch.manual_seed(0)
+head = ConvGRUDecoder(num_iters=4).to(dev)
+before = torch.randn(B, H, H, 64, device=dev)
+after = torch.randn(B, H, H, 64, device=dev)
+coords = torch.zeros(B, N, 3, dtype=torch.int32, device=dev)
+coords[..., 1:] = torch.randint(0, H, (B, N, 2), device=dev, dtype=torch.int32)
+offs = (torch.rand(B, N, 3, device=dev) - 0.5) * 0.2
+counts = torch.full((B,), int(N * 0.9), dtype=torch.int32, device=dev)
+ps = PointSet(coords, offs, counts)
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+flops = 0.9 * B * N * (4 * 3 * 2 * 192 * 128 + 2 * 192 * 32)
+t_inf = timeit(lambda: head.run(img(before), img(after), ps, False))
+t_trn = timeit(lambda: head.run(img(before), img(after), ps, True))
+print(f"gru fwd inference {t_inf:.2f} ms ({flops / t_inf / 1e9:.1f} TF/s)   training(save) {t_trn:.2f} ms ({flops / t_trn / 1e9:.1f} TF/s)")
