@@ -123,7 +123,7 @@ def main():
                 f.write(f"{name:28s} {flops / 1e9:10.2f} GF {ms_:8.3f} ms {flops / ms_ / 1e9:8.1f} TF/s\n")
     if prof is not None:
         summ = prof.summary()
-        conv = {k: v for k, v in summ.items() if k.startswith("conv_kernel")}
+        conv = {k: v for k, v in summ.items() if k.startswith("conv_")}
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -54,6 +54,7 @@ _SIGS = {
     "df_conv2d": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_tile_m": [L, I],
     "df_conv2d_variant": [L, L, I, I],
+    "df_conv2d_last_dma": [],
     "df_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P],
     "df_bn_gelu_apply": [P, P, I, DfImg, P],
     "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],
@@ -80,7 +81,7 @@ _SIGS = {
     "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
 }
 _RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
-_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant"}  # return values, not status
+_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

@@ -767,6 +767,9 @@ extern "C" int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int 
   return pick_variant(rows, rows_per_stat_group, cout, epi);
 }
 
+static int g_last_dma = 0;
+extern "C" int df_conv2d_last_dma(void) { return g_last_dma; }  // 1 if the previous df_conv2d used the LDS-DMA kernel
+
 extern "C" int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout) {
   return pick_variant(rows_per_stat_group, rows_per_stat_group, cout, DF_EPI_STATS) / 1000;
 }
@@ -828,6 +831,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
       p.dshift = (unsigned)dsh;
     }
   }
+  g_last_dma = p.x_bytes != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);

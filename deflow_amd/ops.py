@@ -52,7 +52,8 @@ def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int)
         v = call("df_conv2d_variant", rows, y.grp_size * y.h * y.w, y.c, epi)
     bm, bn = v // 1000, v % 1000
     wm, wn = {(128, 32): (4, 1), (256, 64): (4, 1)}.get((bm, bn), (2, 2))
-    return f"conv_kernel<{bm},{bn},{wm},{wn}>"
+    kern = "conv_dma_kernel" if call("df_conv2d_last_dma") else "conv_kernel"
+    return f"{kern}<{bm},{bn},{wm},{wn}>"
 
 
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
@@ -144,7 +145,9 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, stream())
     if prof is not None:
         e1.record()
-        prof.records.append((f"wgrad_kernel<{ks},{stride}>", 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
+        name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+                else f"wgrad_kernel<{ks},{stride},32>")  # mirrors df_conv2d_wgrad's dispatch
+        prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
 

@@ -1,0 +1,119 @@
+"""Minimal trainer with the reference's command-line surface:
+
+    python -m deflow_amd.train model=deflow lr=2e-4 epochs=15 batch_size=16 loss_fn=deflowLoss \
+           "model.target.num_iters=4" "voxel_size=[0.2, 0.2, 6]" checkpoint=out.ckpt      [REF README.md:66; 1_train.sh:28-78]
+
+hydra-style ``key=value`` overrides (lists in brackets, dotted ``model.target.*`` keys), data-parallel under
+``torch.distributed.run`` (one process per GPU, RCCL), checkpoints in the Lightning layout the reference's
+``load_from_checkpoint`` expects ({"state_dict": {"model.<name>": tensor}, "hyper_parameters": cfg, ...}
+[REF deflow.py:41-47]).  The HDF5 dataset is out of scope (h5py absent, section 8(f) N2): ``train_data=synthetic``
+draws seeded Argoverse-2-shaped pairs (deflow_amd/synth.py).  wandb / slurm keys are accepted and ignored."""
+from __future__ import annotations
+
+import ast
+import json
+import os
+import sys
+import time
+from typing import Any, Dict, List
+
+import torch
+
+DEFAULTS: Dict[str, Any] = {
+    "model": "deflow", "lr": 2e-4, "epochs": 1, "batch_size": 16, "loss_fn": "deflowLoss", "num_workers": 0,
+    "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
+    "model.target.num_iters": 4, "model.target.decoder_option": "gru",
+    "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
+    "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 1,
+}
+
+
+def parse_overrides(argv: List[str]) -> Dict[str, Any]:
+    cfg = dict(DEFAULTS)
+    for a in argv:
+        if "=" not in a:
+            raise SystemExit(f"expected key=value, got {a!r}")
+        k, v = a.split("=", 1)
+        k = k.lstrip("+")
+        try:
+            val = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            val = v
+        cfg[k] = val
+    if cfg["model"] not in ("deflow", "fastflow3d"):
+        raise SystemExit(f"unknown model {cfg['model']!r}")
+    if cfg["model"] == "fastflow3d":
+        cfg["model.target.decoder_option"] = "linear"
+    if cfg["loss_fn"] != "deflowLoss":
+        raise SystemExit("only loss_fn=deflowLoss is implemented (ff3dLoss / zeroflowLoss are ablation baselines)")
+    return cfg
+
+
+def grid_from(cfg) -> List[int]:
+    vs, rg = cfg["voxel_size"], cfg["point_cloud_range"]
+    return [int(round((rg[4] - rg[1]) / vs[1])), int(round((rg[3] - rg[0]) / vs[0]))]
+
+
+def build_model(cfg):
+    import deflow_amd
+    return deflow_amd.DeFlow(voxel_size=cfg["voxel_size"], point_cloud_range=cfg["point_cloud_range"],
+                             grid_feature_size=grid_from(cfg), decoder_option=cfg["model.target.decoder_option"],
+                             num_iters=int(cfg["model.target.num_iters"]))
+
+
+def save_checkpoint(path: str, model, trainer, cfg, epoch: int, step: int):
+    sd = {"model." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+    opt = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in trainer.opt.state_dict().items()}
+    torch.save({"state_dict": sd, "hyper_parameters": {"cfg": cfg}, "epoch": epoch, "global_step": step,
+                "optimizer_states": [opt], "pytorch-lightning_version": "deflow_amd"}, path)
+
+
+def main(argv=None):
+    cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "training runs on the HIP engine only"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from deflow_amd.metrics import evaluate_batch
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+
+    torch.manual_seed(int(cfg["seed"]))
+    model = build_model(cfg).to(dev)
+    if cfg["checkpoint"]:
+        model.load_from_checkpoint(cfg["checkpoint"])
+    model.train()
+    trainer = Trainer(model, lr=float(cfg["lr"]))
+    B, N, H = int(cfg["batch_size"]), int(cfg["points_per_cloud"]), grid_from(cfg)[0]
+    steps_per_epoch = max(1, int(cfg["pairs_per_epoch"]) // (B * world))
+    gstep = 0
+    for epoch in range(int(cfg["epochs"])):
+        for it in range(steps_per_epoch):
+            seed = Trainer.shard_seed(int(cfg["seed"]) + (epoch * steps_per_epoch + it) * B * world, rank, B)
+            batch = synth_batch(B, N, seed=seed, grid_hw=(H, H), device=dev)
+            t0 = time.perf_counter()
+            loss = trainer.step(batch)
+            gstep += 1
+            if rank == 0 and gstep % int(cfg["log_every"]) == 0:
+                lv = float(loss)  # sync only when logging
+                print(json.dumps({"epoch": epoch, "step": gstep, "trainer/loss": lv / B,
+                                  "pairs_per_s": B * world / (time.perf_counter() - t0)}), flush=True)
+        model.eval()
+        with torch.no_grad():
+            vb = synth_batch(min(B, 4), N, seed=int(cfg["seed"]) + 10 ** 6 + epoch, grid_hw=(H, H), device=dev)
+            metrics = evaluate_batch(model(vb), vb)
+        model.train()
+        if rank == 0:
+            print(json.dumps({"epoch": epoch, "val": metrics}), flush=True)
+            if cfg["save_checkpoint"]:
+                save_checkpoint(cfg["save_checkpoint"], model, trainer, cfg, epoch, gstep)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

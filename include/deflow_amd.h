@@ -110,6 +110,7 @@ int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, 
 int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick for DF_EPI_STATS */
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);
+int df_conv2d_last_dma(void); /* 1 if the previous df_conv2d call launched the LDS-DMA kernel (profiling tools) */
 /* BatchNorm2d training statistics from the partials. groups = stat groups (the shared encoder is
  * applied to pc0 then pc1: two calls => two groups, running stats updated in call order).
  * bn_ss [groups,4,C] = scale, shift, mean, invstd. */

@@ -1,0 +1,50 @@
+"""CPU: hydra-style override parsing, Lightning-layout checkpoint round trip, EPE metrics (rows N1 / N3)."""
+import os
+
+import pytest
+import torch
+
+
+def test_parse_overrides_reference_commands():
+    from deflow_amd.train import parse_overrides, grid_from
+    c = parse_overrides("model=deflow lr=2e-4 epochs=15 batch_size=16 loss_fn=deflowLoss".split())   # [REF README.md:66]
+    assert c["lr"] == 2e-4 and c["epochs"] == 15 and c["batch_size"] == 16 and grid_from(c) == [512, 512]
+    c = parse_overrides(["model=deflow", "model.target.num_iters=8", "model.target.decoder_option=gru",
+                         "voxel_size=[0.1, 0.1, 6]", "wandb_mode=online", "slurm_id=123"])            # [REF 1_train.sh:42,66,74]
+    assert c["model.target.num_iters"] == 8 and c["voxel_size"] == [0.1, 0.1, 6] and grid_from(c) == [1024, 1024]
+    assert parse_overrides(["model=fastflow3d"])["model.target.decoder_option"] == "linear"
+    with pytest.raises(SystemExit):
+        parse_overrides(["loss_fn=zeroflowLoss"])
+
+
+def test_checkpoint_roundtrip_lightning_layout(tmp_path):
+    import deflow_amd
+    from deflow_amd.optim import Trainer
+    from deflow_amd.train import save_checkpoint, parse_overrides
+    cfg = parse_overrides(["voxel_size=[0.2, 0.2, 6]", "point_cloud_range=[-6.4, -6.4, -3, 6.4, 6.4, 3]"])
+    kw = dict(voxel_size=cfg["voxel_size"], point_cloud_range=cfg["point_cloud_range"], grid_feature_size=[64, 64])
+    torch.manual_seed(1)
+    m = deflow_amd.DeFlow(**kw)
+    tr = Trainer(m)
+    p = os.path.join(tmp_path, "x.ckpt")
+    save_checkpoint(p, m, tr, cfg, 3, 42)
+    ck = torch.load(p, map_location="cpu")
+    assert all(k.startswith("model.") for k in ck["state_dict"]) and ck["epoch"] == 3
+    assert ck["state_dict"]["model.backbone.decoder_step4.weight"].is_contiguous()
+    torch.manual_seed(2)
+    m2 = deflow_amd.DeFlow(**kw)
+    r = m2.load_from_checkpoint(p)            # the reference's loader contract [REF deflow.py:41-47]
+    assert not r.missing_keys and not r.unexpected_keys
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_epe_metrics():
+    from deflow_amd.metrics import epe_metrics
+    gt = torch.tensor([[0.0, 0, 0], [1.0, 0, 0], [0.0, 2.0, 0], [float("nan")] * 3])
+    est = torch.tensor([[0.03, 0, 0], [1.0, 0.2, 0], [0.0, 2.0, 0.04], [0.0, 0, 0]])
+    pose = torch.zeros(4, 3)
+    m = epe_metrics(est, gt, pose)
+    assert m["n"] == 3 and abs(m["EPE"] - (0.03 + 0.2 + 0.04) / 3) < 1e-6
+    assert abs(m["AccS"] - 2 / 3) < 1e-6 and abs(m["AccR"] - 2 / 3) < 1e-6
+    assert abs(m["EPE_FD"] - 0.12) < 1e-6 and abs(m["EPE_FS"] - 0.03) < 1e-6
