@@ -479,6 +479,7 @@ struct WgradParams {
   const int32_t* row_counts;  // optional (1x1 only): pixel p of a row list is valid iff p % rows_per_seg < row_counts[p / rows_per_seg]
   int rows_per_seg;
   int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
+  unsigned x_bytes, dy_bytes;  // DMA path: buffer extents (0 = use the register-staged kernels)
 };
 
 // chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
@@ -713,6 +714,210 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// LDS-DMA variants of the weight-gradient kernels: operand tiles go straight to double-buffered LDS with
+// buffer_load_dwordx4 ... lds (out-of-range lanes = zeros = padding / masked rows), one barrier per chunk, no VGPR
+// staging.  LDS images are pixel-major [pixel][channel tile] and linear (fragment reads are lane-consecutive b32).
+template <int KS, int STRIDE, int P>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int XW = (P - 1) * STRIDE + KS;
+  constexpr int TAPS = KS * KS;
+  constexpr int LC = 64;
+  constexpr int YSZ = P * LC, XSZ = ((KS * XW + 3) / 4) * 4 * LC;  // floats per buffer (X rounded up to whole DMA ops)
+  constexpr int NYI = P / 4, NXI = (KS * XW + 3) / 4;               // 1-KB DMA ops (4 pixels x 64 ch) per tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dYs = lds;               // [2][YSZ]
+  float* Xs = lds + 2 * YSZ;      // [2][XSZ]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wci = wave & 1, wco = wave >> 1;
+  const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
+  const bool wave_active = (ci0 + wci * 32) < p.K;
+  const int lp = lane >> 4, lc4 = lane & 15;   // pixel within the DMA op, 16-byte channel slot
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const bool ci_ok = ci0 + lc4 * 4 < p.K;
+
+  auto issue = [&](int ch, int buf) {
+    const WgChunk c = wg_chunk(p, ch, P);
+    const int64_t yb = df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0 + lc4 * 4;
+    const int64_t xb = df_img_base(p.x, c.n) + ci0 + lc4 * 4;
+    for (int k = wave; k < NYI; k += 4) {
+      const int px = 4 * k + lp;
+      const bool ok = c.ox0 + px < wy && wg_row_ok(p, c.ox0 + px);
+      const unsigned vo = ok ? (unsigned)((yb + (int64_t)(c.ox0 + px) * p.dy.ld) * 4) : DMA_BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + buf * YSZ + k * 256), 16, vo, 0, 0, 0);
+    }
+    for (int k = wave; k < NXI; k += 4) {
+      const int q = 4 * k + lp;
+      const int ky = q / XW, xi = q - ky * XW;
+      const int iy = c.oy * STRIDE + ky - p.pad, ix = c.ox0 * STRIDE + xi - p.pad;
+      const bool ok = ci_ok && ky < KS && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx && wg_row_ok(p, ix);
+      const unsigned vo = ok ? (unsigned)((xb + ((int64_t)iy * wx + ix) * p.x.ld) * 4) : DMA_BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + buf * XSZ + k * 256), 16, vo, 0, 0, 0);
+    }
+  };
+
+  if (c_begin < c_end) issue(c_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+    if (wave_active) {
+      const float* dyb = dYs + buf * YSZ;
+      const float* xbuf = Xs + buf * XSZ;
+#pragma unroll 4
+      for (int ks = 0; ks < P / 2; ++ks) {
+        const int px = 2 * ks + kh;
+        const float a = dyb[px * LC + wco * 32 + li];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float b = xbuf[(ky * XW + px * STRIDE + kx) * LC + wci * 32 + li];
+            acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * KS + kx], 0, 0, 0);
+          }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (wave_active) {
+    float* o = p.ws + (int64_t)split * p.N * TAPS * p.K;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * TAPS + t) * p.K + ci] = acc[t][e];
+      }
+  }
+#endif
+}
+
+template <int CIT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 32, COT = 128;
+  constexpr int TCI = CIT / 64;
+  constexpr int YSZ = P * COT, XSZ = P * CIT;
+  constexpr int YPP = 1024 / (COT * 4), XPP = 1024 / (CIT * 4);   // pixels per 1-KB DMA op (2; 2 or 4)
+  constexpr int NYI = P / YPP, NXI = P / XPP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dYs = lds;
+  float* Xs = lds + 2 * YSZ;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int ci0 = blockIdx.x * CIT, co0 = blockIdx.y * COT, split = blockIdx.z;
+  const int ciw = ci0 + wci * (CIT / 2);
+
+  f32x16 acc[2][TCI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int ylp = lane / (COT / 4), yc4 = lane % (COT / 4);
+  const int xlp = lane / (CIT / 4), xc4 = lane % (CIT / 4);
+  const bool ci_ok = ci0 + xc4 * 4 < p.K;
+
+  auto issue = [&](int ch, int buf) {
+    const WgChunk c = wg_chunk(p, ch, P);
+    const int64_t yb = df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0 + yc4 * 4;
+    const int64_t xb = df_img_base(p.x, c.n) + (int64_t)c.oy * wy * p.x.ld + ci0 + xc4 * 4;
+    for (int k = wave; k < NYI; k += 4) {
+      const int px = c.ox0 + YPP * k + ylp;
+      const bool ok = px < wy && wg_row_ok(p, px);
+      const unsigned vo = ok ? (unsigned)((yb + (int64_t)px * p.dy.ld) * 4) : DMA_BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + buf * YSZ + k * 256), 16, vo, 0, 0, 0);
+    }
+    for (int k = wave; k < NXI; k += 4) {
+      const int px = c.ox0 + XPP * k + xlp;
+      const bool ok = ci_ok && px < wy && wg_row_ok(p, px);
+      const unsigned vo = ok ? (unsigned)((xb + (int64_t)px * p.x.ld) * 4) : DMA_BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + buf * XSZ + k * 256), 16, vo, 0, 0, 0);
+    }
+  };
+  if (c_begin < c_end) issue(c_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bool wave_active = ciw < p.K;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    const int buf = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+    if (wave_active) {
+      const float* dyb = dYs + buf * YSZ;
+      const float* xbuf = Xs + buf * XSZ;
+#pragma unroll 4
+      for (int ks = 0; ks < P / 2; ++ks) {
+        const int px = 2 * ks + kh;
+        float a[2], b[TCI];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = dyb[px * COT + wco * 64 + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) b[j] = xbuf[px * CIT + wci * (CIT / 2) + j * 32 + li];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (wave_active) {
+    float* o = p.ws + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TCI; ++j) {
+        const int ci = ciw + j * 32 + li;
+        if (ci < p.K) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            o[(int64_t)co * p.K + ci] = acc[i][j][e];
+          }
+        }
+      }
+  }
+#endif
+}
+
+template <typename K>
+static int launch_wgrad_dma(K kern, dim3 grid, size_t lds_bytes, hipStream_t s, const WgradParams& p) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int64_t per_split, int row_len,
                                     float* __restrict__ dw, int64_t ld_co, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -880,6 +1085,35 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  p.x_bytes = p.dy_bytes = 0;
+  {
+    static const int no_dma = getenv("DF_CONV_NO_DMA") ? atoi(getenv("DF_CONV_NO_DMA")) : 0;
+    auto extent = [](const df_img& d) {
+      return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+    };
+    const int64_t ex = extent(x), ey = extent(dy);
+    if (!no_dma && x.img_stride >= 0 && dy.img_stride >= 0 && x.grp_off >= 0 && dy.grp_off >= 0 &&
+        ex < (int64_t)DMA_BAD && ey < (int64_t)DMA_BAD) {
+      p.x_bytes = (unsigned)ex;
+      p.dy_bytes = (unsigned)ey;
+    }
+  }
+  // Measured on MI355X (bs16 step): the DMA form wins for 3x3 stride 1 (124.7 -> 128.4 TFLOP/s); for 1x1 and stride 2
+  // the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step; s2 needs 116 KB LDS = 1 workgroup/CU), so
+  // those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere (A/B runs, tests).
+  static const int dma_all = getenv("DF_WGRAD_DMA_ALL") ? atoi(getenv("DF_WGRAD_DMA_ALL")) : 0;
+  if (p.x_bytes && (dma_all || (ksize == 3 && stride == 1))) {
+    if (wgrad_use_1x1(ksize, dy.c)) {
+      const int cit = wgrad_cit(x.c);
+      dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);
+      if (cit == 128) return launch_wgrad_dma(wgrad1x1_dma_kernel<128>, g1, 2 * (32 * 128 + 32 * 128) * 4, s, p);
+      return launch_wgrad_dma(wgrad1x1_dma_kernel<64>, g1, 2 * (32 * 128 + 32 * 64) * 4, s, p);
+    }
+    auto bytes = [](int ks_, int st_) { const int xw = 31 * st_ + ks_; return (size_t)2 * (32 * 64 + ((ks_ * xw + 3) / 4) * 4 * 64) * 4; };
+    if (ksize == 1) return launch_wgrad_dma(wgrad_dma_kernel<1, 1, 32>, grid, bytes(1, 1), s, p);
+    if (stride == 1) return launch_wgrad_dma(wgrad_dma_kernel<3, 1, 32>, grid, bytes(3, 1), s, p);
+    return launch_wgrad_dma(wgrad_dma_kernel<3, 2, 32>, grid, bytes(3, 2), s, p);
+  }
   if (wgrad_use_1x1(ksize, dy.c)) {
     const int cit = wgrad_cit(x.c);
     dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);

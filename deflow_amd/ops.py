@@ -146,7 +146,8 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     if prof is not None:
         e1.record()
         name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
-                else f"wgrad_kernel<{ks},{stride},32>")  # mirrors df_conv2d_wgrad's dispatch
+                else (f"wgrad_dma_kernel<{ks},{stride},32>" if (ks == 3 and stride == 1) else f"wgrad_kernel<{ks},{stride},32>"))
+        # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
