@@ -959,12 +959,16 @@ bool img_ok(const df_img& d) {
 // tile variant as BM * 1000 + BN.  rows = GEMM rows one tile range covers (per parity class in class mode).
 static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi) {
   if (cout % 64) return 128032;
+  static const int force = getenv("DF_CONV_TILE") ? atoi(getenv("DF_CONV_TILE")) : 0;  // A/B experiments only
+  if (force == 128064 && rows > 128 * 256 && (epi != DF_EPI_STATS || rows_per_stat_group % 128 == 0)) return 128064;
   int bm;
   if (epi == DF_EPI_STATS) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
   else bm = (rows <= 128 * 256) ? 64 : 128;  // small problems: more tiles to fill 256 CUs
   if (bm == 64) return 64064;
   if (cout % 128 == 0) return 128128;
-  const bool ok256 = (epi == DF_EPI_STATS) ? (rows_per_stat_group % 256 == 0) : (rows >= 256 * 512 && rows % 256 == 0);
+  // 64 output channels: 128x64 (48 KB LDS -> 3 workgroups/CU) measured 120 vs 115 TFLOP/s for the 256x64 tile
+  static const int use256 = getenv("DF_CONV_TILE") ? atoi(getenv("DF_CONV_TILE")) == 256064 : 0;
+  const bool ok256 = use256 && ((epi == DF_EPI_STATS) ? (rows_per_stat_group % 256 == 0) : (rows >= 256 * 512 && rows % 256 == 0));
   return ok256 ? 256064 : 128064;
 }
 
