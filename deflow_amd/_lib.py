@@ -73,6 +73,7 @@ _SIGS = {
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
     "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],
     "df_linear_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, P, P, P, P, P, P, P, P],
+    "df_linear_decoder_bwd": [DfImg, DfImg, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_ego_transform": [P, P, I, I, P, P, P],
     "df_deflow_loss_fwd": [P, P, P, I, I, P, I, P],
     "df_deflow_loss_finalize": [P, I, I, P, P, P],

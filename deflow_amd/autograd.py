@@ -38,6 +38,7 @@ class GruHeadFn(torch.autograd.Function):
         ah = after.detach().permute(0, 2, 3, 1).contiguous()
         flow, sv = head.run(img(bh), img(ah), ps, True)
         ctx.head, ctx.ps, ctx.sv, ctx.shape, ctx.params = head, ps, sv, bh.shape, list(params)
+        ctx.imgs = (bh, ah)
         return flow
 
     @staticmethod
@@ -48,8 +49,9 @@ class GruHeadFn(torch.autograd.Function):
         db = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         da = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         grads = GradDict()
-        head.run_backward(dflow, ps, ctx.sv, img(db), img(da), False, False, grads)
-        ctx.sv = None
+        head.run_backward(dflow, ps, ctx.sv, img(db), img(da), False, False, grads, before=img(ctx.imgs[0]),
+                          after=img(ctx.imgs[1]))
+        ctx.sv = ctx.imgs = None
         return (None, None, db.permute(0, 3, 1, 2), da.permute(0, 3, 1, 2)) + _grads_for(ctx.params, grads)
 
 
@@ -75,7 +77,8 @@ class DeFlowFn(torch.autograd.Function):
         dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         dv = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
-        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads)
+        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                before=img(bstar), after=img(st["v"]))
         st["sv"] = None
         # UNet: accumulates its own d(bstar) into the same buffer
         model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads)

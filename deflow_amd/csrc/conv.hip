@@ -1061,7 +1061,8 @@ extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride
   const int tiles = wgrad_use_1x1(ksize, dy.c) ? ((x.c + wgrad_cit(x.c) - 1) / wgrad_cit(x.c)) * (dy.c / 128)
                                                : ((x.c + 63) / 64) * (dy.c / 64);
   const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
-  int64_t splits = (1024 + tiles - 1) / tiles;
+  static const int target = getenv("DF_WGRAD_BLOCKS") ? atoi(getenv("DF_WGRAD_BLOCKS")) : 1024;
+  int64_t splits = (target + tiles - 1) / tiles;
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;
   // make every split non-empty

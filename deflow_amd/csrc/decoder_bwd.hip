@@ -258,6 +258,127 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
         red[o] + red[416 + o] + red[832 + o] + red[1248 + o];
 }
 
+// ------------------------------------------------------------------------------ LinearDecoder bwd ---
+// [REF decoder.py:72-120] differentiated: flow = W2 gelu(W1 [before | after | offset_enc(128)] + b1) + b2.  Recomputes the
+// gather and the hidden layer (cheaper than saving them), writes [v | xenc] rows for the W1 weight-gradient GEMM.
+struct LinBwdParams {
+  df_img before, after;
+  const int32_t* coords;
+  const float* offs;
+  const int32_t* counts;
+  const float* dflow;
+  int N;
+  const float *w_off, *b_off, *w_1, *b_1, *w_2, *wt_1;  // wt_1 = W1^T [256,32]
+  float *vx, *dh0, *dxe, *dpre1, *hid;
+};
+constexpr int BS_L = 256 * LDB;
+
+__global__ __launch_bounds__(256) void linear_bwd_kernel(LinBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Bs = lds;                 // [2][256][36]
+  float* As = lds + 2 * BS_L;      // [4][16][LDA_B]
+  const int b = blockIdx.y;
+  const int cnt = p.counts[b];
+  const int p0 = blockIdx.x * 64;
+  if (p0 >= cnt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  float* Aw = As + wave * 16 * LDA_B;
+  const int wp0 = p0 + wave * 16;
+  const int64_t grow0 = (int64_t)b * p.N + wp0;
+  const float* a_lane = Aw + li * LDA_B + lq * 4;
+  Stager stg;
+  int par = 0;
+  stage_load<32>(stg, p.w_1, 256, 0);
+  {
+    const float* bp = reinterpret_cast<const float*>(p.before.ptr) + df_img_base(p.before, b);
+    const float* ap = reinterpret_cast<const float*>(p.after.ptr) + df_img_base(p.after, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = lane + 64 * j;
+      const int pt = f >> 5, c4 = f & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wp0 + pt < cnt) {
+        const int32_t* cc = p.coords + (grow0 + pt) * 3;
+        const int64_t cell = (int64_t)cc[1] * p.before.w + cc[2];
+        v = (c4 < 16) ? ld4(bp + cell * p.before.ld + c4 * 4) : ld4(ap + cell * p.after.ld + (c4 - 16) * 4);
+      }
+      st4(Aw + pt * LDA_B + c4 * 4, v);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int o = lane + 64 * half;
+      const float w0 = p.w_off[o * 3 + 0], w1 = p.w_off[o * 3 + 1], w2 = p.w_off[o * 3 + 2], bo = p.b_off[o];
+      for (int pt = 0; pt < 16; ++pt) {
+        float x = 0.f;
+        if (wp0 + pt < cnt) {
+          const float* of = p.offs + (grow0 + pt) * 3;
+          x = fmaf(w2, of[2], fmaf(w1, of[1], fmaf(w0, of[0], bo)));
+        }
+        Aw[pt * LDA_B + 128 + o] = x;
+      }
+    }
+  }
+  stage_store<32>(stg, Bs);
+  __syncthreads();
+  // [v | xenc] rows -> global (coalesced) for dW1 = dpre1^T [v | xenc]
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int f = lane + 64 * j;
+    const int pt = f >> 6, c4 = f & 63;
+    if (wp0 + pt < cnt) st4(p.vx + (grow0 + pt) * 256 + c4 * 4, ld4(Aw + pt * LDA_B + c4 * 4));
+  }
+  f32x4 pre1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float bia = p.b_1[16 * t + li];
+    pre1[t] = f32x4{bia, bia, bia, bia};
+  }
+  gemm_stream<32, 256, BS_L>(p.w_1, 256, 8, p.wt_1, 32, a_lane, Bs, par, pre1, stg);
+  {
+    float df[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) df[r][o] = (wp0 + 4 * lq + r < cnt) ? p.dflow[(grow0 + 4 * lq + r) * 3 + o] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = 16 * t + li;
+      const float w20 = p.w_2[0 * 32 + col], w21 = p.w_2[1 * 32 + col], w22 = p.w_2[2 * 32 + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pre = pre1[t][r];
+        const float dp = (df[r][0] * w20 + df[r][1] * w21 + df[r][2] * w22) * df_gelu_grad(pre);
+        if (wp0 + 4 * lq + r < cnt) {
+          p.hid[(grow0 + 4 * lq + r) * 32 + col] = df_gelu(pre);
+          p.dpre1[(grow0 + 4 * lq + r) * 32 + col] = dp;
+        }
+        Aw[(4 * lq + r) * LDA_B + col] = dp;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_stream<256, 32, BS_L>(p.wt_1, 32, 1, nullptr, 0, a_lane, Bs, par, acc, stg);
+  // d[v | xenc] -> LDS (C layout -> rows) -> global
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Aw[(4 * lq + r) * LDA_B + 16 * t + li] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int f = lane + 64 * j;
+    const int pt = f >> 5, c4 = f & 31;
+    if (wp0 + pt < cnt) {
+      st4(p.dh0 + (grow0 + pt) * 128 + c4 * 4, ld4(Aw + pt * LDA_B + c4 * 4));
+      st4(p.dxe + (grow0 + pt) * 128 + c4 * 4, ld4(Aw + pt * LDA_B + 128 + c4 * 4));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ gather bwd ---
 __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ dh0,
                                                          const uint32_t* __restrict__ idx_sorted,
@@ -374,6 +495,35 @@ extern "C" int df_small_outer(const float* a, int lda, int na, const float* b, i
   const int64_t rpb = (rows + nblk - 1) / nblk;
   hipLaunchKernelGGL(small_outer_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, lda, na, b,
                      ldb, nb, counts, rows_per_seg, nseg, rows, rpb, partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_linear_decoder_bwd(df_img before, df_img after, const int32_t* coords, const float* offs,
+                                     const int32_t* counts, const float* dflow, int B, int N, const float* w_off,
+                                     const float* b_off, const float* w_1, const float* b_1, const float* w_2,
+                                     const float* wt_1, float* vx, float* dh0, float* dxe, float* dpre1, float* hid,
+                                     void* stream) {
+  DF_REQUIRE(before.ptr && after.ptr && coords && offs && counts && dflow && w_off && b_off && w_1 && b_1 && w_2 && wt_1 &&
+                 vx && dh0 && dxe && dpre1 && hid && B > 0 && N > 0,
+             DF_E_ARG);
+  DF_REQUIRE(before.n == B && after.n == B && before.c == 64 && after.c == 64 && before.h == after.h && before.w == after.w,
+             DF_E_SHAPE);
+  DF_REQUIRE(df_aligned16(w_1) && df_aligned16(wt_1) && df_aligned16(vx) && df_aligned16(dh0) && df_aligned16(dxe), DF_E_ALIGN);
+  LinBwdParams p;
+  p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts; p.dflow = dflow; p.N = N;
+  p.w_off = w_off; p.b_off = b_off; p.w_1 = w_1; p.b_1 = b_1; p.w_2 = w_2; p.wt_1 = wt_1;
+  p.vx = vx; p.dh0 = dh0; p.dxe = dxe; p.dpre1 = dpre1; p.hid = hid;
+  const size_t lds_bytes = (size_t)(2 * BS_L + 4 * 16 * LDA_B) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -115,7 +115,7 @@ class ConvGRUDecoder(nn.Module):
         return flow, sv
 
     def run_backward(self, dflow: torch.Tensor, ps: PointSet, sv: torch.Tensor, dbefore: DfImg, dafter: DfImg,
-                     acc_before: bool, acc_after: bool, grads: dict):
+                     acc_before: bool, acc_after: bool, grads: dict, before: DfImg = None, after: DfImg = None):
         B, N, _ = ps.coords.shape
         dev, T, s = dflow.device, self.num_iters, stream()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -214,7 +214,7 @@ class LinearDecoder(nn.Module):
         self.decoder = nn.Sequential(nn.Linear(pseudoimage_channels * 4, 32), nn.GELU(), nn.Linear(32, 3))
 
     def run(self, before: DfImg, after: DfImg, ps: PointSet, save: bool = False):
-        assert not save, "LinearDecoder backward is not implemented yet (fastflow3d training is a 'next' row)"
+        """-> flow [B,N,3], None (the backward recomputes the gather and the hidden layer instead of saving them)"""
         B, N, _ = ps.coords.shape
         flow = torch.empty(B, N, 3, dtype=torch.float32, device=ps.coords.device)
         d = self.decoder
@@ -223,12 +223,51 @@ class LinearDecoder(nn.Module):
              ptr(d[0].bias.detach()), ptr(d[2].weight.detach()), ptr(d[2].bias.detach()), ptr(flow), stream())
         return flow, None
 
+    def run_backward(self, dflow: torch.Tensor, ps: PointSet, sv, dbefore: DfImg, dafter: DfImg, acc_before: bool,
+                     acc_after: bool, grads: dict, before: DfImg = None, after: DfImg = None):
+        B, N, _ = ps.coords.shape
+        dev, s = dflow.device, stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        BN = B * N
+        d = self.decoder
+        w1 = d[0].weight.detach()
+        wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 256)).view(256, 32)
+        vx, dh0, dxe = torch.empty(BN, 256, **f32), torch.empty(BN, 128, **f32), torch.empty(BN, 128, **f32)
+        dpre1, hid = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32)
+        dflow = dflow.contiguous()
+        call("df_linear_decoder_bwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), ptr(dflow), B, N,
+             ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(w1),
+             ptr(d[0].bias.detach()), ptr(d[2].weight.detach()), ptr(wt_1), ptr(vx), ptr(dh0), ptr(dxe), ptr(dpre1),
+             ptr(hid), s)
+        ncell = dbefore.h * dbefore.w
+        call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
+             int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
+        # dW1^T [256,32] = vx^T dpre1 (row GEMM with the validity mask), then transpose back
+        rows = lambda t, c: DfImg(t.data_ptr(), 1, 1, BN, c, c, 1, BN * c, 0)
+        dW1t = torch.empty(256, 32, **f32)
+        ops.conv2d_wgrad(rows(dpre1, 32), rows(vx, 256), 1, 1, dW1t, ld_co=32, row_counts=ps.counts, rows_per_seg=N)
+        grads[d[0].weight] = ops.weight_transpose(dW1t.view(256, 1, 1, 32)).view(32, 256)
+        so = lambda a, lda, na, b, ldb, nb: ops.small_outer(a, lda, na, b, ldb, nb, ps.counts, N, B, BN)
+        grads[d[0].bias] = so(dpre1, 32, 32, None, 0, 1).view(32)
+        dfl = dflow.view(BN, 3)
+        grads[d[2].weight] = so(dfl, 3, 3, hid, 32, 32)
+        grads[d[2].bias] = so(dfl, 3, 3, None, 0, 1).view(3)
+        offs = ps.offs.view(BN, 3)
+        grads[self.offset_encoder.weight] = torch.cat([so(dxe, 128, 64, offs, 3, 3), so(dxe[:, 64:], 128, 64, offs, 3, 3)], 0)
+        grads[self.offset_encoder.bias] = so(dxe, 128, 128, None, 0, 1).view(128)
+
     def forward(self, before_pseudoimages, after_pseudoimages, voxelizer_infos):
+        from .autograd import GruHeadFn
         H, W = before_pseudoimages.shape[2:]
-        ps = pack_infos(voxelizer_infos, H, W, before_pseudoimages.device, False)
+        need_bwd = torch.is_grad_enabled() and (before_pseudoimages.requires_grad or after_pseudoimages.requires_grad or
+                                                any(p.requires_grad for p in self.parameters()))
+        ps = pack_infos(voxelizer_infos, H, W, before_pseudoimages.device, need_bwd)
         ns = [int(i["voxel_coords"].shape[0]) for i in voxelizer_infos]
-        bh = before_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
-        ah = after_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
-        with torch.no_grad():
-            flow, _ = self.run(img(bh), img(ah), ps, False)
+        if need_bwd:
+            flow = GruHeadFn.apply(self, ps, before_pseudoimages, after_pseudoimages, *self.parameters())
+        else:
+            bh = before_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
+            ah = after_pseudoimages.detach().permute(0, 2, 3, 1).contiguous()
+            with torch.no_grad():
+                flow, _ = self.run(img(bh), img(ah), ps, False)
         return [flow[b, :n] for b, n in enumerate(ns)]

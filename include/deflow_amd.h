@@ -191,6 +191,15 @@ int df_linear_decoder_fwd(df_img before, df_img after, const int32_t* coords, co
                           const float* w_1, const float* b_1, const float* w_2, const float* b_2,
                           float* flow, void* stream);
 
+/* LinearDecoder backward data pass (recomputes gather + hidden layer).  wt_1 = W1^T [256,32].  Writes
+ * vx [B*N,256] = [before|after|offset_enc] rows, dh0 [B*N,128], dxe [B*N,128] (grad of the offset encoding),
+ * dpre1 [B*N,32], hid [B*N,32]; weight gradients follow with df_conv2d_wgrad / df_small_outer, image gradients
+ * with df_gather_bwd. */
+int df_linear_decoder_bwd(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
+                          const float* dflow, int B, int N, const float* w_off, const float* b_off, const float* w_1,
+                          const float* b_1, const float* w_2, const float* wt_1, float* vx, float* dh0, float* dxe,
+                          float* dpre1, float* hid, void* stream);
+
 /* ------------------------------------------------------------ ego motion + loss --------*/
 /* [REF deflow.py:60-77]: pc0' = pc0 R^T + t ; pose_flow = pc0' - pc0.  T [B,4,4] row-major. */
 int df_ego_transform(const float* pc0, const float* T, int B, int N, float* pc0_t, float* pose_flow, void* stream);

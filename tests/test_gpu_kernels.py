@@ -291,9 +291,16 @@ def test_linear_decoder_golden(dev, golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "g3_lineardecoder.npz")))
     m = _load_head(LinearDecoder, g, dev)
     infos = [{"voxel_coords": torch.from_numpy(g[f"vc{i}"]), "point_offsets": torch.from_numpy(g[f"off{i}"])} for i in range(2)]
-    flows = m(torch.from_numpy(g["before"]).to(dev), torch.from_numpy(g["after"]).to(dev), infos)
+    before = torch.from_numpy(g["before"]).to(dev).requires_grad_(True)
+    after = torch.from_numpy(g["after"]).to(dev).requires_grad_(True)
+    flows = m(before, after, infos)
     for i, f in enumerate(flows):
         check(f"linear flow{i}", f, torch.from_numpy(g[f"flow{i}"]))
+    sum((f * torch.from_numpy(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows)).backward()
+    check("linear d(before)", before.grad, torch.from_numpy(g["gbefore"]), tol=5e-4)
+    check("linear d(after)", after.grad, torch.from_numpy(g["gafter"]), tol=5e-4)
+    for k, p in m.named_parameters():
+        check(f"linear grad {k}", p.grad, torch.from_numpy(g["gw." + k]), tol=5e-4)
 
 
 # ---------------------------------------------------------------------------- misc ----------------

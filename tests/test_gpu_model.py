@@ -112,6 +112,26 @@ def test_train_step_vs_oracle(dev):
     print(f"[parity] worst parameter-gradient rel err: {worst:.3e}")
 
 
+def test_fastflow3d_train_step_vs_oracle(dev):
+    """decoder_option=linear (the fastflow3d head): training step gradients vs the oracle"""
+    from oracle import ref_torch as O
+    ref, mine = build_pair(dev, 4, decoder_option="linear")
+    ref.train(); mine.train()
+    batch = make_batch(2, 1200, 400)
+    loss_r = O.training_loss(ref(batch), batch)
+    loss_r.backward()
+    bd = to_dev(batch, dev)
+    loss_m = O.training_loss(mine(bd), bd)
+    check("linear-head loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    loss_m.backward()
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        if k.endswith("conv.bias") and "encoder_step" in k:
+            continue
+        e = rel_err(p.grad, pr[k].grad)
+        assert e <= 2e-3, (k, e)
+
+
 def test_fused_loss_path_matches_list_path(dev):
     """the padded fast path (DeflowLossFn on last_state) == the drop-in list path"""
     from deflow_amd.autograd import DeflowLossFn
