@@ -32,3 +32,25 @@ flops = 0.9 * B * N * (4 * 3 * 2 * 192 * 128 + 2 * 192 * 32)
 t_inf = timeit(lambda: head.run(img(before), img(after), ps, False))
 t_trn = timeit(lambda: head.run(img(before), img(after), ps, True))
 print(f"gru fwd inference {t_inf:.2f} ms ({flops / t_inf / 1e9:.1f} TF/s)   training(save) {t_trn:.2f} ms ({flops / t_trn / 1e9:.1f} TF/s)")
+
+# backward data pass alone (needs a forward save each time because it overwrites planes; time fwd+bwd and subtract)
+def fwd_bwd():
+    flow, sv = head.run(img(before), img(after), ps, True)
+    f32 = dict(dtype=torch.float32, device=dev)
+    BN = B * N
+    from deflow_amd import ops
+    from deflow_amd._lib import DfGruWeightsT, call, ptr, stream
+    W, keep = head._weights()
+    w_zr, b_zr, w_q = keep
+    w1 = head.decoder[0].weight.detach()
+    wt_zr = ops.weight_transpose(w_zr.view(256, 1, 1, 192)).view(192, 256)
+    wt_q = ops.weight_transpose(w_q.view(128, 1, 1, 192)).view(192, 128)
+    wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
+    WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
+    dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
+    dpre1, hid, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
+    bp = torch.zeros(B * ((N + 63) // 64), 416, **f32)
+    call("df_gru_decoder_bwd", ptr(flow), ptr(ps.offs), ptr(ps.counts), B, N, 4, W, WT, ptr(sv), ptr(dh0), ptr(dx),
+         ptr(dpre1), ptr(hid), ptr(xbuf), ptr(bp), stream())
+t_fb = timeit(fwd_bwd, 4)
+print(f"gru fwd(train)+bwd data pass {t_fb:.2f} ms -> bwd ~ {t_fb - t_trn:.2f} ms (DF_GRU_DBG={os.environ.get('DF_GRU_DBG', '0')})")
