@@ -425,20 +425,27 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
     if (st + 1 < nst) load_stage(buf ^ 1);   // buf^1 was last read in stage st-1; every wave has passed that barrier
     const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
     const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
+    // fragments double-buffered in registers: the ds_read_b128s of k-group g+1 are issued before the MFMAs of group g
+    f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDT + rslot[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDT + rslot[0]);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      f32x4 af[TM], bf[TN];
+      if (g + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ld4(a + i * 32 * LDT + rslot[g]);
+        for (int i = 0; i < TM; ++i) af[(g + 1) & 1][i] = ld4(a + i * 32 * LDT + rslot[g + 1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = ld4(b + j * 32 * LDT + rslot[g]);
+        for (int j = 0; j < TN; ++j) bf[(g + 1) & 1][j] = ld4(b + j * 32 * LDT + rslot[g + 1]);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for the next stage has landed
     __syncthreads();                                     // ... and everyone's
