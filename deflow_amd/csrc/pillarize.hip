@@ -197,6 +197,20 @@ __device__ __forceinline__ void pfn_linear(const PfnCtx& c, const float (&f)[9],
 
 constexpr int CELLS_PER_BLOCK = 32;
 
+// Sparse iteration: the feature-net kernels visit OCCUPIED pillars only.  The sorted key array is globally ordered by
+// b * H * W + cell, so sample b owns sorted positions [off, off + cnt) with off = sum of counts[0..b); a position whose
+// key differs from its predecessor's is a pillar head, and its run is [i, cell_rng[key].end).
+struct SampleRange {
+  int off, cnt;
+};
+__device__ __forceinline__ SampleRange sample_range(const int32_t* __restrict__ counts, int b) {
+  SampleRange r;
+  r.off = 0;
+  for (int k = 0; k < b; ++k) r.off += counts[k];
+  r.cnt = counts[b];
+  return r;
+}
+
 // reduce NV floats per lane across the 32 cell groups of a block (lanes with equal `sub`)
 template <int NV>
 __device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*NV]*/) {
@@ -213,7 +227,8 @@ __device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*
 
 __global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict__ pts,
                                                         const uint32_t* __restrict__ idx_sorted,
-                                                        const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                        const int32_t* __restrict__ cell_rng,
+    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                         const float* __restrict__ w_pfn, float* __restrict__ partial) {
   __shared__ float lds[256 * 8];
   const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
@@ -221,8 +236,12 @@ __global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict_
   PfnCtx c;
   pfn_load_w(c, w_pfn, sub);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
-    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+  const SampleRange sr = sample_range(counts, b);
+  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
+    const uint32_t key = key_sorted[i0];
+    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
+    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
     pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
@@ -297,7 +316,8 @@ __global__ void pfn_bn_finalize_kernel(const float* __restrict__ partial, int B,
 
 __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict__ pts,
                                                          const uint32_t* __restrict__ idx_sorted,
-                                                         const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                         const int32_t* __restrict__ cell_rng,
+    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                          const float* __restrict__ w_pfn,
                                                          const float* __restrict__ bn_ss, int bn_sample_stride,
                                                          int mode, df_img out) {
@@ -307,10 +327,14 @@ __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict
   pfn_load_w(c, w_pfn, sub);
   pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
   float* __restrict__ op = reinterpret_cast<float*>(out.ptr) + df_img_base(out, b);
-  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
-    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+  const SampleRange sr = sample_range(counts, b);
+  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
+    const uint32_t key = key_sorted[i0];
+    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
+    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (e > s) {
+    {
       float mx, my, mz, ctx, cty, ctz;
       pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
       pfn_centre(g, cell, ctx, cty, ctz);
@@ -338,7 +362,8 @@ __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict
 // backward pass A: per-sample sums of (g_hat, g_hat * xhat) where g_hat = dL/d(BN output) after the ReLU mask
 __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restrict__ pts,
                                                             const uint32_t* __restrict__ idx_sorted,
-                                                            const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                            const int32_t* __restrict__ cell_rng,
+    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                             const float* __restrict__ w_pfn,
                                                             const float* __restrict__ bn_ss, int bn_sample_stride,
                                                             df_img gout, float* __restrict__ partial) {
@@ -350,8 +375,12 @@ __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restr
   pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
   const float* __restrict__ gp = reinterpret_cast<const float*>(gout.ptr) + df_img_base(gout, b);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
-    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+  const SampleRange sr = sample_range(counts, b);
+  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
+    const uint32_t key = key_sorted[i0];
+    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
+    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
     pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
@@ -419,7 +448,8 @@ __global__ void pfn_bwd_finalize_kernel(const float* __restrict__ partial, int B
 // backward pass B: dW[32][9] partial sums of du (x) f
 __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __restrict__ pts,
                                                               const uint32_t* __restrict__ idx_sorted,
-                                                              const int32_t* __restrict__ cell_rng, df_pillar_geom g,
+                                                              const int32_t* __restrict__ cell_rng,
+    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                               const float* __restrict__ w_pfn,
                                                               const float* __restrict__ bn_ss, int bn_sample_stride,
                                                               const float* __restrict__ coef, df_img gout,
@@ -440,8 +470,12 @@ __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __res
   float acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.f;
-  for (int cell = blockIdx.x * CELLS_PER_BLOCK + grp; cell < ncell; cell += gridDim.x * CELLS_PER_BLOCK) {
-    const int s = cell_rng[2 * ((int64_t)b * ncell + cell)], e = cell_rng[2 * ((int64_t)b * ncell + cell) + 1];
+  const SampleRange sr = sample_range(counts, b);
+  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
+    const uint32_t key = key_sorted[i0];
+    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
+    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
     pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
@@ -545,11 +579,12 @@ extern "C" int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t nc
   return DF_OK;
 }
 
-extern "C" int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+extern "C" int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+    const int32_t* counts, int B,
                             df_pillar_geom g, const float* w_pfn, float* partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
+  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
   hipLaunchKernelGGL(pfn_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, g, w_pfn, partial);
+                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -564,27 +599,29 @@ extern "C" int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, co
   return DF_OK;
 }
 
-extern "C" int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+extern "C" int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+    const int32_t* counts, int B,
                              df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode,
                              df_img out, int nblk, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
+  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
   DF_REQUIRE(out.n == B && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr),
              DF_E_SHAPE);
   DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
   hipLaunchKernelGGL(pfn_canvas_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
+                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
 
-extern "C" int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+extern "C" int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+    const int32_t* counts, int B,
                                 df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
                                 df_img gout, float* partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
+  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
              DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
   hipLaunchKernelGGL(pfn_bwd_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
+                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -598,15 +635,16 @@ extern "C" int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, c
   return DF_OK;
 }
 
-extern "C" int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, int B,
+extern "C" int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+    const int32_t* counts, int B,
                                   df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
                                   const float* coef, df_img gout, float* dw_partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
+  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
                  geom_ok(g),
              DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
   hipLaunchKernelGGL(pfn_bwd_weights_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     pts, idx_sorted, cell_rng, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
+                     pts, idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

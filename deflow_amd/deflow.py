@@ -56,7 +56,7 @@ class DeFlow(nn.Module):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device
-        bstar = torch.empty(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)
+        bstar = torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)  # streaming zero-fill; pillars overwrite
         self.timer[1].start("Voxelization")
         p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train)
         p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train)

@@ -37,6 +37,7 @@ class PillarState:
     cpos: torch.Tensor         # [B*N] i32 original -> compact
     idx_sorted: torch.Tensor   # [B*N] u32 (as i32) original flat index, sorted by cell
     cell_rng: torch.Tensor     # [B*H*W,2] i32
+    key_sorted: torch.Tensor   # [B*N] u32 (as i32) sorted cell keys
     bn_ss: torch.Tensor        # [B or 1,4,32]
     bn_stride: int             # 128 (per-sample stats) or 0
 
@@ -74,7 +75,7 @@ class DynamicEmbedder(nn.Module):
 
     # -- engine ------------------------------------------------------------------------------
     def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
-        """pts [B,N,3] f32 contiguous on the GPU; writes the [B,H,W,32] canvas described by `out`."""
+        """pts [B,N,3] f32 contiguous on the GPU; writes the occupied cells of the ZERO-FILLED [B,H,W,32] canvas `out`."""
         assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
         B, N, _ = pts.shape
         dev, g, s = pts.device, self.geom, stream()
@@ -106,9 +107,9 @@ class DynamicEmbedder(nn.Module):
         w = self._lin.weight.detach()
         bn = self._bn
         if train:
-            nbs = max(1, min(256, (H * W) // 32))
+            nbs = max(1, min(256, (N + 31) // 32))
             partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
-            call("df_pfn_stats", ptr(pts), ptr(idx_sorted), ptr(cell_rng), B, g, ptr(w), ptr(partial), nbs, s)
+            call("df_pfn_stats", ptr(pts), ptr(idx_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
             bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
             call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                  bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
@@ -119,10 +120,10 @@ class DynamicEmbedder(nn.Module):
             scale = bn.weight.detach() * invstd
             bn_ss = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
             bn_stride = 0
-        nbc = max(1, min(2048, (H * W) // 32))
-        call("df_pfn_canvas", ptr(pts), ptr(idx_sorted), ptr(cell_rng), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
+        nbc = max(1, min(2048, (N + 31) // 32))
+        call("df_pfn_canvas", ptr(pts), ptr(idx_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
              out, nbc, s)
-        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, bn_ss, bn_stride)
+        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, bn_ss, bn_stride)
 
     def pillarize_bwd(self, st: PillarState, gout: DfImg, grads: Optional[Tuple[torch.Tensor, ...]]):
         """Accumulates (dW [32,9], dgamma [32], dbeta [32]) for one cloud set; grads=None starts from zero."""
@@ -130,19 +131,19 @@ class DynamicEmbedder(nn.Module):
         B, N, _ = st.pts.shape
         dev, g, s = st.pts.device, self.geom, stream()
         w = self._lin.weight.detach()
-        nbs = max(1, min(256, (self.H * self.W) // 32))
+        nbs = max(1, min(256, (N + 31) // 32))
         acc = grads is not None
         if grads is None:
             grads = (torch.empty(32, 9, dtype=torch.float32, device=dev), torch.empty(32, dtype=torch.float32, device=dev),
                      torch.empty(32, dtype=torch.float32, device=dev))
         dW, dgamma, dbeta = grads
         partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
-        call("df_pfn_bwd_stats", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), B, g, ptr(w), ptr(st.bn_ss),
+        call("df_pfn_bwd_stats", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, gout, ptr(partial), nbs, s)
         coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
         dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
-        call("df_pfn_bwd_weights", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), B, g, ptr(w), ptr(st.bn_ss),
+        call("df_pfn_bwd_weights", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, ptr(coef), gout, ptr(dwp), nbs, s)
         call("df_colsum_finalize", ptr(dwp), B * nbs, 288, 1, ptr(dW), int(acc), s)
         return grads
@@ -156,7 +157,7 @@ class DynamicEmbedder(nn.Module):
     def forward(self, points: torch.Tensor):
         pts = points.contiguous().float()
         B = pts.shape[0]
-        canvas = torch.empty(B, self.H, self.W, 32, dtype=torch.float32, device=pts.device)
+        canvas = torch.zeros(B, self.H, self.W, 32, dtype=torch.float32, device=pts.device)
         with torch.no_grad():
             st = self.pillarize(pts, img(canvas), self.training)
         infos = self.infos_from_state(st, st.counts.tolist())

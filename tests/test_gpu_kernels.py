@@ -247,7 +247,7 @@ def test_pillarize_backward(dev):
     out, _ = ref(pts)
     gout = torch.randn(out.shape)
     out.backward(gout)
-    canvas = torch.empty(2, 64, 64, 32, device=dev)
+    canvas = torch.zeros(2, 64, 64, 32, device=dev)
     st = mine.pillarize(pts.to(dev), img(canvas), True)
     dW, dgamma, dbeta = mine.pillarize_bwd(st, img(nhwc(gout).to(dev)), None)
     lin, bn = ref.feature_net.pfn_layers[0][0], ref.feature_net.pfn_layers[0][1]
