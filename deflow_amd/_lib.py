@@ -44,13 +44,14 @@ _SIGS = {
     "df_pillar_compact": [P, P, P, I, I, DfGeom, P, P, P, P, P, P],
     "df_pillar_sort_ws_bytes": [L],
     "df_pillar_sort": [P, P, P, L, I, P, L, P],
+    "df_pillar_gather_sorted": [P, P, P, L, L, P, P],
     "df_pillar_cells": [P, L, L, P, P],
-    "df_pfn_stats": [P, P, P, P, P, I, DfGeom, P, P, I, P],
+    "df_pfn_stats": [P, P, P, P, I, DfGeom, P, P, I, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
-    "df_pfn_canvas": [P, P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
-    "df_pfn_bwd_stats": [P, P, P, P, P, I, DfGeom, P, P, I, DfImg, P, I, P],
+    "df_pfn_canvas": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
+    "df_pfn_bwd_stats": [P, P, P, P, I, DfGeom, P, P, I, DfImg, P, I, P],
     "df_pfn_bwd_finalize": [P, I, I, P, P, P, I, P, P],
-    "df_pfn_bwd_weights": [P, P, P, P, P, I, DfGeom, P, P, I, P, DfImg, P, I, P],
+    "df_pfn_bwd_weights": [P, P, P, P, I, DfGeom, P, P, I, P, DfImg, P, I, P],
     "df_conv2d": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_tile_m": [L, I],
     "df_conv2d_variant": [L, L, I, I],

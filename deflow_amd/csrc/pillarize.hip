@@ -126,6 +126,16 @@ __global__ void iota_kernel(uint32_t* p, int64_t n) {
   if (i < n) p[i] = (uint32_t)i;
 }
 
+__global__ void pillar_gather_sorted_kernel(const float* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
+                                            const uint32_t* __restrict__ key_sorted, uint32_t invalid_key, int64_t n,
+                                            float* __restrict__ pts_sorted) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || key_sorted[i] >= invalid_key) return;  // dropped points sort to the tail and are never read
+  const float* p = pts + (int64_t)idx_sorted[i] * 3;
+  float* o = pts_sorted + i * 3;
+  o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
 __global__ void pillar_cells_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t ncells,
                                     int32_t* __restrict__ cell_rng) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,11 +175,10 @@ __device__ __forceinline__ void pfn_centre(const df_pillar_geom& g, int cell, fl
   cty = __fadd_rn(__fmul_rn((float)cy, g.vy), g.offy);
   ctz = __fadd_rn(0.f, g.offz);
 }
-__device__ __forceinline__ void pfn_mean(const float* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
-                                         int s, int e, float& mx, float& my, float& mz) {
+__device__ __forceinline__ void pfn_mean(const float* __restrict__ pts, int s, int e, float& mx, float& my, float& mz) {
   float sx = 0.f, sy = 0.f, sz = 0.f;
   for (int i = s; i < e; ++i) {
-    const float* p = pts + (int64_t)idx_sorted[i] * 3;
+    const float* p = pts + (int64_t)i * 3;
     sx += p[0];
     sy += p[1];
     sz += p[2];
@@ -226,7 +235,6 @@ __device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*
 }
 
 __global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict__ pts,
-                                                        const uint32_t* __restrict__ idx_sorted,
                                                         const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                         const float* __restrict__ w_pfn, float* __restrict__ partial) {
@@ -244,11 +252,11 @@ __global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict_
     const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
-    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_mean(pts, s, e, mx, my, mz);
     pfn_centre(g, cell, ctx, cty, ctz);
     for (int i = s; i < e; ++i) {
       float f[9], u[4];
-      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
       pfn_linear(c, f, u);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -315,7 +323,6 @@ __global__ void pfn_bn_finalize_kernel(const float* __restrict__ partial, int B,
 }
 
 __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict__ pts,
-                                                         const uint32_t* __restrict__ idx_sorted,
                                                          const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                          const float* __restrict__ w_pfn,
@@ -336,11 +343,11 @@ __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     {
       float mx, my, mz, ctx, cty, ctz;
-      pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+      pfn_mean(pts, s, e, mx, my, mz);
       pfn_centre(g, cell, ctx, cty, ctz);
       for (int i = s; i < e; ++i) {
         float f[9], u[4];
-        pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+        pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
         pfn_linear(c, f, u);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -361,7 +368,6 @@ __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict
 
 // backward pass A: per-sample sums of (g_hat, g_hat * xhat) where g_hat = dL/d(BN output) after the ReLU mask
 __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restrict__ pts,
-                                                            const uint32_t* __restrict__ idx_sorted,
                                                             const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                             const float* __restrict__ w_pfn,
@@ -383,13 +389,13 @@ __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restr
     const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
-    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_mean(pts, s, e, mx, my, mz);
     pfn_centre(g, cell, ctx, cty, ctz);
     const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
     const float inv = 1.f / (float)(e - s);
     for (int i = s; i < e; ++i) {
       float f[9], u[4];
-      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
       pfn_linear(c, f, u);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -447,7 +453,6 @@ __global__ void pfn_bwd_finalize_kernel(const float* __restrict__ partial, int B
 
 // backward pass B: dW[32][9] partial sums of du (x) f
 __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __restrict__ pts,
-                                                              const uint32_t* __restrict__ idx_sorted,
                                                               const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
                                                               const float* __restrict__ w_pfn,
@@ -478,13 +483,13 @@ __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __res
     const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
     if (e <= s) continue;
     float mx, my, mz, ctx, cty, ctz;
-    pfn_mean(pts, idx_sorted, s, e, mx, my, mz);
+    pfn_mean(pts, s, e, mx, my, mz);
     pfn_centre(g, cell, ctx, cty, ctz);
     const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
     const float inv = 1.f / (float)(e - s);
     for (int i = s; i < e; ++i) {
       float f[9], u[4];
-      pfn_feat(pts + (int64_t)idx_sorted[i] * 3, mx, my, mz, ctx, cty, ctz, f);
+      pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
       pfn_linear(c, f, u);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -571,6 +576,15 @@ extern "C" int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_
   return (int)e;
 }
 
+extern "C" int df_pillar_gather_sorted(const float* pts, const uint32_t* idx_sorted, const uint32_t* key_sorted,
+                                       int64_t n, int64_t ncells, float* pts_sorted, void* stream) {
+  DF_REQUIRE(pts && idx_sorted && key_sorted && pts_sorted && n > 0 && ncells > 0 && ncells < 0x7fffffffll, DF_E_ARG);
+  hipLaunchKernelGGL(pillar_gather_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), pts, idx_sorted, key_sorted, (uint32_t)ncells, n, pts_sorted);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 extern "C" int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream) {
   DF_REQUIRE(key_sorted && cell_rng && n > 0 && ncells > 0 && ncells < 0x7fffffffll, DF_E_ARG);
   hipLaunchKernelGGL(pillar_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -579,12 +593,11 @@ extern "C" int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t nc
   return DF_OK;
 }
 
-extern "C" int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+extern "C" int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                             df_pillar_geom g, const float* w_pfn, float* partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
-  hipLaunchKernelGGL(pfn_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, partial);
+  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
+  hipLaunchKernelGGL(pfn_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -599,29 +612,27 @@ extern "C" int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, co
   return DF_OK;
 }
 
-extern "C" int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+extern "C" int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                              df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode,
                              df_img out, int nblk, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
+  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
   DF_REQUIRE(out.n == B && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr),
              DF_E_SHAPE);
   DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
-  hipLaunchKernelGGL(pfn_canvas_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
+  hipLaunchKernelGGL(pfn_canvas_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
 
-extern "C" int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+extern "C" int df_pfn_bwd_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                                 df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
                                 df_img gout, float* partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
+  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
              DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
-  hipLaunchKernelGGL(pfn_bwd_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts,
-                     idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
+  hipLaunchKernelGGL(pfn_bwd_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -635,16 +646,16 @@ extern "C" int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, c
   return DF_OK;
 }
 
-extern "C" int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+extern "C" int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                                   df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
                                   const float* coef, df_img gout, float* dw_partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
+  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
                  geom_ok(g),
              DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
   hipLaunchKernelGGL(pfn_bwd_weights_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     pts, idx_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
+                     pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -38,6 +38,7 @@ class PillarState:
     idx_sorted: torch.Tensor   # [B*N] u32 (as i32) original flat index, sorted by cell
     cell_rng: torch.Tensor     # [B*H*W,2] i32
     key_sorted: torch.Tensor   # [B*N] u32 (as i32) sorted cell keys
+    pts_sorted: torch.Tensor   # [B*N,3] points gathered into sorted order
     bn_ss: torch.Tensor        # [B or 1,4,32]
     bn_stride: int             # 128 (per-sample stats) or 0
 
@@ -102,6 +103,8 @@ class DynamicEmbedder(nn.Module):
         ncells = B * H * W
         call("df_pillar_sort", ptr(key), ptr(key_sorted), ptr(idx_sorted), B * N, max(1, int(ncells).bit_length()),
              ptr(ws), ws_bytes, s)
+        pts_sorted = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
+        call("df_pillar_gather_sorted", ptr(pts), ptr(idx_sorted), ptr(key_sorted), B * N, ncells, ptr(pts_sorted), s)
         cell_rng = torch.zeros(ncells, 2, **i32)
         call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), s)
         w = self._lin.weight.detach()
@@ -109,7 +112,7 @@ class DynamicEmbedder(nn.Module):
         if train:
             nbs = max(1, min(256, (N + 31) // 32))
             partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
-            call("df_pfn_stats", ptr(pts), ptr(idx_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
+            call("df_pfn_stats", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
             bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
             call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                  bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
@@ -121,9 +124,9 @@ class DynamicEmbedder(nn.Module):
             bn_ss = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
             bn_stride = 0
         nbc = max(1, min(2048, (N + 31) // 32))
-        call("df_pfn_canvas", ptr(pts), ptr(idx_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
+        call("df_pfn_canvas", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
              out, nbc, s)
-        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, bn_ss, bn_stride)
+        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss, bn_stride)
 
     def pillarize_bwd(self, st: PillarState, gout: DfImg, grads: Optional[Tuple[torch.Tensor, ...]]):
         """Accumulates (dW [32,9], dgamma [32], dbeta [32]) for one cloud set; grads=None starts from zero."""
@@ -138,12 +141,12 @@ class DynamicEmbedder(nn.Module):
                      torch.empty(32, dtype=torch.float32, device=dev))
         dW, dgamma, dbeta = grads
         partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
-        call("df_pfn_bwd_stats", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
+        call("df_pfn_bwd_stats", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, gout, ptr(partial), nbs, s)
         coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
         dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
-        call("df_pfn_bwd_weights", ptr(st.pts), ptr(st.idx_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
+        call("df_pfn_bwd_weights", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, ptr(coef), gout, ptr(dwp), nbs, s)
         call("df_colsum_finalize", ptr(dwp), B * nbs, 288, 1, ptr(dW), int(acc), s)
         return grads

@@ -64,10 +64,14 @@ int df_pillar_compact(const float* pts, const uint32_t* key, const int32_t* blk_
 int64_t df_pillar_sort_ws_bytes(int64_t n);
 int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_t* idx_out, int64_t n, int key_bits,
                    void* ws, int64_t ws_bytes, void* stream);
+/* step 4b: points gathered into sorted order, pts_sorted[i] = pts[idx_sorted[i]] (rows of dropped points untouched):
+ * the feature-net passes then read one contiguous run per pillar instead of chasing indices. */
+int df_pillar_gather_sorted(const float* pts, const uint32_t* idx_sorted, const uint32_t* key_sorted, int64_t n,
+                            int64_t ncells, float* pts_sorted, void* stream);
 /* step 5: dense per-cell [start,end) table from the sorted keys.  cell_rng [B*gy*gx, 2] i32 must be zeroed. */
 int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream);
 /* step 6 (training): BatchNorm1d batch statistics of u = W f per sample.  partial [B, nblk_stat, 32, 2] f32 */
-int df_pfn_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
                  const float* w_pfn /*[32,9]*/, float* partial, int nblk_stat, void* stream);
 /* finalize: per-sample scale/shift/mean/invstd from the partials, sequential running-stat update (one
@@ -79,19 +83,19 @@ int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, const int32_t
 /* step 7: canvas.  `out` (n=B images, c=32) must be ZERO-FILLED by the caller (a streaming memset); this writes the
  * occupied cells only: the pillar mean (mode 0) / max (mode 1) of ReLU(BN(W f)).  All pfn kernels iterate over occupied
  * pillars (heads of the sorted key runs of sample b = sorted positions [sum counts[0..b), +counts[b])), not over cells.  bn_sample_stride = 128 (per-sample stats) or 0 (shared: eval). */
-int df_pfn_canvas(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
                   const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, df_img out, int nblk,
                   void* stream);
 /* backward (mean mode): pass A partial sums [B,nblk_stat,32,2] of (g_hat, g_hat*xhat); finalize -> dgamma, dbeta,
  * coef [B,2,32] = (S1/M_b, S2/M_b); pass B dW partials [B*nblk_stat,32,9] (sum with df_colsum_finalize). */
-int df_pfn_bwd_stats(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+int df_pfn_bwd_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
                      const float* w_pfn, const float* bn_ss, int bn_sample_stride, df_img gout, float* partial,
                      int nblk_stat, void* stream);
 int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, float* dgamma,
                         float* dbeta, int accumulate, float* coef, void* stream);
-int df_pfn_bwd_weights(const float* pts, const uint32_t* idx_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
+int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
                        const float* w_pfn, const float* bn_ss, int bn_sample_stride, const float* coef, df_img gout,
                        float* dw_partial, int nblk_stat, void* stream);
