@@ -178,7 +178,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   // and the top-left input coordinate.  Invalid rows point at element 0 and are masked at the LDS store.
   const float* arow[RA];
   int ay[RA], ax[RA];
-  unsigned rowok = 0;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
@@ -188,7 +187,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
       int n, oy, ox;
       dec(m, n, oy, ox);
       arow[i] += df_img_base(p.x, n);
-      rowok |= 1u << i;
       if (p.mode == DF_CONV_FWD) {
         ay[i] = oy * p.stride - p.pad;
         ax[i] = ox * p.stride - p.pad;

@@ -6,7 +6,6 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib as L
 from ._lib import DfImg, call, img, img_pair, ptr, stream
 
 CONV_FWD, CONV_DGRAD = 0, 1

@@ -251,3 +251,48 @@ def test_trainer_learns_and_cli_runs(dev, tmp_path):
     m2 = deflow_amd.DeFlow(**SMALL, num_iters=2)
     r = m2.load_from_checkpoint(ck)
     assert not r.missing_keys and not r.unexpected_keys
+
+
+def test_edge_cases_empty_ragged_and_big_grid(dev):
+    """SURVEY 8(c) edge cases: a sample with no valid point, pc0/pc1 padded to different lengths, and the 1024x1024 grid
+    (BASELINE config 5 shape, voxel 0.1 m, 160k points) through the whole engine."""
+    import deflow_amd
+    from oracle import ref_torch as O
+    ref, mine = build_pair(dev, 9, decoder_option="gru", num_iters=2)
+    ref.eval(); mine.eval()
+    batch = make_batch(3, 1500, 600)
+    batch["pc1"] = batch["pc1"][:, :1100].contiguous()          # ragged: N' != N
+    batch["pc0"][1] = float("nan")                               # sample 1: nothing valid in pc0
+    with torch.no_grad():
+        want = ref(batch)
+        got = mine(to_dev(batch, dev))
+    assert got["flow"][1].shape == (0, 3) and got["pc0_valid_point_idxes"][1].numel() == 0
+    for b in (0, 2):
+        assert torch.equal(got["pc0_valid_point_idxes"][b].cpu(), want["pc0_valid_point_idxes"][b])
+        assert torch.equal(got["pc1_valid_point_idxes"][b].cpu(), want["pc1_valid_point_idxes"][b])
+        check(f"ragged flow b{b}", got["flow"][b], want["flow"][b], 1e-4)
+    # 1024 x 1024 grid, 160k points: finite, deterministic, correctly sized
+    torch.manual_seed(0)
+    big = deflow_amd.DeFlow(voxel_size=[0.1, 0.1, 6], grid_feature_size=[1024, 1024], num_iters=8).to(dev).eval()
+    from deflow_amd.synth import synth_pair
+    p = synth_pair(77, 160000)
+    bb = {"pc0": p[0][None].to(dev), "pc1": p[1][None].to(dev), "pose0": torch.eye(4)[None].to(dev),
+          "pose1": torch.linalg.inv(p[2])[None].to(dev)}
+    with torch.no_grad():
+        r1, r2 = big(bb), big(bb)
+    f = r1["flow"][0]
+    assert torch.isfinite(f).all() and f.shape[0] == r1["pc0_valid_point_idxes"][0].numel() > 100000
+    assert torch.equal(f, r2["flow"][0])
+
+
+@pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"}])
+def test_alternate_kernel_paths(env):
+    """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors) and the all-DMA wgrad variants stay correct:
+    re-run the conv / ConvWithNorms / train-step parity tests in a subprocess with the dispatch override"""
+    import subprocess
+    import sys
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_gpu_kernels.py", "tests/test_gpu_model.py",
+                        "-k", "conv or cwn or train_step_vs_oracle", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
