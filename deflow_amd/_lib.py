@@ -70,7 +70,7 @@ _SIGS = {
     "df_upsample2x": [DfImg, DfImg, I, P],
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],
     "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],
-    "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P, P],
+    "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
     "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],
     "df_linear_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, P, P, P, P, P, P, P, P],

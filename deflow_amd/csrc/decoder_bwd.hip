@@ -32,9 +32,8 @@ struct GruBwdParams {
   float* dh0;
   float* dx;
   float* dpre1;
-  float* hid;
   float* xout;
-  float* bias_partial;  // [blocks][416]: column sums of dz_pre, dr_pre, dq_pre (3 x 128) and dpre1 (32)
+  float* bias_partial;  // [blocks][772]: per-workgroup partial sums of all small gradients (layout at the end of the kernel)
 };
 
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
@@ -107,6 +106,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
   __syncthreads();
 
   float sb[3][8], sb1[2] = {0.f, 0.f};
+  float sw2[2][3], sdf[3];  // partials of dW2[o][col] = sum_rows dflow[row][o] hid[row][col] and db2[o]
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -126,18 +126,21 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
 #pragma unroll
       for (int o = 0; o < 3; ++o) df[r][o] = (wp0 + 4 * lq + r < cnt) ? p.dflow[(grow0 + 4 * lq + r) * 3 + o] : 0.f;
 #pragma unroll
+    for (int o = 0; o < 3; ++o) sdf[o] = df[0][o] + df[1][o] + df[2][o] + df[3][o];
+#pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int col = 16 * t + li;
       const float w20 = p.w.w_2[0 * 32 + col], w21 = p.w.w_2[1 * 32 + col], w22 = p.w.w_2[2 * 32 + col];
+      sw2[t][0] = sw2[t][1] = sw2[t][2] = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pre = pre1[t][r];
         const float dhid = df[r][0] * w20 + df[r][1] * w21 + df[r][2] * w22;
         const float dp = dhid * df_gelu_grad(pre);
-        if (wp0 + 4 * lq + r < cnt) {
-          p.hid[(grow0 + 4 * lq + r) * 32 + col] = df_gelu(pre);
-          p.dpre1[(grow0 + 4 * lq + r) * 32 + col] = dp;
-        }
+        const float hv = df_gelu(pre);
+        if (wp0 + 4 * lq + r < cnt) p.dpre1[(grow0 + 4 * lq + r) * 32 + col] = dp;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) sw2[t][o] += df[r][o] * hv;  // df is 0 on invalid rows
         Aw[(4 * lq + r) * LDA_B + col] = dp;  // A operand of the next GEMM (cols 0..31)
         if (r == 0) sb1[t] = dp; else sb1[t] += dp;
       }
@@ -234,8 +237,57 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     const int pt = f >> 4, c4 = f & 15;
     if (wp0 + pt < cnt) st4(p.dx + (grow0 + pt) * 64 + c4 * 4, ld4(Aw + pt * LDA_B + 128 + c4 * 4));
   }
-  // ---- bias-gradient partials (rows beyond cnt contributed exact zeros) --------------------------------
-  float* red = Bs;  // the weight buffers are idle now: [4 waves][416]
+  // ---- per-workgroup partial sums of every small gradient (rows beyond cnt contributed exact zeros) ------
+  // layout (PW columns): [0,384) d b_z|b_r|b_q, [384,416) d b_1, [416,608) dW_off[c][d], [608,672) d b_off[c],
+  // [672,768) dW_2[o][col], [768,771) d b_2[o]
+  constexpr int PW = 772;
+  float* red = Bs;  // the weight buffers are idle now: [4 waves][PW]
+  {
+    float off[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) off[k][d] = (wp0 + 4 * lq + k < cnt) ? p.offs[(grow0 + 4 * lq + k) * 3 + d] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] += dxa[t][k] * off[k][d];
+        v[3] += dxa[t][k];
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        v[d] += __shfl_xor(v[d], 16);
+        v[d] += __shfl_xor(v[d], 32);
+      }
+      if (lq == 0) {
+        const int c = 16 * t + li;
+        red[wave * PW + 416 + c * 3 + 0] = v[0];
+        red[wave * PW + 416 + c * 3 + 1] = v[1];
+        red[wave * PW + 416 + c * 3 + 2] = v[2];
+        red[wave * PW + 608 + c] = v[3];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        float v = sw2[t][o];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) red[wave * PW + 672 + o * 32 + 16 * t + li] = v;
+      }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float v = sdf[o];  // identical on the 16 lanes of a row group: reduce over the 4 row groups only
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane == 0) red[wave * PW + 768 + o] = v;
+    }
+    if (lane == 0) red[wave * PW + 771] = 0.f;
+  }
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -243,19 +295,19 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
       float v = sb[g][t];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (lq == 0) red[wave * 416 + g * 128 + 16 * t + li] = v;
+      if (lq == 0) red[wave * PW + g * 128 + 16 * t + li] = v;
     }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float v = sb1[t];
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (lq == 0) red[wave * 416 + 384 + 16 * t + li] = v;
+    if (lq == 0) red[wave * PW + 384 + 16 * t + li] = v;
   }
   __syncthreads();
-  for (int o = tid; o < 416; o += 256)
-    p.bias_partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 416 + o] =
-        red[o] + red[416 + o] + red[832 + o] + red[1248 + o];
+  for (int o = tid; o < PW; o += 256)
+    p.bias_partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PW + o] =
+        red[o] + red[PW + o] + red[2 * PW + o] + red[3 * PW + o];
 }
 
 // ------------------------------------------------------------------------------ LinearDecoder bwd ---
@@ -445,9 +497,8 @@ __global__ __launch_bounds__(256) void small_outer_kernel(const float* __restric
 
 extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N,
                                   int num_iters, df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0,
-                                  float* dx, float* dpre1, float* hid, float* xout, float* bias_partial,
-                                  void* stream) {
-  DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && hid && xout && bias_partial && B > 0 && N > 0 &&
+                                  float* dx, float* dpre1, float* xout, float* bias_partial, void* stream) {
+  DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && xout && bias_partial && B > 0 && N > 0 &&
                  num_iters >= 1,
              DF_E_ARG);
   DF_REQUIRE(wts.w_off && wts.b_off && wts.w_1 && wts.b_1 && wts.w_2 && wtt.wt_zr && wtt.wt_q && wtt.wt_1, DF_E_ARG);
@@ -458,7 +509,7 @@ extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const i
   p.dflow = dflow; p.offs = offs; p.counts = counts; p.N = N; p.T = num_iters; p.w = wts; p.wt = wtt; p.save = save;
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
-  p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.hid = hid; p.xout = xout; p.bias_partial = bias_partial;
+  p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.xout = xout; p.bias_partial = bias_partial;
   const size_t lds_bytes = (size_t)(2 * BS_B + 4 * 16 * LDA_B) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

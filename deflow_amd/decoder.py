@@ -128,14 +128,14 @@ class ConvGRUDecoder(nn.Module):
         wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
         WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
         dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
-        dpre1, hid, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
+        dpre1, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
         dflow = dflow.contiguous()
         nblocks = B * ((N + 63) // 64)
-        bias_partial = torch.zeros(nblocks, 416, **f32)
+        bias_partial = torch.zeros(nblocks, 772, **f32)
         call("df_gru_decoder_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-             ptr(dpre1), ptr(hid), ptr(xbuf), ptr(bias_partial), s)
-        bias_g = torch.empty(416, **f32)
-        call("df_colsum_finalize", ptr(bias_partial), nblocks, 416, 1, ptr(bias_g), 0, s)
+             ptr(dpre1), ptr(xbuf), ptr(bias_partial), s)
+        bias_g = torch.empty(772, **f32)
+        call("df_colsum_finalize", ptr(bias_partial), nblocks, 772, 1, ptr(bias_g), 0, s)
         # image gradients: per-cell segmented sum (no atomics)
         ncell = dbefore.h * dbefore.w
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
@@ -174,17 +174,14 @@ class ConvGRUDecoder(nn.Module):
         grads[g.convr.weight] = dW_zr[128:].unsqueeze(2)
         grads[g.convq.weight] = dW_q.unsqueeze(2)
         grads[self.decoder[0].weight] = dW1
-        so = lambda a, lda, na, b, ldb, nb, rows: ops.small_outer(a, lda, na, b, ldb, nb, ps.counts, N, B, rows)
         grads[g.convz.bias] = bias_g[0:128]
         grads[g.convr.bias] = bias_g[128:256]
         grads[g.convq.bias] = bias_g[256:384]
         grads[self.decoder[0].bias] = bias_g[384:416]
-        dfl = dflow.view(BN, 3)
-        grads[self.decoder[2].weight] = so(dfl, 3, 3, hid, 32, 32, BN)
-        grads[self.decoder[2].bias] = so(dfl, 3, 3, None, 0, 1, BN).view(3)
-        offs = ps.offs.view(BN, 3)
-        grads[self.offset_encoder.weight] = so(dx, 64, 64, offs, 3, 3, BN)
-        grads[self.offset_encoder.bias] = so(dx, 64, 64, None, 0, 1, BN).view(64)
+        grads[self.offset_encoder.weight] = bias_g[416:608].view(64, 3)
+        grads[self.offset_encoder.bias] = bias_g[608:672]
+        grads[self.decoder[2].weight] = bias_g[672:768].view(3, 32)
+        grads[self.decoder[2].bias] = bias_g[768:771]
 
     # -- reference-compatible call ------------------------------------------------------------------------------
     def forward(self, before_pseudoimages: torch.Tensor, after_pseudoimages: torch.Tensor,

@@ -177,13 +177,14 @@ typedef struct df_gru_weights_t {          /* transposed copies (df_weight_trans
   const float* wt_1;  /* [192,32]  */
 } df_gru_weights_t;
 /* backward data pass.  Consumes dflow [B,N,3] and the forward's `save`; overwrites save's z, r, q planes with
- * dz_pre, dr_pre, dq_pre (inputs of the weight-gradient GEMMs); writes dh0 [B*N,128], dx [B*N,64],
- * dpre1 [B*N,32], hid [B*N,32], xout [B*N,64] (rows of valid points only), and per-workgroup column sums
- * bias_partial [B * ceil(N/64), 416] (= d b_z | d b_r | d b_q | d b_1; must be zero-filled: workgroups with no
- * valid point do not write; sum with df_colsum_finalize). */
+ * dz_pre, dr_pre, dq_pre (inputs of the weight-gradient GEMMs); writes dh0 [B*N,128], dx [B*N,64], dpre1 [B*N,32],
+ * xout [B*N,64] (rows of valid points only), and per-workgroup partial sums of every small gradient:
+ * partial [B * ceil(N/64), 772] = d b_z|b_r|b_q (384) | d b_1 (32) | dW_off[64][3] (192) | d b_off (64) | dW_2[3][32] (96) |
+ * d b_2 (3) | pad.  `partial` must be zero-filled (workgroups with no valid point do not write); sum its rows with
+ * df_colsum_finalize. */
 int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
                        df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
-                       float* hid, float* xout, float* bias_partial, void* stream);
+                       float* xout, float* partial, void* stream);
 /* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
  * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
  * with accumulate_* != 0, added to. */

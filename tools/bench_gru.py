@@ -48,9 +48,9 @@ def fwd_bwd():
     wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
     WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
     dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
-    dpre1, hid, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
-    bp = torch.zeros(B * ((N + 63) // 64), 416, **f32)
+    dpre1, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
+    bp = torch.zeros(B * ((N + 63) // 64), 772, **f32)
     call("df_gru_decoder_bwd", ptr(flow), ptr(ps.offs), ptr(ps.counts), B, N, 4, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-         ptr(dpre1), ptr(hid), ptr(xbuf), ptr(bp), stream())
+         ptr(dpre1), ptr(xbuf), ptr(bp), stream())
 t_fb = timeit(fwd_bwd, 4)
 print(f"gru fwd(train)+bwd data pass {t_fb:.2f} ms -> bwd ~ {t_fb - t_trn:.2f} ms (DF_GRU_DBG={os.environ.get('DF_GRU_DBG', '0')})")
