@@ -65,7 +65,7 @@ _SIGS = {
     "df_colsum_finalize": [P, I, I, I, P, I, P],
     "df_weight_transpose": [P, P, I, I, I, P],
     "df_conv2d_wgrad_splits": [DfImg, DfImg, I, I],
-    "df_conv2d_wgrad": [DfImg, DfImg, I, I, I, P, I, P, I, P],
+    "df_conv2d_wgrad": [DfImg, DfImg, I, I, I, P, I, P, I, P, P],
     "df_conv2d_wgrad_reduce": [P, I, I, I, I, P, L, I, P],
     "df_upsample2x": [DfImg, DfImg, I, P],
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],

@@ -485,6 +485,7 @@ struct WgradParams {
   int rows_per_seg;
   int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
   unsigned x_bytes, dy_bytes;  // DMA path: buffer extents (0 = use the register-staged kernels)
+  float* bias_ws;              // optional [splits][N]: per-split column sums of dy (bias gradient), written by ci-tile 0
 };
 
 // chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
@@ -523,6 +524,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   const int wci = wave & 1, wco = wave >> 1;
   const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
   const bool wave_active = (ci0 + wci * 32) < p.K;  // K == 32 leaves half of the ci tile empty
+  const bool do_bias = p.bias_ws && blockIdx.x == 0;
+  float bsum = 0.f;
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -595,9 +598,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
           }
       }
     }
+    if (do_bias) {  // all 256 threads: column tid & 63, pixel group tid >> 6 (combined once after the loop)
+#pragma unroll
+      for (int j = 0; j < P / 4; ++j) bsum += dYs[((tid >> 6) * (P / 4) + j) * LC + (tid & 63)];
+    }
     __syncthreads();
     if (ch + 1 < c_end) stash();
     __syncthreads();
+  }
+  if (do_bias) {
+    dYs[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) p.bias_ws[(int64_t)split * p.N + co0 + tid] = dYs[tid] + dYs[64 + tid] + dYs[128 + tid] + dYs[192 + tid];
   }
   if (wave_active) {
     float* o = p.ws + (int64_t)split * p.N * TAPS * p.K;
@@ -628,6 +640,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
   const int wco = wave & 1, wci = wave >> 1;
   const int ci0 = blockIdx.x * CIT, co0 = blockIdx.y * COT, split = blockIdx.z;
   const int ciw = ci0 + wci * (CIT / 2);      // first ci of this wave
+  const bool do_bias = p.bias_ws && blockIdx.x == 0;
+  float bsum = 0.f;
 
   f32x16 acc[2][TCI];
 #pragma unroll
@@ -697,9 +711,18 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
           for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+    if (do_bias) {  // all 256 threads: column tid & 127, pixel half tid >> 7 (combined once after the loop)
+#pragma unroll
+      for (int j = 0; j < P / 2; ++j) bsum += dYs[((tid >> 7) * (P / 2) + j) * COT + (tid & 127)];
+    }
     __syncthreads();
     if (ch + 1 < c_end) stash();
     __syncthreads();
+  }
+  if (do_bias) {
+    dYs[tid] = bsum;
+    __syncthreads();
+    if (tid < COT) p.bias_ws[(int64_t)split * p.N + co0 + tid] = dYs[tid] + dYs[128 + tid];
   }
   if (wave_active) {
     float* o = p.ws + (int64_t)split * p.N * p.K;
@@ -741,6 +764,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
   const int wci = wave & 1, wco = wave >> 1;
   const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
   const bool wave_active = (ci0 + wci * 32) < p.K;
+  const bool do_bias = p.bias_ws && blockIdx.x == 0;
+  float bsum = 0.f;
   const int lp = lane >> 4, lc4 = lane & 15;   // pixel within the DMA op, 16-byte channel slot
 
   f32x16 acc[TAPS];
@@ -798,8 +823,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
           }
       }
     }
+    if (do_bias) {  // all 256 threads: column tid & 63, pixel group tid >> 6 (combined once after the loop)
+      const float* dyb = dYs + buf * YSZ;
+#pragma unroll
+      for (int j = 0; j < P / 4; ++j) bsum += dyb[((tid >> 6) * (P / 4) + j) * LC + (tid & 63)];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (do_bias) {
+    dYs[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) p.bias_ws[(int64_t)split * p.N + co0 + tid] = dYs[tid] + dYs[64 + tid] + dYs[128 + tid] + dYs[192 + tid];
   }
   if (wave_active) {
     float* o = p.ws + (int64_t)split * p.N * TAPS * p.K;
@@ -1077,7 +1112,7 @@ extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride
 }
 
 extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
-                               const int32_t* row_counts, int rows_per_seg, void* stream) {
+                               const int32_t* row_counts, int rows_per_seg, float* bias_ws, void* stream) {
   DF_REQUIRE(!row_counts || (ksize == 1 && x.h == 1 && rows_per_seg > 0), DF_E_ARG);
   DF_REQUIRE(img_ok(x) && img_ok(dy) && ws && df_aligned16(ws), DF_E_ALIGN);
   DF_REQUIRE(x.n == dy.n && x.c % 32 == 0 && dy.c % 64 == 0, DF_E_SHAPE);
@@ -1085,6 +1120,7 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE(dy.h == (x.h + 2 * pad - ksize) / stride + 1 && dy.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
   WgradParams p;
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1;
+  p.bias_ws = bias_ws;
   p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
   const int P = wgrad_chunk(ksize);
   p.chunks_per_row = (dy.w + P - 1) / P;
@@ -1112,7 +1148,7 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   // the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step; s2 needs 116 KB LDS = 1 workgroup/CU), so
   // those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere (A/B runs, tests).
   static const int dma_all = getenv("DF_WGRAD_DMA_ALL") ? atoi(getenv("DF_WGRAD_DMA_ALL")) : 0;
-  if (p.x_bytes && (dma_all || (ksize == 3 && stride == 1))) {
+  if (p.x_bytes && ((dma_all && !(bias_ws && ksize == 1 && (dy.c % 128) == 0)) || (ksize == 3 && stride == 1))) {
     if (wgrad_use_1x1(ksize, dy.c)) {
       const int cit = wgrad_cit(x.c);
       dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);

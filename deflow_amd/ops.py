@@ -131,8 +131,10 @@ def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld_co: Optional[int] = None,
-                 accumulate: bool = False, row_counts: Optional[torch.Tensor] = None, rows_per_seg: int = 0, dw_off: int = 0):
-    """dw (float memory [Cout][taps][Cin] with row pitch ld_co, starting dw_off elements in) (+)= dy^T x."""
+                 accumulate: bool = False, row_counts: Optional[torch.Tensor] = None, rows_per_seg: int = 0, dw_off: int = 0,
+                 want_bias: bool = False) -> Optional[torch.Tensor]:
+    """dw (float memory [Cout][taps][Cin] with row pitch ld_co, starting dw_off elements in) (+)= dy^T x.
+    want_bias: also return the bias gradient sum_p dy[p, :] (fused: the kernel already stages every dy tile)."""
     dev = dw.device
     splits = call("df_conv2d_wgrad_splits", x, dy, ks, stride)
     taps = ks * ks
@@ -141,7 +143,9 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, stream())
+    bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
+    call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
+         stream())
     if prof is not None:
         e1.record()
         name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
@@ -150,6 +154,11 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
+    if want_bias:
+        db = _f32(dy.c, device=dev)
+        call("df_colsum_finalize", ptr(bias_ws), splits, dy.c, 1, ptr(db), 0, stream())
+        return db
+    return None
 
 
 def upsample2x(x: DfImg, y: DfImg, align_corners: bool):

@@ -17,6 +17,9 @@ import torch.nn as nn
 from . import ops
 from ._lib import DfImg, img, img_pair, ptr
 
+import os
+_NO_FUSED_BIAS = bool(int(os.environ.get("DF_NO_FUSED_BIAS", "0")))  # A/B switch: separate column-sum pass for conv bias grads
+
 
 class ConvWithNorms(nn.Module):
     def __init__(self, in_num_channels: int, out_num_channels: int, kernel_size: int, stride: int, padding: int):
@@ -161,10 +164,11 @@ class FastFlow3DUNet(nn.Module):
         if dx is not None:
             ops.conv2d(dy, ops.weight_transpose(w), None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
         dw = torch.empty_like(w)  # [O,kh,kw,I] memory
-        ops.conv2d_wgrad(x, dy, ks, stride, dw)
+        fused = with_bias and not _NO_FUSED_BIAS
+        db = ops.conv2d_wgrad(x, dy, ks, stride, dw, want_bias=fused)
         grads[m.weight] = dw.permute(0, 3, 1, 2)  # logical [O,I,kh,kw], channels_last strides
         if with_bias:
-            grads[m.bias] = ops.colsum(dy, dev)
+            grads[m.bias] = db if fused else ops.colsum(dy, dev)
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict
                      ) -> torch.Tensor:

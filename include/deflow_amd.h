@@ -146,9 +146,11 @@ int df_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, 
  * ws: splits * Cout * taps * Cin floats, splits = df_conv2d_wgrad_splits(...). */
 int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride);
 /* row_counts (optional, 1x1 with h == 1 only): pixel p is summed only if p % rows_per_seg < row_counts[p / rows_per_seg]
- * (padded per-sample point rows of the decoder). */
+ * (padded per-sample point rows of the decoder).
+ * bias_ws (optional) [splits, Cout]: per-split column sums of dy = the conv's bias gradient, produced from the dy tiles
+ * the kernel stages anyway (sum its rows with df_colsum_finalize). */
 int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
-                    const int32_t* row_counts, int rows_per_seg, void* stream);
+                    const int32_t* row_counts, int rows_per_seg, float* bias_ws, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
 /* bilinear x2 (PyTorch F.interpolate semantics, align_corners selectable), forward and backward */

@@ -106,8 +106,9 @@ def test_conv_dgrad_wgrad(dev, cin, cout, k, s, n, h, w):
     ops.conv2d(img(gyd), ops.weight_transpose(wd), None, img(dx), k, s, mode=ops.CONV_DGRAD)
     check(f"conv_dgrad {cin}->{cout} k{k} s{s}", nchw(dx), x.grad)
     dw = torch.empty_like(wd)
-    ops.conv2d_wgrad(img(xd), img(gyd), k, s, dw)
+    db_f = ops.conv2d_wgrad(img(xd), img(gyd), k, s, dw, want_bias=True)
     check(f"conv_wgrad {cin}->{cout} k{k} s{s}", dw.permute(0, 3, 1, 2), wt.grad)
+    check("bias grad (fused in wgrad)", db_f, gy.sum((0, 2, 3)))
     db = ops.colsum(img(gyd), dev)
     check("bias grad (colsum)", db, gy.sum((0, 2, 3)))
 
