@@ -71,6 +71,8 @@ _SIGS = {
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],
     "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],
     "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
+    "df_gru_wgrad_splits": [],
+    "df_gru_wgrad": [P, P, P, I, I, I, P, I, P],
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
     "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],
     "df_linear_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, P, P, P, P, P, P, P, P],
@@ -83,7 +85,7 @@ _SIGS = {
     "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
 }
 _RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
-_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma"}  # return values, not status
+_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

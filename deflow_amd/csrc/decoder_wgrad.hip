@@ -1,0 +1,168 @@
+// Fused weight gradients of the ConvGRU gates ([REF decoder.py:123-147] differentiated w.r.t. convz/convr/convq).
+//
+//   dW_z = dz_pre^T [h_in | x]     dW_r = dr_pre^T [h_in | x]     dW_q = dq_pre^T [r*h | x]      (each [128, 192])
+//
+// summed over every valid point row of every GRU iteration -- three "TN" GEMMs with a 4.6 M-deep reduction at the
+// bench shape.  As six generic 1x1 weight-gradient calls these were HBM-latency-bound streams (two operand planes
+// per 128 x 128 tile, 32 flops per byte, one chunk of prefetch): 12 ms per step, as much as the data-gradient kernel.
+// Here one launch streams each plane once per tile: a workgroup owns one gate's full [128 co x 192 ci] tile (49 k
+// flops per 1280 operand bytes) over a contiguous range of 16-row chunks, operands go global -> LDS by DMA
+// (buffer_load ... lds) through a 3-deep ring, i.e. two stages (~5 us) of prefetch with no staging registers, and
+// only chunks holding valid rows are visited.  Partial tiles go to ws[split][384][192]; df_conv2d_wgrad_reduce sums
+// them in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int WP = 16;                          // rows per stage
+constexpr int WD = 3;                           // ring depth
+constexpr int STG = WP * (128 + 128 + 64);      // floats per stage: G[16][128], H[16][128], X[16][64]
+constexpr unsigned BAD = 0xFFFFFFFFu - (8u << 20);  // always outside the buffer range -> the DMA writes zeros
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct GruWgradParams {
+  const float* save;   // planes as written by the forward / backward kernels: [6][T][B*N][128]
+  const float* x;      // [B*N][64] offset encoding
+  const int32_t* counts;
+  int B, N, T, nsplit;
+  int64_t plane_stride, iter_stride;  // floats
+  float* ws;           // [nsplit][384][192]
+};
+
+__global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) float ring[WD * STG];   // 60 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int split = blockIdx.x, gate = blockIdx.y;   // gate 0: z, 1: r, 2: q
+  const float* gplane = p.save + (1 + gate) * p.plane_stride;
+  const float* hplane = p.save + (gate == 2 ? 4 : 0) * p.plane_stride;
+
+  // ---- this workgroup's range of valid 16-row chunks, enumerated (iteration, sample, chunk) -----------------------
+  int S = 0;
+  for (int b = 0; b < p.B; ++b) S += (p.counts[b] + WP - 1) / WP;
+  const int64_t total = (int64_t)S * p.T;
+  const int64_t w0 = total * split / p.nsplit, w1 = total * (split + 1) / p.nsplit;
+  const int nst = (int)(w1 - w0);
+  // issue cursor
+  int it = S ? (int)(w0 / S) : 0, ib = 0, ic = S ? (int)(w0 % S) : 0, inch = 0;
+  if (nst > 0) {
+    for (;; ++ib) {
+      inch = (p.counts[ib] + WP - 1) / WP;
+      if (ic < inch) break;
+      ic -= inch;
+    }
+  }
+  const int g_row = lane >> 5, g_c4 = lane & 31;   // G / H ops: 2 rows x 128 floats
+  const int x_row = lane >> 4, x_c4 = lane & 15;   // X op: 4 rows x 64 floats
+  const unsigned x_bytes = (unsigned)min((int64_t)p.B * p.N * 256, (int64_t)0x7fffffff);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_bytes, 0x00020000);
+  const unsigned pl_bytes = (unsigned)min((int64_t)p.B * p.N * 512, (int64_t)0x7fffffff);
+
+  auto issue = [&](int buf) {   // DMA the stage at the cursor into ring slot `buf`, then advance the cursor
+    float* G = ring + buf * STG;
+    float* H = G + WP * 128;
+    float* X = H + WP * 128;
+    const int cnt = p.counts[ib];
+    const int row0 = ic * WP;                         // first row of the chunk within the sample
+    const int64_t srow = (int64_t)ib * p.N + row0;    // global row
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(hplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int op = 2 * wave + k;                    // rows 2 op, 2 op + 1
+      const int r = 2 * op + g_row;
+      const unsigned vo = (row0 + r < cnt) ? (unsigned)(((srow + r) * 128 + g_c4 * 4) * 4) : BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + op * 256), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + op * 256), 16, vo, 0, 0, 0);
+    }
+    {
+      const int r = 4 * wave + x_row;
+      const unsigned vo = (row0 + r < cnt) ? (unsigned)(((srow + r) * 64 + x_c4 * 4) * 4) : BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(X + wave * 256), 16, vo, 0, 0, 0);
+    }
+    if (++ic == inch) {
+      ic = 0;
+      do {
+        if (++ib == p.B) { ib = 0; ++it; }
+        inch = (p.counts[ib] + WP - 1) / WP;
+      } while (inch == 0);
+    }
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // per-lane operand offsets inside a stage: a = G[px][wco*64 + 32 i + li]; b_j = column wci*96 + 32 j + li of [H | X]
+  const int a_off = kh * 128 + wco * 64 + li;
+  int b_off[3], b_pitch[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int ci = wci * 96 + 32 * j;
+    if (ci < 128) { b_off[j] = WP * 128 + kh * 128 + ci + li; b_pitch[j] = 256; }
+    else { b_off[j] = 2 * WP * 128 + kh * 64 + (ci - 128) + li; b_pitch[j] = 128; }
+  }
+
+  if (nst > 0) issue(0);
+  if (nst > 1) issue(1);
+  for (int i = 0; i < nst; ++i) {
+    // this wave's DMA for stage i has landed (5 ops per stage per wave, at most one younger stage in flight) ...
+    if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // ... and everyone's; all waves are also done reading slot (i - 1) % WD
+    if (i + 2 < nst) issue((i + 2) % WD);
+    const float* st = ring + (i % WD) * STG;
+#pragma unroll
+    for (int ks = 0; ks < WP / 2; ++ks) {
+      const float a0 = st[a_off + ks * 256], a1 = st[a_off + ks * 256 + 32];
+      float b[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) b[j] = st[b_off[j] + ks * b_pitch[j]];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
+      }
+    }
+  }
+  float* o = p.ws + ((int64_t)split * 384 + gate * 128) * 192;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ci = wci * 96 + 32 * j + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        o[co * 192 + ci] = acc[i][j][e];
+      }
+    }
+#endif
+}
+
+}  // namespace
+
+extern "C" int df_gru_wgrad_splits(void) { return 170; }   // 3 gates x 170 = 510 workgroups: one resident wave at 2 per CU
+
+extern "C" int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters,
+                            float* ws, int nsplit, void* stream) {
+  DF_REQUIRE(save && x && counts && ws && B > 0 && N > 0 && num_iters >= 1 && nsplit >= 1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(save) && df_aligned16(x), DF_E_ALIGN);
+  DF_REQUIRE((int64_t)B * N * 512 < (int64_t)0x7fffffff, DF_E_SHAPE);  // 32-bit DMA offsets within one iteration's plane
+  GruWgradParams p;
+  p.save = save; p.x = x; p.counts = counts; p.B = B; p.N = N; p.T = num_iters; p.nsplit = nsplit;
+  p.iter_stride = (int64_t)B * N * 128;
+  p.plane_stride = p.iter_stride * num_iters;
+  p.ws = ws;
+  hipLaunchKernelGGL(gru_wgrad_kernel, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

@@ -4,6 +4,8 @@ decoder.{0,2}.*) so ``deflow_best.ckpt`` loads [REF deflow.py:41-47].  Compute: 
 csrc/decoder_bwd.hip."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -154,15 +156,23 @@ class ConvGRUDecoder(nn.Module):
         hT = rows_img(sv, 5 * plane, 1, 128, 128, BN * 128)
         x_rep = rows_img(xbuf, 0, T, 64, 64, 0)          # the same x rows for every iteration
         x_one = rows_img(xbuf, 0, 1, 64, 64, BN * 64)
-        dW_zr = torch.empty(256, 192, **f32)
-        dW_q = torch.empty(128, 192, **f32)
         kw = dict(row_counts=ps.counts, rows_per_seg=N)
-        ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
-        ops.conv2d_wgrad(x_rep, dz, 1, 1, dW_zr, ld_co=192, dw_off=128, **kw)
-        ops.conv2d_wgrad(h_in, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192, **kw)
-        ops.conv2d_wgrad(x_rep, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192 + 128, **kw)
-        ops.conv2d_wgrad(rh, dq, 1, 1, dW_q, ld_co=192, dw_off=0, **kw)
-        ops.conv2d_wgrad(x_rep, dq, 1, 1, dW_q, ld_co=192, dw_off=128, **kw)
+        if os.environ.get("DF_GRU_WGRAD_V1"):  # six generic 1x1 weight-gradient GEMMs (first generation), for A/B
+            dW_zr = torch.empty(256, 192, **f32)
+            dW_q = torch.empty(128, 192, **f32)
+            ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
+            ops.conv2d_wgrad(x_rep, dz, 1, 1, dW_zr, ld_co=192, dw_off=128, **kw)
+            ops.conv2d_wgrad(h_in, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192, **kw)
+            ops.conv2d_wgrad(x_rep, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192 + 128, **kw)
+            ops.conv2d_wgrad(rh, dq, 1, 1, dW_q, ld_co=192, dw_off=0, **kw)
+            ops.conv2d_wgrad(x_rep, dq, 1, 1, dW_q, ld_co=192, dw_off=128, **kw)
+        else:  # one fused streaming pass over the planes
+            nsplit = call("df_gru_wgrad_splits")
+            ws = torch.empty(nsplit, 384, 192, **f32)
+            call("df_gru_wgrad", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, s)
+            dW_all = torch.empty(384, 192, **f32)
+            call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
+            dW_zr, dW_q = dW_all[:256], dW_all[256:]
         # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
         dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
         dW1t = torch.empty(192, 32, **f32)

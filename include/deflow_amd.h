@@ -187,6 +187,13 @@ typedef struct df_gru_weights_t {          /* transposed copies (df_weight_trans
 int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
                        df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
                        float* xout, float* partial, void* stream);
+/* Weight gradients of the three GRU gate convolutions in one streaming pass over the planes df_gru_decoder_fwd saved
+ * and df_gru_decoder_bwd overwrote (replaces autograd's six 1x1 conv weight-gradient GEMMs over [REF decoder.py:139-147]):
+ * ws[split][384][192] partial tiles, rows 0..127 dW_z, 128..255 dW_r, 256..383 dW_q, columns [h | x]; sum the splits
+ * with df_conv2d_wgrad_reduce(ws, splits, 384, 1, 192, ...).  x = the [B*N,64] offset encoding df_gru_decoder_bwd wrote. */
+int df_gru_wgrad_splits(void);
+int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,
+                 int nsplit, void* stream);
 /* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
  * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
  * with accumulate_* != 0, added to. */

@@ -54,3 +54,18 @@ def fwd_bwd():
          ptr(dpre1), ptr(xbuf), ptr(bp), stream())
 t_fb = timeit(fwd_bwd, 4)
 print(f"gru fwd(train)+bwd data pass {t_fb:.2f} ms -> bwd ~ {t_fb - t_trn:.2f} ms (DF_GRU_DBG={os.environ.get('DF_GRU_DBG', '0')})")
+
+# weight-gradient GEMMs of the three gates (after a backward pass left the gate gradients in the planes)
+def wgrad_fused():
+    from deflow_amd._lib import call, ptr, stream
+    nsplit = call("df_gru_wgrad_splits")
+    ws = torch.empty(nsplit, 384, 192, device=dev)
+    call("df_gru_wgrad", ptr(SV), ptr(XB), ptr(ps.counts), B, N, 4, ptr(ws), nsplit, stream())
+    out = torch.empty(384, 192, device=dev)
+    call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(out), 192, 0, stream())
+    return out
+_, SV = head.run(img(before), img(after), ps, True)
+XB = torch.randn(B * N, 64, device=dev)
+t_wg = timeit(wgrad_fused)
+wf = 0.9 * B * N * 4 * 2 * 192 * 384
+print(f"gru fused weight gradients {t_wg:.2f} ms ({wf / t_wg / 1e9:.1f} TF/s)")
