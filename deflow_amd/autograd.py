@@ -2,10 +2,12 @@
 forward and backward computation inside them is a HIP kernel launched through the C ABI."""
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
 
+from . import ops
 from ._lib import img, call, ptr, stream
 
 
@@ -51,6 +53,8 @@ class GruHeadFn(torch.autograd.Function):
         grads = GradDict()
         head.run_backward(dflow, ps, ctx.sv, img(db), img(da), False, False, grads, before=img(ctx.imgs[0]),
                           after=img(ctx.imgs[1]))
+        if ops.SIDE is not None:
+            ops.SIDE.join()
         ctx.sv = ctx.imgs = None
         return (None, None, db.permute(0, 3, 1, 2), da.permute(0, 3, 1, 2)) + _grads_for(ctx.params, grads)
 
@@ -72,6 +76,8 @@ class DeFlowFn(torch.autograd.Function):
         model, st = ctx.model, ctx.state
         grads = GradDict()
         bstar = st["bstar"]
+        if ops.SIDE is None and os.environ.get("DF_SIDE_STREAM") == "1":
+            ops.SIDE = ops.SideStream(bstar.device)
         B, H, W, _ = bstar.shape
         dev = bstar.device
         dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
@@ -88,6 +94,8 @@ class DeFlowFn(torch.autograd.Function):
         g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)
         g = emb.pillarize_bwd(st["p1"], img(dbstar, 32, 32), g)
         grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
+        if ops.SIDE is not None:
+            ops.SIDE.join()
         ctx.state = None
         return (None, None, None) + _grads_for(ctx.params, grads)
 

@@ -4,6 +4,7 @@ decoder.{0,2}.*) so ``deflow_best.ckpt`` loads [REF deflow.py:41-47].  Compute: 
 csrc/decoder_bwd.hip."""
 from __future__ import annotations
 
+import contextlib
 import os
 
 from dataclasses import dataclass
@@ -142,43 +143,48 @@ class ConvGRUDecoder(nn.Module):
         ncell = dbefore.h * dbefore.w
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
              int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
-        # weight gradients: split-K GEMMs over the saved planes (now holding the gate pre-activation gradients)
-        plane = T * BN * 128
+        side = ops.SIDE
+        if side is not None:
+            side.keep.extend([sv, xbuf, dpre1, ps])
+        with (side.fork() if side is not None else contextlib.nullcontext()):
+            s = stream()  # the side stream inside the fork
+            # weight gradients: split-K GEMMs over the saved planes (now holding the gate pre-activation gradients)
+            plane = T * BN * 128
 
-        def rows_img(t: torch.Tensor, off: int, n_img: int, c: int, ld: int, img_stride: int) -> DfImg:
-            return DfImg(t.data_ptr() + 4 * off, n_img, 1, BN, c, ld, n_img, img_stride, 0)
+            def rows_img(t: torch.Tensor, off: int, n_img: int, c: int, ld: int, img_stride: int) -> DfImg:
+                return DfImg(t.data_ptr() + 4 * off, n_img, 1, BN, c, ld, n_img, img_stride, 0)
 
-        h_in = rows_img(sv, 0 * plane, T, 128, 128, BN * 128)
-        dz = rows_img(sv, 1 * plane, T, 128, 128, BN * 128)
-        dr = rows_img(sv, 2 * plane, T, 128, 128, BN * 128)
-        dq = rows_img(sv, 3 * plane, T, 128, 128, BN * 128)
-        rh = rows_img(sv, 4 * plane, T, 128, 128, BN * 128)
-        hT = rows_img(sv, 5 * plane, 1, 128, 128, BN * 128)
-        x_rep = rows_img(xbuf, 0, T, 64, 64, 0)          # the same x rows for every iteration
-        x_one = rows_img(xbuf, 0, 1, 64, 64, BN * 64)
-        kw = dict(row_counts=ps.counts, rows_per_seg=N)
-        if os.environ.get("DF_GRU_WGRAD_V1"):  # six generic 1x1 weight-gradient GEMMs (first generation), for A/B
-            dW_zr = torch.empty(256, 192, **f32)
-            dW_q = torch.empty(128, 192, **f32)
-            ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
-            ops.conv2d_wgrad(x_rep, dz, 1, 1, dW_zr, ld_co=192, dw_off=128, **kw)
-            ops.conv2d_wgrad(h_in, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192, **kw)
-            ops.conv2d_wgrad(x_rep, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192 + 128, **kw)
-            ops.conv2d_wgrad(rh, dq, 1, 1, dW_q, ld_co=192, dw_off=0, **kw)
-            ops.conv2d_wgrad(x_rep, dq, 1, 1, dW_q, ld_co=192, dw_off=128, **kw)
-        else:  # one fused streaming pass over the planes
-            nsplit = call("df_gru_wgrad_splits")
-            ws = torch.empty(nsplit, 384, 192, **f32)
-            call("df_gru_wgrad", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, s)
-            dW_all = torch.empty(384, 192, **f32)
-            call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
-            dW_zr, dW_q = dW_all[:256], dW_all[256:]
-        # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
-        dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
-        dW1t = torch.empty(192, 32, **f32)
-        ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
-        ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
-        dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
+            h_in = rows_img(sv, 0 * plane, T, 128, 128, BN * 128)
+            dz = rows_img(sv, 1 * plane, T, 128, 128, BN * 128)
+            dr = rows_img(sv, 2 * plane, T, 128, 128, BN * 128)
+            dq = rows_img(sv, 3 * plane, T, 128, 128, BN * 128)
+            rh = rows_img(sv, 4 * plane, T, 128, 128, BN * 128)
+            hT = rows_img(sv, 5 * plane, 1, 128, 128, BN * 128)
+            x_rep = rows_img(xbuf, 0, T, 64, 64, 0)          # the same x rows for every iteration
+            x_one = rows_img(xbuf, 0, 1, 64, 64, BN * 64)
+            kw = dict(row_counts=ps.counts, rows_per_seg=N)
+            if os.environ.get("DF_GRU_WGRAD_V1"):  # six generic 1x1 weight-gradient GEMMs (first generation), for A/B
+                dW_zr = torch.empty(256, 192, **f32)
+                dW_q = torch.empty(128, 192, **f32)
+                ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
+                ops.conv2d_wgrad(x_rep, dz, 1, 1, dW_zr, ld_co=192, dw_off=128, **kw)
+                ops.conv2d_wgrad(h_in, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192, **kw)
+                ops.conv2d_wgrad(x_rep, dr, 1, 1, dW_zr, ld_co=192, dw_off=128 * 192 + 128, **kw)
+                ops.conv2d_wgrad(rh, dq, 1, 1, dW_q, ld_co=192, dw_off=0, **kw)
+                ops.conv2d_wgrad(x_rep, dq, 1, 1, dW_q, ld_co=192, dw_off=128, **kw)
+            else:  # one fused streaming pass over the planes
+                nsplit = call("df_gru_wgrad_splits")
+                ws = torch.empty(nsplit, 384, 192, **f32)
+                call("df_gru_wgrad", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, s)
+                dW_all = torch.empty(384, 192, **f32)
+                call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
+                dW_zr, dW_q = dW_all[:256], dW_all[256:]
+            # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
+            dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
+            dW1t = torch.empty(192, 32, **f32)
+            ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
+            ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
+            dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
         g = self.gru
         grads[g.convz.weight] = dW_zr[:128].unsqueeze(2)
         grads[g.convr.weight] = dW_zr[128:].unsqueeze(2)

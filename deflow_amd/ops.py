@@ -27,11 +27,11 @@ class KernelProfiler:
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (kernel name, algorithmic flops, start event, end event)
+        self.records = []  # (kernel name, algorithmic flops, start event, end event, layer tag)
 
     def summary(self):
         out = {}
-        for name, flops, e0, e1 in self.records:
+        for name, flops, e0, e1, _ in self.records:
             d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
@@ -40,6 +40,32 @@ class KernelProfiler:
 
 
 PROFILER: Optional[KernelProfiler] = None
+
+
+class SideStream:
+    """Second HIP stream for the weight-gradient GEMMs of the backward pass.  They depend only on a layer's input and
+    output gradient, nothing on the critical path (data gradients -> next layer) depends on them until the optimizer, so
+    they run concurrently with the HBM-bound normalisation / activation backward kernels and fill the MFMA pipe while
+    those stream.  `keep` pins every tensor a side-stream kernel reads until the main stream has joined (the caching
+    allocator would otherwise hand the blocks to later main-stream allocations)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep: list = []
+
+    def fork(self):
+        """context manager: work enqueued inside runs on the side stream, after everything enqueued so far on main"""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
+SIDE: Optional[SideStream] = None
 
 
 def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int) -> str:
@@ -67,7 +93,8 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
-        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi), flops, e0, e1))
+        tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
+        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi), flops, e0, e1, tag))
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:
@@ -151,7 +178,8 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (f"wgrad_dma_kernel<{ks},{stride},32>" if (ks == 3 and stride == 1) else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
-        prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1))
+        tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"
+        prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
     if want_bias:

@@ -163,12 +163,20 @@ class FastFlow3DUNet(nn.Module):
         dev = w.device
         if dx is not None:
             ops.conv2d(dy, ops.weight_transpose(w), None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
-        dw = torch.empty_like(w)  # [O,kh,kw,I] memory
         fused = with_bias and not _NO_FUSED_BIAS
-        db = ops.conv2d_wgrad(x, dy, ks, stride, dw, want_bias=fused)
-        grads[m.weight] = dw.permute(0, 3, 1, 2)  # logical [O,I,kh,kw], channels_last strides
-        if with_bias:
-            grads[m.bias] = db if fused else ops.colsum(dy, dev)
+
+        def wgrad():
+            dw = torch.empty_like(w)  # [O,kh,kw,I] memory
+            db = ops.conv2d_wgrad(x, dy, ks, stride, dw, want_bias=fused)
+            grads[m.weight] = dw.permute(0, 3, 1, 2)  # logical [O,I,kh,kw], channels_last strides
+            if with_bias:
+                grads[m.bias] = db if fused else ops.colsum(dy, dev)
+
+        if ops.SIDE is None:
+            wgrad()
+        else:
+            with ops.SIDE.fork():
+                wgrad()
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict
                      ) -> torch.Tensor:
@@ -179,10 +187,19 @@ class FastFlow3DUNet(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         tape = list(tape)
 
+        keep = ops.SIDE.keep if ops.SIDE is not None else None
+
         def pop(kind):
             e = tape.pop()
             assert e[0] == kind, (e[0], kind)
+            if keep is not None:
+                keep.append(e)
             return e
+
+        def hold(t):
+            if keep is not None:
+                keep.append(t)
+            return t
 
         def plain_conv_bwd(dy: torch.Tensor, dx: Optional[DfImg], acc: bool):
             _, m, x, ks = pop("conv")
@@ -191,24 +208,24 @@ class FastFlow3DUNet(nn.Module):
         def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: DfImg, acc_b: bool):
             # reverse of: u1(a)->t ; up(t)->cat[:lat] ; u3(b)->cat[lat:] ; u4(cat) ; u5(u4)
             _, m5, x5, _ = tape[-1]
-            du4 = torch.empty_like(x5)
+            du4 = hold(torch.empty_like(x5))
             plain_conv_bwd(dout, img(du4), False)
             _, m4, x4, _ = tape[-1]
-            dcat = torch.empty_like(x4)
+            dcat = hold(torch.empty_like(x4))
             plain_conv_bwd(du4, img(dcat), False)
             lat = dcat.shape[3] // 2
             # u3
             _, m3, xb, ks = pop("conv")
             self._conv_bwd(m3, img(xb), img(dcat, lat, lat), 1, 1, db, acc_b, grads)
             _, h, w, lat_ = pop("up")
-            dt = torch.empty(B, h, w, lat, **f32)
+            dt = hold(torch.empty(B, h, w, lat, **f32))
             ops.upsample2x_bwd(img(dcat, lat, 0), img(dt), self.align_corners)
             _, m1, xa, ks = pop("conv")
             self._conv_bwd(m1, img(xa), img(dt), 1, 1, da, acc_a, grads)
 
         # decoder_step4
         _, m, xu, _ = tape[-1]
-        du = torch.empty_like(xu)
+        du = hold(torch.empty_like(xu))
         plain_conv_bwd(dv, img(du), False)
         # decoder_step3: a = T, b = bstar
         if dbstar is None:
@@ -216,13 +233,13 @@ class FastFlow3DUNet(nn.Module):
             acc_b = False
         else:
             acc_b = True
-        dT = torch.empty(B, H // 2, W // 2, 128, **f32)
+        dT = hold(torch.empty(B, H // 2, W // 2, 128, **f32))
         upsample_skip_bwd(du, img(dT), False, img(dbstar), acc_b)
-        dF = torch.empty(B, H // 2, W // 2, 128, **f32)   # d(fstar)
-        dS = torch.empty(B, H // 4, W // 4, 256, **f32)
+        dF = hold(torch.empty(B, H // 2, W // 2, 128, **f32))   # d(fstar)
+        dS = hold(torch.empty(B, H // 4, W // 4, 256, **f32))
         upsample_skip_bwd(dT, img(dS), False, img(dF), False)
-        dL = torch.empty(B, H // 4, W // 4, 256, **f32)   # d(lstar)
-        dR = torch.empty(B, H // 8, W // 8, 512, **f32)   # d(rstar)
+        dL = hold(torch.empty(B, H // 4, W // 4, 256, **f32))   # d(lstar)
+        dR = hold(torch.empty(B, H // 8, W // 8, 512, **f32))   # d(rstar)
         upsample_skip_bwd(dS, img(dR), False, img(dL), False)
         # encoder, stages 3..1; dz of a stage's last layer lives in the concatenated gradient buffer
         stage_in_grads = {3: (dL, 128), 2: (dF, 64), 1: (dbstar, 32)}
@@ -232,6 +249,7 @@ class FastFlow3DUNet(nn.Module):
                 pop("keep")
                 _, m, x, y, bn_ss, ipg, groups = pop("cwn")
                 dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups)
+                hold(dy)
                 grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
                 if i > 0:
                     dxt = torch.empty(2 * B, x.h, x.w, x.c, **f32)
