@@ -1101,7 +1101,7 @@ extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride
   const int tiles = wgrad_use_1x1(ksize, dy.c) ? ((x.c + wgrad_cit(x.c) - 1) / wgrad_cit(x.c)) * (dy.c / 128)
                                                : ((x.c + 63) / 64) * (dy.c / 64);
   const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
-  static const int target = getenv("DF_WGRAD_BLOCKS") ? atoi(getenv("DF_WGRAD_BLOCKS")) : 1024;
+  static const int target = getenv("DF_WGRAD_BLOCKS") ? atoi(getenv("DF_WGRAD_BLOCKS")) : 512;  // = one resident round at 2 workgroups per CU (1024: +0.6 ms of partial-sum traffic, 768: a ragged second round)
   int64_t splits = (target + tiles - 1) / tiles;
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;

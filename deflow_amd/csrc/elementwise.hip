@@ -8,7 +8,42 @@
 namespace {
 
 // ------------------------------------------------------------------ BN finalize ---------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_per_group,
+// Stage A (large layers): block (channel block, group, split) sums its range of per-tile partials in double and
+// leaves [sum, sum of squares] per channel in scratch[g][split][2][C] -- the biggest layer has 32768 tiles per group,
+// far too many for the C/32 blocks of the finalize kernel alone (it took 250 us there).
+__global__ __launch_bounds__(1024) void bn_stats_split_kernel(const float* __restrict__ partial, int tiles_per_group,
+                                                             int C, int splits, double* __restrict__ scratch) {
+  __shared__ double red[2][32][32];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g = blockIdx.y, sp = blockIdx.z;
+  const int t0 = (int)((int64_t)tiles_per_group * sp / splits), t1 = (int)((int64_t)tiles_per_group * (sp + 1) / splits);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int t = t0 + tl; t < t1; t += 32) {
+      const float* q = partial + (((int64_t)g * tiles_per_group + t) * C + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+  }
+  red[0][tl][cl] = s1;
+  red[1][tl][cl] = s2;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int k = 1; k < 32; ++k) {
+      s1 += red[0][k][cl];
+      s2 += red[1][k][cl];
+    }
+    double* o = scratch + ((int64_t)g * splits + sp) * 2 * C;
+    o[c] = s1;
+    o[C + c] = s2;
+  }
+}
+
+// PRE = false: partial is the conv epilogue's float [group][tile][C][2]; PRE = true: stage A's double
+// [group][split][2][C] (tiles_per_group = splits).
+template <bool PRE>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const void* __restrict__ partial_, int tiles_per_group,
                                                           int groups, int C, double count, const float* gamma,
                                                           const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
@@ -20,9 +55,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
       for (int t = tl; t < tiles_per_group; t += 32) {
-        const float* q = partial + (((int64_t)g * tiles_per_group + t) * C + c) * 2;
-        s1 += (double)q[0];
-        s2 += (double)q[1];
+        if (PRE) {
+          const double* q = reinterpret_cast<const double*>(partial_) + ((int64_t)g * tiles_per_group + t) * 2 * C;
+          s1 += q[c];
+          s2 += q[C + c];
+        } else {
+          const float* q = reinterpret_cast<const float*>(partial_) + (((int64_t)g * tiles_per_group + t) * C + c) * 2;
+          s1 += (double)q[0];
+          s2 += (double)q[1];
+        }
       }
     }
     red[0][tl][cl] = s1;
@@ -354,11 +395,20 @@ unsigned grid_for(int64_t total, int per_block = 256, unsigned cap = 256 * 16) {
 
 extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                              float* running_var, float* bn_ss, void* stream) {
+                              float* running_var, float* bn_ss, double* scratch, int splits, void* stream) {
   DF_REQUIRE(partial && bn_ss && tiles_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, DF_E_ARG);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     partial, tiles_per_group, groups, C, (double)count_per_group, gamma, beta, eps, momentum,
-                     running_mean, running_var, bn_ss);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (scratch && splits > 1) {
+    hipLaunchKernelGGL(bn_stats_split_kernel, dim3((C + 31) / 32, groups, splits), dim3(1024), 0, s, partial,
+                       tiles_per_group, C, splits, scratch);
+    DF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((C + 31) / 32), dim3(1024), 0, s, (const void*)scratch, splits,
+                       groups, C, (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, bn_ss);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, s, (const void*)partial,
+                       tiles_per_group, groups, C, (double)count_per_group, gamma, beta, eps, momentum, running_mean,
+                       running_var, bn_ss);
+  }
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -102,8 +102,10 @@ def conv_tile_m(rows_per_group: int, cout: int) -> int:
 
 
 def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss):
+    splits = min(64, tiles_per_group // 64)  # two-stage reduction once a group has thousands of tile partials
+    scratch = torch.empty(groups * splits * 2 * C, dtype=torch.float64, device=partial.device) if splits > 1 else None
     call("df_bn_finalize", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,
-         ptr(rmean), ptr(rvar), ptr(bn_ss), stream())
+         ptr(rmean), ptr(rvar), ptr(bn_ss), ptr(scratch), splits, stream())
 
 
 def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):

@@ -122,10 +122,11 @@ int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int e
 int df_conv2d_last_dma(void); /* 1 if the previous df_conv2d call launched the LDS-DMA kernel (profiling tools) */
 /* BatchNorm2d training statistics from the partials. groups = stat groups (the shared encoder is
  * applied to pc0 then pc1: two calls => two groups, running stats updated in call order).
- * bn_ss [groups,4,C] = scale, shift, mean, invstd. */
+ * bn_ss [groups,4,C] = scale, shift, mean, invstd.  Optional two-stage reduction for layers with many tiles:
+ * scratch [groups, splits, 2, C] doubles and splits > 1 (NULL / <= 1: single stage). */
 int df_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
                    const float* gamma, const float* beta, float eps, float momentum,
-                   float* running_mean, float* running_var, float* bn_ss, void* stream);
+                   float* running_mean, float* running_var, float* bn_ss, double* scratch, int splits, void* stream);
 /* z = gelu(y * scale + shift) ; y plain [n,h,w,C]; imgs_per_group images share one stat group */
 int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream);
 /* backward of z = gelu(bn(y)): pass 1 partial sums [nblk, C, 2] of (dyh, dyh*xhat) */
