@@ -1,0 +1,298 @@
+// ConvGRU decoder forward with the loop-invariant x projection hoisted ([REF decoder.py:123-183]).
+//
+// x (the offset encoding) is the same in every GRU iteration [REF decoder.py:180], so W[:, 128:] x + b of the three
+// gates is computed ONCE per point (registers, 3 x 32 per lane in MFMA C layout) and each iteration only multiplies
+// the 128 h / r*h columns: 54 instead of 72 weight chunks for 4 iterations (-25 % MFMA work; only the fp32 summation
+// order changes -- x part first, then the h part).  Everything else follows decoder2.hip (two workgroups per CU,
+// 16 points per wave, wave-private LDS A operand), except that weight chunks now go L2 -> LDS by DMA
+// (buffer_load ... lds): no staging registers, which is what makes room for the 96 hoisted ones.  The DMA writes
+// each wave's 64 x 16 B linearly, so weight tiles are unpadded [rows][32] with the XOR slot swizzle of the conv
+// kernels applied to the SOURCE column (physical slot = logical slot ^ ((row >> 1) & 7)).
+#include "common.h"
+
+namespace {
+
+constexpr int LDH = 132;            // A region pitch (floats): 33 slots of 16 B -> conflict-free b128 rows
+constexpr int BT = 128 * 32;        // one weight buffer: 128 rows x 32 floats, unpadded
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+
+// 32-deep k chunk `chunk` of ROWS weight rows (192 floats apart) -> LDS buffer, all four waves cooperating: one DMA
+// instruction moves 8 rows x 128 B, wave w takes row groups w, w + 4, ...
+template <int ROWS>
+__device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
+  const rsrc_t r = make_rsrc(W, 0x7fffffffu);
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
+                                             (unsigned)((i * 32 * 192 + chunk * 32) * 4), 0, 0);
+}
+
+struct WStream {   // the weight-chunk pipeline state shared by consecutive GEMMs
+  float* Bs;
+  int par, wave;
+  unsigned voff;       // per-lane DMA source offset (row within the group of 8, swizzled 16-B slot)
+  const float* b_lane; // fragment base: row li of buffer 0
+  int bsl[2];          // swizzled slot offsets (floats) of the two 16-wide k groups
+};
+
+// acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
+// registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
+// (Wn, cn, ROWS_NEXT rows) is fetched during the last chunk.
+template <int ROWS, int NCH, bool XA, int ROWS_NEXT>
+__device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const float* __restrict__ Wn, int cn,
+                                     const float* a_lane, const f32x4 (&xf)[4], WStream& ws, f32x4 (&acc)[ROWS / 16]) {
+  constexpr int NPAIR = ROWS / 32;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
+    if (c + 1 < NCH) dma_chunk<ROWS>(W, c0 + c + 1, nb, ws.wave, ws.voff);
+    else if (Wn) dma_chunk<ROWS_NEXT>(Wn, cn, nb, ws.wave, ws.voff);
+    const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
+    f32x4 a0, a1;
+    if (XA) {
+      a0 = xf[2 * c];
+      a1 = xf[2 * c + 1];
+    } else {
+      a0 = ld4(a_lane + c * 32);
+      a1 = ld4(a_lane + c * 32 + 16);
+    }
+    f32x4 nb0 = ld4(bb + ws.bsl[0]), nb1 = ld4(bb + 512 + ws.bsl[0]);
+#pragma unroll
+    for (int j = 0; j < 2 * NPAIR; ++j) {
+      const int g = j / NPAIR, t = 2 * (j % NPAIR);
+      const f32x4 b0 = nb0, b1 = nb1;
+      if (j + 1 < 2 * NPAIR) {
+        const int gn = (j + 1) / NPAIR, tn = 2 * ((j + 1) % NPAIR);
+        nb0 = ld4(bb + tn * 512 + ws.bsl[gn]);
+        nb1 = ld4(bb + (tn + 1) * 512 + ws.bsl[gn]);
+      }
+      const f32x4 a = g ? a1 : a0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
+    __syncthreads();                                     // ... and everyone's; the current buffer is free again
+  }
+  ws.par = (ws.par + NCH) & 1;
+}
+
+struct Gru3Params {
+  df_img before, after;
+  const int32_t* coords;
+  const float* offs;
+  const int32_t* counts;
+  int N, T;
+  df_gru_weights w;
+  float* flow;
+  float* save;
+  int64_t plane_stride, iter_stride;
+};
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
+  __shared__ __attribute__((aligned(16))) float As[4 * 16 * LDH];   // 33.8 KB
+  const int b = blockIdx.y;
+  const int cnt = p.counts[b];
+  const int p0 = blockIdx.x * 64;
+  if (p0 >= cnt) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  float* Aw = As + wave * 16 * LDH;
+  const int wp0 = p0 + wave * 16;
+  const int64_t grow0 = (int64_t)b * p.N + wp0;
+  const float* a_lane = Aw + li * LDH + lq * 4;
+  float* c_lane = Aw + 4 * lq * LDH + li;                   // C-layout element (row 4 lq + r, col 16 t + li)
+  float* r_lane = Aw + (lane >> 5) * LDH + (lane & 31) * 4;  // row copies: float4 j at r_lane + 2 j LDH
+  const unsigned row_bytes = (unsigned)min(max(cnt - wp0, 0), 16) * 512u;
+  const unsigned rl_off = ((lane >> 5) * 128 + (lane & 31) * 4) * 4, cl_off = (4 * lq * 128 + li) * 4;
+  const float* w_z = p.w.w_zr;
+  const float* w_r = p.w.w_zr + 128 * 192;
+  const float* w_q = p.w.w_q;
+
+  WStream ws;
+  ws.Bs = Bs; ws.par = 0; ws.wave = wave;
+  {
+    const int l3 = lane >> 3, c4 = lane & 7;
+    const int row = wave * 8 + l3;                      // (row >> 1) & 7 is the same for row + 32 i
+    ws.voff = (unsigned)((row * 192 + ((c4 ^ ((row >> 1) & 7)) * 4)) * 4);
+    ws.b_lane = Bs + li * 32;
+    ws.bsl[0] = ((lq) ^ ((li >> 1) & 7)) * 4;
+    ws.bsl[1] = ((4 + lq) ^ ((li >> 1) & 7)) * 4;
+  }
+  dma_chunk<128>(w_z, 4, Bs, wave, ws.voff);   // first chunk of the x projection
+
+  // ---- x = offset encoder -> A region (temporarily) -> register fragments ------------------------------------------
+  f32x4 xf[4];
+  {
+    const float w0 = p.w.w_off[lane * 3 + 0], w1 = p.w.w_off[lane * 3 + 1], w2 = p.w.w_off[lane * 3 + 2];
+    const float bo = p.w.b_off[lane];
+    for (int pt = 0; pt < 16; ++pt) {
+      float x = 0.f;
+      if (wp0 + pt < cnt) {
+        const float* o = p.offs + (grow0 + pt) * 3;
+        x = fmaf(w2, o[2], fmaf(w1, o[1], fmaf(w0, o[0], bo)));
+      }
+      Aw[pt * LDH + lane] = x;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + k * 16);
+  __syncthreads();
+  // ---- gather h0 = [before | after] -------------------------------------------------------------------------------
+  {
+    const float* bp = reinterpret_cast<const float*>(p.before.ptr) + df_img_base(p.before, b);
+    const float* ap = reinterpret_cast<const float*>(p.after.ptr) + df_img_base(p.after, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = lane + 64 * j;
+      const int pt = f >> 5, c4 = f & 31;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wp0 + pt < cnt) {
+        const int32_t* cc = p.coords + (grow0 + pt) * 3;
+        const int64_t cell = (int64_t)cc[1] * p.before.w + cc[2];
+        v = (c4 < 16) ? ld4(bp + cell * p.before.ld + c4 * 4) : ld4(ap + cell * p.after.ld + (c4 - 16) * 4);
+      }
+      st4(r_lane + 2 * j * LDH, v);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto bias_init = [&](f32x4 (&acc)[8], const float* bias) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float bia = bias[16 * t + li];
+      acc[t] = f32x4{bia, bia, bia, bia};
+    }
+  };
+  // ---- hoisted x projections (bias included) ---------------------------------------------------------------------
+  f32x4 xz[8], xr[8], xq[8];
+  bias_init(xz, p.w.b_zr);
+  gemm<128, 2, true, 128>(w_z, 4, w_r, 4, a_lane, xf, ws, xz);
+  bias_init(xr, p.w.b_zr + 128);
+  gemm<128, 2, true, 128>(w_r, 4, w_q, 4, a_lane, xf, ws, xr);
+  bias_init(xq, p.w.b_q);
+  gemm<128, 2, true, 128>(w_q, 4, w_z, 0, a_lane, xf, ws, xq);
+
+  f32x4 h[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[t][r] = c_lane[r * LDH + 16 * t];
+
+  auto save_rows = [&](int plane, int it) {  // coalesced copy of the wave's 16 x 128 A region
+    const rsrc_t dst = make_rsrc(p.save + plane * p.plane_stride + it * p.iter_stride + grow0 * 128, row_bytes);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) buf_st4(dst, rl_off + j * 1024, ld4(r_lane + 2 * j * LDH));
+  };
+  auto save_regs = [&](int plane, int it, const f32x4 (&v)[8]) {  // C-layout registers -> [row][128]
+    const rsrc_t dst = make_rsrc(p.save + plane * p.plane_stride + it * p.iter_stride + grow0 * 128, row_bytes);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf_st1(dst, cl_off + (r * 128 + 16 * t) * 4, v[t][r]);
+  };
+
+  for (int it = 0; it < p.T; ++it) {
+    if (SAVE) save_rows(0, it);  // h_in
+    f32x4 z[8], acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z[t] = xz[t];
+    gemm<128, 4, false, 128>(w_z, 0, w_r, 0, a_lane, xf, ws, z);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[t][r] = df_sigmoid_fast(z[t][r]);
+    if (SAVE) save_regs(1, it, z);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = xr[t];
+    gemm<128, 4, false, 128>(w_r, 0, w_q, 0, a_lane, xf, ws, acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = df_sigmoid_fast(acc[t][r]);
+    if (SAVE) save_regs(2, it, acc);
+    // the wave's A region is private and the GEMM's closing barrier is behind us: overwrite h with r * h
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c_lane[r * LDH + 16 * t] = acc[t][r] * h[t][r];
+    __syncthreads();
+    if (SAVE) save_rows(4, it);  // r * h
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = xq[t];
+    const bool last = it + 1 == p.T;
+    if (!last) gemm<128, 4, false, 128>(w_q, 0, w_z, 0, a_lane, xf, ws, acc);
+    else gemm<128, 4, false, 32>(w_q, 0, p.w.w_1, 0, a_lane, xf, ws, acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[t][r] = df_tanh_fast(acc[t][r]);
+        h[t][r] = (1.f - z[t][r]) * h[t][r] + z[t][r] * acc[t][r];
+        c_lane[r * LDH + 16 * t] = h[t][r];
+      }
+    if (SAVE) save_regs(3, it, acc);
+    __syncthreads();
+  }
+  if (SAVE) save_rows(5, 0);  // h_T
+  // ---- MLP head: hid = W1 [h_T | x] + b1 -------------------------------------------------------------------------
+  f32x4 hid[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float bia = p.w.b_1[16 * t + li];
+    hid[t] = f32x4{bia, bia, bia, bia};
+  }
+  gemm<32, 4, false, 32>(p.w.w_1, 0, p.w.w_1, 4, a_lane, xf, ws, hid);
+  gemm<32, 2, true, 32>(p.w.w_1, 4, nullptr, 0, a_lane, xf, ws, hid);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_lane[r * LDH + 16 * t] = df_gelu(hid[t][r]);
+  __syncthreads();
+  if (lane < 48) {
+    const int pt = lane / 3, o = lane - pt * 3;
+    if (wp0 + pt < cnt) {
+      float a = p.w.b_2[o];
+      for (int c = 0; c < 32; ++c) a = fmaf(p.w.w_2[o * 32 + c], Aw[pt * LDH + c], a);
+      p.flow[(grow0 + pt) * 3 + o] = a;
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+// Arguments are validated by the C-ABI entry (df_gru_decoder_fwd in decoder.hip), which dispatches here.
+int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
+                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, void* stream) {
+  Gru3Params p;
+  p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;
+  p.N = N; p.T = num_iters; p.w = wts; p.flow = flow; p.save = save;
+  p.iter_stride = (int64_t)B * N * 128;
+  p.plane_stride = p.iter_stride * num_iters;
+  const dim3 grid((N + 63) / 64, B);
+  if (save) hipLaunchKernelGGL(gru_fwd3_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(gru_fwd3_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

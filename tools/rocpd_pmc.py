@@ -20,7 +20,17 @@ def load(path):
     return out
 
 
+def dump(paths, pattern):
+    """--raw PATTERN db...: every counter summed over dispatches for kernels matching PATTERN (per-call averages)"""
+    for p in paths:
+        for (k, cn), (n, v) in sorted(load(p).items()):
+            if pattern in k:
+                print(f"{k[:50]:50s} {cn:32s} calls {n:4d}  per-call {v / max(n, 1):16.1f}")
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--raw":
+        return dump(sys.argv[3:], sys.argv[2])
     agg = {}
     for p in sys.argv[1:]:
         for (k, cn), (n, v) in load(p).items():
