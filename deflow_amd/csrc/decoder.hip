@@ -274,8 +274,6 @@ bool img64_ok(const df_img& d, int B) {
 
 int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
                        int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, void* stream);
-int df_launch_gru_fwd2(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
-                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, void* stream);
 
 extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
                                   const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts, float* flow,
@@ -287,8 +285,6 @@ extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* co
                  wts.b_2 && df_aligned16(wts.w_zr) && df_aligned16(wts.w_q) && df_aligned16(wts.w_1),
              DF_E_ARG);
   static const bool use_v1 = getenv("DF_GRU_V1") != nullptr;  // first-generation kernel (1 workgroup / CU), for A/B
-  static const bool use_v2 = getenv("DF_GRU_V2") != nullptr;  // second generation (x projection not hoisted), for A/B
-  if (use_v2) return df_launch_gru_fwd2(before, after, coords, offs, counts, B, N, num_iters, wts, flow, save, stream);
   if (!use_v1) return df_launch_gru_fwd3(before, after, coords, offs, counts, B, N, num_iters, wts, flow, save, stream);
   GruFwdParams p;
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;

@@ -3,93 +3,17 @@
 // x (the offset encoding) is the same in every GRU iteration [REF decoder.py:180], so W[:, 128:] x + b of the three
 // gates is computed ONCE per point (registers, 3 x 32 per lane in MFMA C layout) and each iteration only multiplies
 // the 128 h / r*h columns: 54 instead of 72 weight chunks for 4 iterations (-25 % MFMA work; only the fp32 summation
-// order changes -- x part first, then the h part).  Everything else follows decoder2.hip (two workgroups per CU,
+// order changes -- x part first, then the h part).  Layout: two workgroups per CU (70 KB LDS, <= 256 VGPRs each),
 // 16 points per wave, wave-private LDS A operand), except that weight chunks now go L2 -> LDS by DMA
 // (buffer_load ... lds): no staging registers, which is what makes room for the 96 hoisted ones.  The DMA writes
 // each wave's 64 x 16 B linearly, so weight tiles are unpadded [rows][32] with the XOR slot swizzle of the conv
 // kernels applied to the SOURCE column (physical slot = logical slot ^ ((row >> 1) & 7)).
 #include "common.h"
+#include "gemm_dma.h"
 
 namespace {
 
-constexpr int LDH = 132;            // A region pitch (floats): 33 slots of 16 B -> conflict-free b128 rows
-constexpr int BT = 128 * 32;        // one weight buffer: 128 rows x 32 floats, unpadded
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
-}
-__device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
-}
-
-// 32-deep k chunk `chunk` of ROWS weight rows (192 floats apart) -> LDS buffer, all four waves cooperating: one DMA
-// instruction moves 8 rows x 128 B, wave w takes row groups w, w + 4, ...
-template <int ROWS>
-__device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
-  const rsrc_t r = make_rsrc(W, 0x7fffffffu);
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
-                                             (unsigned)((i * 32 * 192 + chunk * 32) * 4), 0, 0);
-}
-
-struct WStream {   // the weight-chunk pipeline state shared by consecutive GEMMs
-  float* Bs;
-  int par, wave;
-  unsigned voff;       // per-lane DMA source offset (row within the group of 8, swizzled 16-B slot)
-  const float* b_lane; // fragment base: row li of buffer 0
-  int bsl[2];          // swizzled slot offsets (floats) of the two 16-wide k groups
-};
-
-// acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
-// registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
-// (Wn, cn, ROWS_NEXT rows) is fetched during the last chunk.
-template <int ROWS, int NCH, bool XA, int ROWS_NEXT>
-__device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const float* __restrict__ Wn, int cn,
-                                     const float* a_lane, const f32x4 (&xf)[4], WStream& ws, f32x4 (&acc)[ROWS / 16]) {
-  constexpr int NPAIR = ROWS / 32;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
-    if (c + 1 < NCH) dma_chunk<ROWS>(W, c0 + c + 1, nb, ws.wave, ws.voff);
-    else if (Wn) dma_chunk<ROWS_NEXT>(Wn, cn, nb, ws.wave, ws.voff);
-    const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
-    f32x4 a0, a1;
-    if (XA) {
-      a0 = xf[2 * c];
-      a1 = xf[2 * c + 1];
-    } else {
-      a0 = ld4(a_lane + c * 32);
-      a1 = ld4(a_lane + c * 32 + 16);
-    }
-    f32x4 nb0 = ld4(bb + ws.bsl[0]), nb1 = ld4(bb + 512 + ws.bsl[0]);
-#pragma unroll
-    for (int j = 0; j < 2 * NPAIR; ++j) {
-      const int g = j / NPAIR, t = 2 * (j % NPAIR);
-      const f32x4 b0 = nb0, b1 = nb1;
-      if (j + 1 < 2 * NPAIR) {
-        const int gn = (j + 1) / NPAIR, tn = 2 * ((j + 1) % NPAIR);
-        nb0 = ld4(bb + tn * 512 + ws.bsl[gn]);
-        nb1 = ld4(bb + (tn + 1) * 512 + ws.bsl[gn]);
-      }
-      const f32x4 a = g ? a1 : a0;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
-        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
-    __syncthreads();                                     // ... and everyone's; the current buffer is free again
-  }
-  ws.par = (ws.par + NCH) & 1;
-}
+using namespace gd;
 
 struct Gru3Params {
   df_img before, after;
@@ -128,16 +52,8 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
   const float* w_q = p.w.w_q;
 
   WStream ws;
-  ws.Bs = Bs; ws.par = 0; ws.wave = wave;
-  {
-    const int l3 = lane >> 3, c4 = lane & 7;
-    const int row = wave * 8 + l3;                      // (row >> 1) & 7 is the same for row + 32 i
-    ws.voff = (unsigned)((row * 192 + ((c4 ^ ((row >> 1) & 7)) * 4)) * 4);
-    ws.b_lane = Bs + li * 32;
-    ws.bsl[0] = ((lq) ^ ((li >> 1) & 7)) * 4;
-    ws.bsl[1] = ((4 + lq) ^ ((li >> 1) & 7)) * 4;
-  }
-  dma_chunk<128>(w_z, 4, Bs, wave, ws.voff);   // first chunk of the x projection
+  wstream_init(ws, Bs);
+  dma_chunk<128, 192>(w_z, 4, Bs, wave, ws.voff<192>());   // first chunk of the x projection
 
   // ---- x = offset encoder -> A region (temporarily) -> register fragments ------------------------------------------
   f32x4 xf[4];

@@ -1,0 +1,107 @@
+// Weight-streaming GEMM of the point-decoder kernels, LDS-DMA form (see decoder3.hip for the design notes):
+// a workgroup of 4 waves multiplies each wave's private 16-row A operand by weight rows streamed L2 -> LDS in 32-deep
+// k chunks with buffer_load ... lds, double buffered and one chunk ahead -- also across consecutive GEMMs.
+// v_mfma_f32_16x16x4_f32 with the k permutation k = 16 g + 4 (lane >> 4) + s, so every fragment is one ds_read_b128.
+#pragma once
+#include "common.h"
+
+namespace gd {
+
+constexpr int LDH = 132;            // A region pitch (floats): 33 slots of 16 B -> conflict-free b128 rows
+constexpr int BT = 128 * 32;        // one weight buffer: 128 rows x 32 floats, unpadded
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+
+// 32-deep k chunk `chunk` of ROWS weight rows (LDW floats apart) -> LDS buffer, all four waves cooperating: one DMA
+// instruction moves 8 rows x 128 B, wave w takes row groups w, w + 4, ...  voff = WStream::voff<LDW>.
+template <int ROWS, int LDW>
+__device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
+  const rsrc_t r = make_rsrc(W, 0x7fffffffu);
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
+                                             (unsigned)((i * 32 * LDW + chunk * 32) * 4), 0, 0);
+}
+
+struct WStream;
+__device__ __forceinline__ void wstream_init(WStream& ws, float* Bs);
+
+struct WStream {   // the weight-chunk pipeline state shared by consecutive GEMMs
+  float* Bs;
+  int par, wave;
+  unsigned vrow, vslot; // per-lane DMA source: row within the first 32 (wave * 8 + lane / 8), swizzled slot byte offset
+  template <int LDW>
+  __device__ __forceinline__ unsigned voff() const { return vrow * (unsigned)(LDW * 4) + vslot; }
+  const float* b_lane; // fragment base: row li of buffer 0
+  int bsl[2];          // swizzled slot offsets (floats) of the two 16-wide k groups
+};
+
+// acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
+// registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
+// (Wn, cn, ROWS_NEXT rows) is fetched during the last chunk.
+template <int ROWS, int NCH, bool XA, int ROWS_NEXT, int LDW = 192, int LDW_NEXT = 192>
+__device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const float* __restrict__ Wn, int cn,
+                                     const float* a_lane, const f32x4 (&xf)[4], WStream& ws, f32x4 (&acc)[ROWS / 16]) {
+  constexpr int NPAIR = ROWS / 32;
+  auto chunk = [&](int c, const f32x4 a0, const f32x4 a1) {
+    float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
+    if (c + 1 < NCH) dma_chunk<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.voff<LDW>());
+    else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.voff<LDW_NEXT>());
+    const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
+    f32x4 nb0 = ld4(bb + ws.bsl[0]), nb1 = ld4(bb + 512 + ws.bsl[0]);
+#pragma unroll
+    for (int j = 0; j < 2 * NPAIR; ++j) {
+      const int g = j / NPAIR, t = 2 * (j % NPAIR);
+      const f32x4 b0 = nb0, b1 = nb1;
+      if (j + 1 < 2 * NPAIR) {
+        const int gn = (j + 1) / NPAIR, tn = 2 * ((j + 1) % NPAIR);
+        nb0 = ld4(bb + tn * 512 + ws.bsl[gn]);
+        nb1 = ld4(bb + (tn + 1) * 512 + ws.bsl[gn]);
+      }
+      const f32x4 a = g ? a1 : a0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc[t + 1], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
+    __syncthreads();                                     // ... and everyone's; the current buffer is free again
+  };
+  if constexpr (XA) {
+    static_assert(NCH == 2, "the x operand is two chunks");
+    chunk(0, xf[0], xf[1]);
+    chunk(1, xf[2], xf[3]);
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) chunk(c, ld4(a_lane + c * 32), ld4(a_lane + c * 32 + 16));
+  }
+  ws.par = (ws.par + NCH) & 1;
+}
+
+__device__ __forceinline__ void wstream_init(WStream& ws, float* Bs) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  ws.Bs = Bs;
+  ws.par = 0;
+  ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l3 = lane >> 3, c4 = lane & 7;
+  const int row = ws.wave * 8 + l3;                 // (row >> 1) & 7 is the same for row + 32 i
+  ws.vrow = (unsigned)row;
+  ws.vslot = (unsigned)((c4 ^ ((row >> 1) & 7)) * 16);
+  ws.b_lane = Bs + li * 32;
+  ws.bsl[0] = ((lq) ^ ((li >> 1) & 7)) * 4;
+  ws.bsl[1] = ((4 + lq) ^ ((li >> 1) & 7)) * 4;
+}
+
+}  // namespace gd

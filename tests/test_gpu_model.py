@@ -285,14 +285,16 @@ def test_edge_cases_empty_ragged_and_big_grid(dev):
     assert torch.equal(f, r2["flow"][0])
 
 
-@pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"}])
+@pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"},
+                                 {"DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1"}, {"DF_SIDE_STREAM": "1"}])
 def test_alternate_kernel_paths(env):
-    """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors) and the all-DMA wgrad variants stay correct:
-    re-run the conv / ConvWithNorms / train-step parity tests in a subprocess with the dispatch override"""
+    """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors), the all-DMA wgrad variants, the
+    first-generation GRU kernels with unfused gate weight gradients, and the side-stream weight-gradient schedule stay
+    correct: re-run the conv / ConvWithNorms / decoder / train-step parity tests in a subprocess with the override"""
     import subprocess
     import sys
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_gpu_kernels.py", "tests/test_gpu_model.py",
-                        "-k", "conv or cwn or train_step_vs_oracle", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
+                        "-k", "conv or cwn or gru or train_step_vs_oracle", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
