@@ -301,11 +301,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 constexpr unsigned DMA_BAD = 0xFFFFFFFFu - (8u << 20);  // + soffset (< 8 MB) never wraps, always out of range
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int RA = BM / 32, RB = BN / 32;
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NW = WM * WN, RP = 8 * NW;       // waves; tile rows one DMA pass of the whole workgroup covers
+  constexpr int RA = BM / RP, RB = BN / RP;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");  // 16 waves (32 x 32 wave tiles) measured 1-2 % slower than 8
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                     // [2][BM][LDT]
   float* Bs = lds + 2 * BM * LDT;      // [2][BN][LDT]
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
   int ay[RA], ax[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RP * i;
     ay[i] = ax[i] = -(1 << 28);
     aoff[i] = DMA_BAD;
     if (m < m_end) {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + 32 * i) * p.ks * p.ks * p.K + c4s * 4) * 4);
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + RP * i) * p.ks * p.ks * p.K + c4s * 4) * 4);
 
   int l_kc = 0, l_iky = 0, l_ikx = 0;
   auto load_stage = [&](int buf) {
@@ -389,11 +390,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const bool ok = (unsigned)(ay[i] + ty) < (unsigned)hx && (unsigned)(ax[i] + tx) < (unsigned)wx;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * 32 * LDT), 16, ok ? aoff[i] : DMA_BAD, soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * RP * LDT), 16, ok ? aoff[i] : DMA_BAD, soffA, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 32 * LDT), 16, boff[i], soffB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * RP * LDT), 16, boff[i], soffB, 0, 0);
     if (++l_kc == KC) {
       l_kc = 0;
       if (++l_ikx == nkx) {
@@ -473,6 +474,24 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
   else
     hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// 8-wave forms (512 threads; wave tile 64 x 32 resp. 32 x 32, 32 / 16 accumulator registers): the same LDS footprint
+// and DMA traffic as the 4-wave kernels but twice the waves per SIMD to cover each other's barrier and DMA waits
+// (measured +2..4 % on the 128 x 128 tile).  DMA path only.
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1085,9 +1104,17 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
     case 64064: return launch_conv<64, 64, 2, 2>(p, s);
-    case 128128: return launch_conv<128, 128, 2, 2>(p, s);
+    case 128128: {
+      static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
+      if ((w8 & 1) && p.x_bytes) return launch_conv_w8<128, 128, 2, 4>(p, s);
+      return launch_conv<128, 128, 2, 2>(p, s);
+    }
     case 256064: return launch_conv<256, 64, 4, 1>(p, s);
-    default: return launch_conv<128, 64, 2, 2>(p, s);
+    default: {
+      static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
+      if ((w8 & 2) && p.x_bytes) return launch_conv_w8<128, 64, 4, 2>(p, s);
+      return launch_conv<128, 64, 2, 2>(p, s);
+    }
   }
 }
 

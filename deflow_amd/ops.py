@@ -2,6 +2,8 @@
 torch's current stream with raw device pointers; nothing here computes with torch ops."""
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -78,6 +80,12 @@ def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int)
     bm, bn = v // 1000, v % 1000
     wm, wn = {(128, 32): (4, 1), (256, 64): (4, 1)}.get((bm, bn), (2, 2))
     kern = "conv_dma_kernel" if call("df_conv2d_last_dma") else "conv_kernel"
+    if kern == "conv_dma_kernel":  # 8-wave forms of the two big tiles (DF_CONV_W8 bit 0 / bit 1, default both)
+        w8 = int(os.environ.get("DF_CONV_W8", "3"))
+        if (bm, bn) == (128, 128) and (w8 & 1):
+            wm, wn = 2, 4
+        elif (bm, bn) == (128, 64) and (w8 & 2):
+            wm, wn = 4, 2
     return f"{kern}<{bm},{bn},{wm},{wn}>"
 
 
