@@ -63,6 +63,7 @@ _SIGS = {
     "df_bn_gelu_bwd_apply": [DfImg, P, P, P, I, P, P, I, P],
     "df_colsum_partial": [DfImg, P, I, P],
     "df_colsum_finalize": [P, I, I, I, P, I, P],
+    "df_colsum_stage": [P, I, I, I, P, P],
     "df_weight_transpose": [P, P, I, I, I, P],
     "df_conv2d_wgrad_splits": [DfImg, DfImg, I, I],
     "df_conv2d_wgrad": [DfImg, DfImg, I, I, I, P, I, P, I, P, P],

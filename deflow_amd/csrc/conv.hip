@@ -1109,7 +1109,11 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
       if ((w8 & 1) && p.x_bytes) return launch_conv_w8<128, 128, 2, 4>(p, s);
       return launch_conv<128, 128, 2, 2>(p, s);
     }
-    case 256064: return launch_conv<256, 64, 4, 1>(p, s);
+    case 256064: {
+      static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
+      if ((w8 & 4) && p.x_bytes) return launch_conv_w8<256, 64, 4, 2>(p, s);
+      return launch_conv<256, 64, 4, 1>(p, s);
+    }
     default: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
       if ((w8 & 2) && p.x_bytes) return launch_conv_w8<128, 64, 4, 2>(p, s);

@@ -277,14 +277,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(df_img x, float* __
   if (rp.row_lane == 0) st4(partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
 }
 
+// gridDim.y > 1: row group blockIdx.y of the partials is summed into out[blockIdx.y][total] (first stage of a two-stage
+// reduction when there are tens of thousands of partial rows)
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int total,
                                                                float* out, int accumulate) {
   __shared__ double red[32][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cl;
+  const int b0 = (int)((int64_t)nblk * blockIdx.y / gridDim.y), b1 = (int)((int64_t)nblk * (blockIdx.y + 1) / gridDim.y);
+  out += (int64_t)blockIdx.y * total;
   double s = 0.0;
   if (i < total)
-    for (int b = tl; b < nblk; b += 32) s += (double)partial[(int64_t)b * total + i];
+    for (int b = b0 + tl; b < b1; b += 32) s += (double)partial[(int64_t)b * total + i];
   red[tl][cl] = s;
   __syncthreads();
   if (tl == 0 && i < total) {
@@ -475,6 +479,14 @@ extern "C" int df_colsum_finalize(const float* partial, int nblk, int C, int nva
   const int total = C * nvals;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 31) / 32), dim3(1024), 0,
                      reinterpret_cast<hipStream_t>(stream), partial, nblk, total, out, accumulate);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_colsum_stage(const float* partial, int nblk, int total, int groups, float* out, void* stream) {
+  DF_REQUIRE(partial && out && nblk > 0 && total > 0 && groups > 0 && groups <= nblk, DF_E_ARG);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((total + 31) / 32, groups), dim3(1024), 0,
+                     reinterpret_cast<hipStream_t>(stream), partial, nblk, total, out, 0);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -138,7 +138,12 @@ class ConvGRUDecoder(nn.Module):
         call("df_gru_decoder_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
              ptr(dpre1), ptr(xbuf), ptr(bias_partial), s)
         bias_g = torch.empty(772, **f32)
-        call("df_colsum_finalize", ptr(bias_partial), nblocks, 772, 1, ptr(bias_g), 0, s)
+        if nblocks >= 2048:  # tens of thousands of per-workgroup rows: two-stage column sum
+            staged = torch.empty(64, 772, **f32)
+            call("df_colsum_stage", ptr(bias_partial), nblocks, 772, 64, ptr(staged), s)
+            call("df_colsum_finalize", ptr(staged), 64, 772, 1, ptr(bias_g), 0, s)
+        else:
+            call("df_colsum_finalize", ptr(bias_partial), nblocks, 772, 1, ptr(bias_g), 0, s)
         # image gradients: per-cell segmented sum (no atomics)
         ncell = dbefore.h * dbefore.w
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,

@@ -141,6 +141,9 @@ int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const fl
 /* generic column sums: out[c] = sum over partial rows (used for conv bias grads etc.) */
 int df_colsum_partial(df_img x, float* partial, int nblk, void* stream);
 int df_colsum_finalize(const float* partial, int nblk, int C, int nvals, float* out, int accumulate, void* stream);
+/* first stage for very many partial rows: out[g][total] = sum of row group g (rows split evenly into `groups`);
+ * finish with df_colsum_finalize(out, groups, ...) */
+int df_colsum_stage(const float* partial, int nblk, int total, int groups, float* out, void* stream);
 /* weight layout helpers: wt[ci][k][co] = w[co][k][ci] */
 int df_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, void* stream);
 /* dW[co][k][ci] (row stride ldw elements between co rows... taps*cin when dense) = sum_p dy[p][co] x[p*s+k-pad][ci].
