@@ -21,9 +21,12 @@ class GradDict(dict):
         return super().get(p.data_ptr())
 
 
-def _grads_for(params: List[torch.Tensor], grads: "GradDict"):
+def _grads_for(params: List[torch.Tensor], grads: "GradDict", sink=None):
     out = []
     for p in params:
+        if sink is not None and sink.was_delivered(p):   # already copied into the gradient arena (optim.GradSink)
+            out.append(None)
+            continue
         g = grads.lookup(p)
         if g is not None and g.shape != p.shape:
             g = g.reshape(p.shape)
@@ -78,6 +81,10 @@ class DeFlowFn(torch.autograd.Function):
         bstar = st["bstar"]
         if ops.SIDE is None and os.environ.get("DF_SIDE_STREAM") == "1":
             ops.SIDE = ops.SideStream(bstar.device)
+        sink = getattr(model, "_grad_sink", None)
+        # phase callback: hand finished gradients to the arena / the overlapped all-reduce (not while weight gradients
+        # are still in flight on the side stream)
+        phase = (lambda params: sink.deliver(params, grads)) if (sink is not None and ops.SIDE is None) else (lambda params: None)
         B, H, W, _ = bstar.shape
         dev = bstar.device
         dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
@@ -86,8 +93,9 @@ class DeFlowFn(torch.autograd.Function):
         model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
                                 before=img(bstar), after=img(st["v"]))
         st["sv"] = None
+        phase(model.head.parameters())
         # UNet: accumulates its own d(bstar) into the same buffer
-        model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads)
+        model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads, phase)
         st["tape"] = None
         # pillar feature net of both clouds (shared weights -> accumulate)
         emb = model.embedder
@@ -96,8 +104,10 @@ class DeFlowFn(torch.autograd.Function):
         grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
         if ops.SIDE is not None:
             ops.SIDE.join()
+        if sink is not None:
+            sink.deliver(ctx.params, grads)   # the pillar feature net, and everything else if phases were off
         ctx.state = None
-        return (None, None, None) + _grads_for(ctx.params, grads)
+        return (None, None, None) + _grads_for(ctx.params, grads, sink)
 
 
 class DeflowLossFn(torch.autograd.Function):

@@ -178,8 +178,8 @@ class FastFlow3DUNet(nn.Module):
             with ops.SIDE.fork():
                 wgrad()
 
-    def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict
-                     ) -> torch.Tensor:
+    def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict,
+                     phase=None) -> torch.Tensor:
         """Consumes the tape of run(train=True).  dv [B,H,W,64].  Returns d(bstar) [B,H,W,64] (added to `dbstar`
         if given).  Parameter gradients go to `grads` {param: tensor}."""
         B, H, W, _ = bstar.shape
@@ -241,6 +241,9 @@ class FastFlow3DUNet(nn.Module):
         dL = hold(torch.empty(B, H // 4, W // 4, 256, **f32))   # d(lstar)
         dR = hold(torch.empty(B, H // 8, W // 8, 512, **f32))   # d(rstar)
         upsample_skip_bwd(dS, img(dR), False, img(dL), False)
+        if phase is not None:   # the four decoder steps are complete: their gradients can leave (optim.GradSink)
+            phase([p for m in (self.decoder_step1, self.decoder_step2, self.decoder_step3, self.decoder_step4)
+                   for p in m.parameters()])
         # encoder, stages 3..1; dz of a stage's last layer lives in the concatenated gradient buffer
         stage_in_grads = {3: (dL, 128), 2: (dF, 64), 1: (dbstar, 32)}
         dz = img_pair(dR, 256)
@@ -259,6 +262,8 @@ class FastFlow3DUNet(nn.Module):
                     dx, acc = img_pair(buf, c), True
                 self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False)
                 dz = dx
+            if phase is not None:
+                phase(stage.parameters())
         assert not tape
         return dbstar
 

@@ -37,13 +37,38 @@ def _worker(rank, world, port, q):
     others = [torch.randn(tr.flat.numel, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
     want_mean = torch.stack(others).sum(0) * scale
     err = float((tr.flat.grad * scale - want_mean).abs().max())
+    # bucketed delivery (optim.GradSink): phase-wise copies into the arena + async all-reduce of each contiguous run,
+    # including a phase that leaves a hole (delivered later) -- must equal one all-reduce of everything
+    from deflow_amd.autograd import GradDict
+    tr.flat.zero_grad()
+    tr.sink.begin()
+    gd, want_sink = GradDict(), torch.zeros(tr.flat.numel)
+    for r in range(world):
+        gr = torch.Generator().manual_seed(1000 + r)
+        for n, p in tr.flat.named:
+            t = torch.randn(p.shape, generator=gr)
+            if r == rank:
+                gd[p] = t
+            off, k = tr.flat.slots[n]
+            want_sink[off:off + k] += (t.permute(0, 2, 3, 1) if t.dim() == 4 else t).reshape(-1)
+    bb = model.backbone
+    hole = bb.encoder_step_2[2].conv.weight
+    tr.sink.deliver(model.head.parameters(), gd)
+    tr.sink.deliver([p for m in (bb.decoder_step1, bb.decoder_step2, bb.decoder_step3, bb.decoder_step4) for p in m.parameters()], gd)
+    for stage in (bb.encoder_step_3, bb.encoder_step_2, bb.encoder_step_1):
+        tr.sink.deliver([p for p in stage.parameters() if p is not hole], gd)
+    n_works = len(tr.sink.works)
+    tr.sink.deliver(list(model.parameters()), gd)   # the embedder and the hole
+    tr.reduce_gradients()
+    sink_err = float((tr.flat.grad - want_sink).abs().max())
+    all_delivered = all(tr.sink.was_delivered(p) for p in model.parameters())
     # parameter views see the arena; gradient views alias the gradient arena
     w = model.backbone.decoder_step4.weight
     alias_ok = w.grad.data_ptr() >= tr.flat.grad.data_ptr() and w.data_ptr() >= tr.flat.param.data_ptr()
     # shards: the two ranks draw different frame pairs
     seed = Trainer.shard_seed(20240116, rank, 2)
     b = synth_batch(2, 64, seed=seed, grid_hw=(64, 64))
-    q.put((rank, p_sum, err, scale, alias_ok, float(b["pc0"][0, 0, 0]), float(local.abs().sum())))
+    q.put((rank, p_sum, err, scale, alias_ok, float(b["pc0"][0, 0, 0]), float(local.abs().sum()), sink_err, all_delivered, n_works))
     dist.destroy_process_group()
 
 
@@ -58,7 +83,9 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, e0, sc0, a0, x0, l0), (r1, s1, e1, sc1, a1, x1, l1) = res
+    (r0, s0, e0, sc0, a0, x0, l0, se0, ad0, nw0), (r1, s1, e1, sc1, a1, x1, l1, se1, ad1, nw1) = res
+    assert se0 < 1e-5 and se1 < 1e-5 and ad0 and ad1, "bucketed gradient delivery must equal one all-reduce"
+    assert nw0 == nw1 and nw0 >= 6, "head, UNet decoder and the encoder stages go out as separate overlapped buckets"
     assert s0 == s1, "rank 1 must hold rank 0's parameters after the broadcast"
     assert e0 < 1e-5 and e1 < 1e-5 and sc0 == sc1 == 0.5
     assert a0 and a1
