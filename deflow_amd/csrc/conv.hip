@@ -869,6 +869,127 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
 #endif
 }
 
+// 3x3 stride-1 weight gradient with 12-wave workgroups: wave = (32 co x 32 ci quadrant) x kernel row ky, 3 taps =
+// 48 accumulator registers (79 VGPRs) instead of 4 waves that each hold all 9 taps (144 accumulators, 191 VGPRs, two
+// waves per SIMD at most).  The three ky groups share every dY / X tile.  D = 2 (default): double-buffered, two
+// workgroups per CU = six waves per SIMD -- measured +1.5..5 % over the 4-wave kernel (132 vs 126 TFLOP/s on the
+// largest layers); D = 3: one workgroup per CU with a 3-deep ring -- measured 5 % SLOWER (one barrier domain per CU).
+template <int P, int D>
+__global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int XW = P + 2, LC = 64;
+  constexpr int YSZ = P * LC, NXI = (3 * XW + 3) / 4, NYI = P / 4, XSZ = NXI * 4 * LC, STG = YSZ + XSZ;
+  constexpr int NOPS = NYI + NXI;                 // 1-KB DMA ops per stage (34), dealt round-robin to the 12 waves
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int quad = wave & 3, ky = wave >> 2;
+  const int wci = quad & 1, wco = quad >> 1;
+  const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
+  const bool wave_active = (ci0 + wci * 32) < p.K;
+  const bool do_bias = p.bias_ws && blockIdx.x == 0;
+  float bsum = 0.f;
+  const int lp = lane >> 4, lc4 = lane & 15;
+  const int my_ops = (NOPS - wave + 11) / 12;     // 3 for waves 0..9, 2 for waves 10, 11
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+  const bool ci_ok = ci0 + lc4 * 4 < p.K;
+
+  auto issue = [&](int ch, int buf) {
+    const WgChunk c = wg_chunk(p, ch, P);
+    float* dYs = lds + buf * STG;
+    float* Xs = dYs + YSZ;
+    const int64_t yb = df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0 + lc4 * 4;
+    const int64_t xb = df_img_base(p.x, c.n) + ci0 + lc4 * 4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = wave + 12 * i;
+      if (j < NYI) {
+        const int px = 4 * j + lp;
+        const bool ok = c.ox0 + px < wy;
+        const unsigned vo = ok ? (unsigned)((yb + (int64_t)(c.ox0 + px) * p.dy.ld) * 4) : DMA_BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + j * 256), 16, vo, 0, 0, 0);
+      } else if (j < NOPS) {
+        const int k = j - NYI;
+        const int q = 4 * k + lp;
+        const int qy = q / XW, xi = q - qy * XW;
+        const int iy = c.oy + qy - p.pad, ix = c.ox0 + xi - p.pad;
+        const bool ok = ci_ok && qy < 3 && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx;
+        const unsigned vo = ok ? (unsigned)((xb + ((int64_t)iy * wx + ix) * p.x.ld) * 4) : DMA_BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + k * 256), 16, vo, 0, 0, 0);
+      }
+    }
+  };
+
+  static_assert(D == 2 || D == 3, "ring depth");
+  if (nst > 0) issue(c_begin, 0);
+  if (D == 3 && nst > 1) issue(c_begin + 1, 1);
+  for (int i = 0; i < nst; ++i) {
+    // this wave's DMA share of stage i has landed (D = 3: at most the ops of stage i + 1 still in flight) ...
+    if (D == 3 && i + 1 < nst) {
+      if (my_ops == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D
+    if (i + D - 1 < nst) issue(c_begin + i + D - 1, (i + D - 1) % D);
+    const float* dyb = lds + (i % D) * STG;
+    const float* xbuf = dyb + YSZ;
+    if (wave_active) {
+#pragma unroll 4
+      for (int ks = 0; ks < P / 2; ++ks) {
+        const int px = 2 * ks + kh;
+        const float a = dyb[px * LC + wco * 32 + li];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float b = xbuf[(ky * XW + px + kx) * LC + wci * 32 + li];
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kx], 0, 0, 0);
+        }
+      }
+    }
+    if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6 (8 groups of 4 pixels; combined after the loop)
+#pragma unroll
+      for (int j = 0; j < P / 8; ++j) bsum += dyb[((tid >> 6) * (P / 8) + j) * LC + (tid & 63)];
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    if (tid < 512) lds[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += lds[64 * w + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t;
+    }
+  }
+  if (wave_active) {
+    float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = acc[kx][e];
+      }
+  }
+#endif
+}
+
 template <int CIT>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -968,11 +1089,11 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
 }
 
 template <typename K>
-static int launch_wgrad_dma(K kern, dim3 grid, size_t lds_bytes, hipStream_t s, const WgradParams& p) {
+static int launch_wgrad_dma(K kern, dim3 grid, size_t lds_bytes, hipStream_t s, const WgradParams& p, int threads = 256) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1125,15 +1246,19 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
 static inline bool wgrad_use_1x1(int ksize, int cout) { return ksize == 1 && (cout % 128) == 0; }
 static inline int wgrad_cit(int cin) { return cin >= 128 ? 128 : 64; }
 static inline int wgrad_chunk(int ksize) { (void)ksize; return 32; }  // 128-pixel chunks for 1x1 measured slower
+static inline int wgrad_ring_depth(int ksize, int stride) {   // 12-wave kernel: 0 = off, 3 = one workgroup per CU with a
+  static const int ring = getenv("DF_WGRAD_RING") ? atoi(getenv("DF_WGRAD_RING")) : 2;   // 3-deep ring, 2 = two per CU
+  return (ksize == 3 && stride == 1) ? ring : 0;
+}
 
 extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
-  (void)stride;
   const int P = wgrad_chunk(ksize);
   const int tiles = wgrad_use_1x1(ksize, dy.c) ? ((x.c + wgrad_cit(x.c) - 1) / wgrad_cit(x.c)) * (dy.c / 128)
                                                : ((x.c + 63) / 64) * (dy.c / 64);
   const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
   static const int target = getenv("DF_WGRAD_BLOCKS") ? atoi(getenv("DF_WGRAD_BLOCKS")) : 512;  // = one resident round at 2 workgroups per CU (1024: +0.6 ms of partial-sum traffic, 768: a ragged second round)
-  int64_t splits = (target + tiles - 1) / tiles;
+  const int tgt = wgrad_ring_depth(ksize, stride) == 3 ? target / 2 : target;   // one resident workgroup per CU
+  int64_t splits = (tgt + tiles - 1) / tiles;
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;
   // make every split non-empty
@@ -1188,6 +1313,11 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
     }
     auto bytes = [](int ks_, int st_) { const int xw = 31 * st_ + ks_; return (size_t)2 * (32 * 64 + ((ks_ * xw + 3) / 4) * 4 * 64) * 4; };
     if (ksize == 1) return launch_wgrad_dma(wgrad_dma_kernel<1, 1, 32>, grid, bytes(1, 1), s, p);
+    const size_t ring_stage = (size_t)(32 * 64 + ((3 * 34 + 3) / 4) * 4 * 64) * 4;
+    if (stride == 1 && wgrad_ring_depth(ksize, stride) == 3)
+      return launch_wgrad_dma(wgrad3_ring_kernel<32, 3>, grid, 3 * ring_stage, s, p, 768);
+    if (stride == 1 && wgrad_ring_depth(ksize, stride) == 2)
+      return launch_wgrad_dma(wgrad3_ring_kernel<32, 2>, grid, 2 * ring_stage, s, p, 768);
     if (stride == 1) return launch_wgrad_dma(wgrad_dma_kernel<3, 1, 32>, grid, bytes(3, 1), s, p);
     return launch_wgrad_dma(wgrad_dma_kernel<3, 2, 32>, grid, bytes(3, 2), s, p);
   }

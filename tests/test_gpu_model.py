@@ -285,7 +285,7 @@ def test_edge_cases_empty_ragged_and_big_grid(dev):
     assert torch.equal(f, r2["flow"][0])
 
 
-@pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"},
+@pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"}, {"DF_WGRAD_RING": "0", "DF_CONV_W8": "0"},
                                  {"DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1"}, {"DF_SIDE_STREAM": "1"}])
 def test_alternate_kernel_paths(env):
     """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors), the all-DMA wgrad variants, the
