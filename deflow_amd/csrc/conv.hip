@@ -874,10 +874,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
 // waves per SIMD at most).  The three ky groups share every dY / X tile.  D = 2 (default): double-buffered, two
 // workgroups per CU = six waves per SIMD -- measured +1.5..5 % over the 4-wave kernel (132 vs 126 TFLOP/s on the
 // largest layers); D = 3: one workgroup per CU with a 3-deep ring -- measured 5 % SLOWER (one barrier domain per CU).
-template <int P, int D>
+template <int P, int D, int STRIDE = 1>
 __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int XW = P + 2, LC = 64;
+  constexpr int XW = (P - 1) * STRIDE + 3, LC = 64;
   constexpr int YSZ = P * LC, NXI = (3 * XW + 3) / 4, NYI = P / 4, XSZ = NXI * 4 * LC, STG = YSZ + XSZ;
   constexpr int NOPS = NYI + NXI;                 // 1-KB DMA ops per stage (34), dealt round-robin to the 12 waves
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
         const int k = j - NYI;
         const int q = 4 * k + lp;
         const int qy = q / XW, xi = q - qy * XW;
-        const int iy = c.oy + qy - p.pad, ix = c.ox0 + xi - p.pad;
+        const int iy = c.oy * STRIDE + qy - p.pad, ix = c.ox0 * STRIDE + xi - p.pad;
         const bool ok = ci_ok && qy < 3 && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx;
         const unsigned vo = ok ? (unsigned)((xb + ((int64_t)iy * wx + ix) * p.x.ld) * 4) : DMA_BAD;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + k * 256), 16, vo, 0, 0, 0);
@@ -934,6 +934,7 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
   };
 
   static_assert(D == 2 || D == 3, "ring depth");
+  static_assert(NOPS <= 36 && P % 8 == 0, "at most three DMA ops per wave and stage");
   if (nst > 0) issue(c_begin, 0);
   if (D == 3 && nst > 1) issue(c_begin + 1, 1);
   for (int i = 0; i < nst; ++i) {
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
         const float a = dyb[px * LC + wco * 32 + li];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float b = xbuf[(ky * XW + px + kx) * LC + wci * 32 + li];
+          const float b = xbuf[(ky * XW + px * STRIDE + kx) * LC + wci * 32 + li];
           acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kx], 0, 0, 0);
         }
       }
@@ -1245,14 +1246,16 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
 
 static inline bool wgrad_use_1x1(int ksize, int cout) { return ksize == 1 && (cout % 128) == 0; }
 static inline int wgrad_cit(int cin) { return cin >= 128 ? 128 : 64; }
-static inline int wgrad_chunk(int ksize) { (void)ksize; return 32; }  // 128-pixel chunks for 1x1 measured slower
 static inline int wgrad_ring_depth(int ksize, int stride) {   // 12-wave kernel: 0 = off, 3 = one workgroup per CU with a
   static const int ring = getenv("DF_WGRAD_RING") ? atoi(getenv("DF_WGRAD_RING")) : 2;   // 3-deep ring, 2 = two per CU
+  // stride 2 (three small layers) measured slower with this form (16-pixel chunks, idle ci waves at Cin = 32): 3.06 vs
+  // 2.41 ms per step for the register-prefetch kernel, which therefore keeps them
   return (ksize == 3 && stride == 1) ? ring : 0;
 }
+static inline int wgrad_chunk(int ksize, int stride) { (void)ksize; (void)stride; return 32; }  // output pixels per chunk
 
 extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
-  const int P = wgrad_chunk(ksize);
+  const int P = wgrad_chunk(ksize, stride);
   const int tiles = wgrad_use_1x1(ksize, dy.c) ? ((x.c + wgrad_cit(x.c) - 1) / wgrad_cit(x.c)) * (dy.c / 128)
                                                : ((x.c + 63) / 64) * (dy.c / 64);
   const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + P - 1) / P);
@@ -1278,15 +1281,6 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1;
   p.bias_ws = bias_ws;
   p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
-  const int P = wgrad_chunk(ksize);
-  p.chunks_per_row = (dy.w + P - 1) / P;
-  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
-  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
-  p.total_chunks = (int)chunks;
-  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
-  DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
-  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   p.x_bytes = p.dy_bytes = 0;
   {
     static const int no_dma = getenv("DF_CONV_NO_DMA") ? atoi(getenv("DF_CONV_NO_DMA")) : 0;
@@ -1300,6 +1294,15 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
       p.dy_bytes = (unsigned)ey;
     }
   }
+  const int P = wgrad_chunk(ksize, stride);
+  p.chunks_per_row = (dy.w + P - 1) / P;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // Measured on MI355X (bs16 step): the DMA form wins for 3x3 stride 1 (124.7 -> 128.4 TFLOP/s); for 1x1 and stride 2
   // the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step; s2 needs 116 KB LDS = 1 workgroup/CU), so
   // those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere (A/B runs, tests).

@@ -167,9 +167,11 @@ def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
     return wt
 
 
-def _wgrad3_name() -> str:
-    ring = int(os.environ.get("DF_WGRAD_RING", "2"))   # mirrors df_conv2d_wgrad's dispatch for 3x3 stride 1
-    return f"wgrad3_ring_kernel<32,{ring}>" if ring in (2, 3) else "wgrad_dma_kernel<3,1,32>"
+def _wgrad3_name(stride: int) -> str:
+    ring = int(os.environ.get("DF_WGRAD_RING", "2"))   # mirrors df_conv2d_wgrad's dispatch for 3x3 kernels
+    if stride == 2:
+        return "wgrad_kernel<3,2,32>"
+    return f"wgrad3_ring_kernel<32,{ring},1>" if ring in (2, 3) else "wgrad_dma_kernel<3,1,32>"
 
 
 def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld_co: Optional[int] = None,
@@ -191,7 +193,7 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     if prof is not None:
         e1.record()
         name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
-                else (_wgrad3_name() if (ks == 3 and stride == 1) else f"wgrad_kernel<{ks},{stride},32>"))
+                else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"
         prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
