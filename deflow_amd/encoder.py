@@ -117,11 +117,15 @@ class DynamicEmbedder(nn.Module):
             call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                  bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
             bn.num_batches_tracked.add_(B)
+            ops.PARAM_GEN[0] += 1
             bn_stride = 128
         else:
-            invstd = torch.rsqrt(bn.running_var + bn.eps)
-            scale = bn.weight.detach() * invstd
-            bn_ss = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, invstd]).contiguous()
+            c = getattr(bn, "_df_fold_ss", None)
+            fold = ops.folded_bn(bn)
+            if c is None or c[0] is not fold[0]:   # re-stack only when the fold was recomputed
+                c = (fold[0], torch.stack(list(fold)).contiguous())
+                bn._df_fold_ss = c
+            bn_ss = c[1]
             bn_stride = 0
         nbc = max(1, min(2048, (N + 31) // 32))
         call("df_pfn_canvas", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,

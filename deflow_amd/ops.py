@@ -109,7 +109,28 @@ def conv_tile_m(rows_per_group: int, cout: int) -> int:
     return call("df_conv2d_tile_m", rows_per_group, cout)
 
 
+# Folded eval-mode BatchNorm (scale, shift, mean, invstd) is cached per module: five tiny torch launches per layer and
+# forward otherwise -- 90 of the 175 launches of a B=1 inference.  The cache key carries the tensors' version counters
+# plus PARAM_GEN, which every HIP-side writer that bypasses autograd's counters bumps (Adam on the flat arena, the
+# running-statistics update of a training forward).
+PARAM_GEN = [0]
+
+
+def folded_bn(bn) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    key = (PARAM_GEN[0], bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_var.data_ptr(), bn.eps)
+    c = getattr(bn, "_df_fold", None)
+    if c is None or c[0] != key:
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight.detach() * invstd).contiguous()
+        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        c = (key, scale, shift, bn.running_mean, invstd)
+        bn._df_fold = c
+    return c[1], c[2], c[3], c[4]
+
+
 def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss):
+    PARAM_GEN[0] += 1  # running statistics change under any cached eval-mode fold
     splits = min(64, tiles_per_group // 64)  # two-stage reduction once a group has thousands of tile partials
     scratch = torch.empty(groups * splits * 2 * C, dtype=torch.float64, device=partial.device) if splits > 1 else None
     call("df_bn_finalize", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,

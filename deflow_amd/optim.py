@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from . import ops
 from ._lib import call, ptr, stream
 
 
@@ -143,6 +144,7 @@ class FlatAdam:
 
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
+        ops.PARAM_GEN[0] += 1  # the kernel writes the parameter arena behind autograd's version counters
         f = self.flat
         call("df_adam_step", ptr(f.param), ptr(f.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), f.numel, self.lr,
              self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, stream())

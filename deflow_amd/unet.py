@@ -57,9 +57,7 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     w, b, bn = ops.ohwi(m.conv.weight), m.conv.bias.detach(), m.batchnorm
     C = m.conv.out_channels
     if not train:
-        invstd = torch.rsqrt(bn.running_var + bn.eps)
-        scale = (bn.weight.detach() * invstd).contiguous()
-        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        scale, shift, _, _ = ops.folded_bn(bn)
         ops.conv2d(x, w, b, z, 3, m.stride, epi=ops.EPI_BN_GELU, scale=scale, shift=shift)
         return
     ipg = n_imgs // groups
@@ -107,6 +105,7 @@ class FastFlow3DUNet(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         x = img_pair(bstar, 32)
         cats: List[torch.Tensor] = []
+        alive: List[torch.Tensor] = []  # DfImg descriptors hold raw pointers: every layer output must outlive its readers
         h, w = H, W
         for stage in (self.encoder_step_1, self.encoder_step_2, self.encoder_step_3):
             for i, m in enumerate(stage):
@@ -122,6 +121,7 @@ class FastFlow3DUNet(nn.Module):
                     keep = torch.empty(2 * B, h, w, C, **f32)
                     z = img(keep)
                 _cwn_forward(m, x, z, 2 * B, 2, train, tape)
+                alive.append(keep)  # without this a no-tape run would free x's tensor before the next conv reads it
                 if tape is not None:
                     tape.append(("keep", keep))
                 x = z

@@ -285,6 +285,23 @@ def test_edge_cases_empty_ragged_and_big_grid(dev):
     assert torch.equal(f, r2["flow"][0])
 
 
+def test_train_mode_forward_without_grad_is_repeatable():
+    """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
+    (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
+    handed the block to the next conv's output -> run-to-run differences of a few percent)"""
+    import deflow_amd
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    m = deflow_amd.DeFlow(grid_feature_size=[256, 256], point_cloud_range=[-25.6, -25.6, -3, 25.6, 25.6, 3]).to(dev).train()
+    from deflow_amd.synth import synth_batch
+    batch = synth_batch(2, 20000, grid_hw=(256, 256), device=dev)
+    with torch.no_grad():
+        outs = [m.forward_padded(batch)["flow"].clone() for _ in range(3)]
+    n = int(m.last_state["counts0"][0])
+    assert n > 1000
+    assert torch.equal(outs[0][0, :n], outs[1][0, :n]) and torch.equal(outs[0][0, :n], outs[2][0, :n])
+
+
 @pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"}, {"DF_WGRAD_RING": "0", "DF_CONV_W8": "0"},
                                  {"DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1"}, {"DF_SIDE_STREAM": "1"}])
 def test_alternate_kernel_paths(env):
