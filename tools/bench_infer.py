@@ -44,7 +44,8 @@ try:
             g.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 50
-        same = bool(torch.equal(m.last_state["flow"], ref))
+        nv = int(m.last_state["counts0"][0])   # rows past the valid count are never written (padding)
+        same = bool(torch.equal(m.last_state["flow"][0, :nv], ref[0, :nv]))
     out["B1_graph"] = {"ms": dt * 1e3, "pairs_per_s": 1 / dt, "tflops": 391.6e9 / dt / 1e12, "replay_equals_eager": same}
 except Exception as e:  # noqa
     out["B1_graph"] = {"error": repr(e)[:300]}
