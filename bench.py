@@ -140,6 +140,23 @@ def main():
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
                                                     "ms_per_step": v["ms"] / args.steps,
                                                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}}
+    if world == 1:
+        # forward-only pairs/s of BASELINE configs[1] (one 80k-point pair, eval mode) beside the headline
+        model.eval()
+        b1 = synth_batch(1, N_POINTS, seed=20240116, device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                model.forward_padded(b1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                model.forward_padded(b1)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t1) / 20 * 1e3
+        model.train()
+        out["forward_only"] = {"workload": "BASELINE configs[1]: deflow inference, 1 pair (B=1), 80000 pts/cloud, 512x512, 4 GRU iters",
+                               "ms_per_pair": fwd_ms, "pairs_per_s": 1e3 / fwd_ms,
+                               "algorithmic_tflops": 391.6e9 / (fwd_ms * 1e-3) / 1e12}
     if use_dist:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:
