@@ -9,6 +9,7 @@ import torch
 
 from . import ops
 from ._lib import img, call, ptr, stream
+from .unet import FastFlow3DUNet
 
 
 class GradDict(dict):
@@ -89,14 +90,34 @@ class DeFlowFn(torch.autograd.Function):
         dev = bstar.device
         dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
         dv = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
-        # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
-        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
-                                before=img(bstar), after=img(st["v"]))
-        st["sv"] = None
-        phase(model.head.parameters())
-        # UNet: accumulates its own d(bstar) into the same buffer
-        model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads, phase)
-        st["tape"] = None
+        # d(bstar) is only read at occupied pillars (pillar feature net backward): the UNet's two data gradients into it
+        # -- skip conv and first encoder conv -- are evaluated there only (df_pillar_input_grad) instead of densely for
+        # all H*W cells.  DF_DENSE_CANVAS_GRAD=1 keeps the dense kernels (A/B, tests).
+        sparse = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(model.backbone, FastFlow3DUNet)
+        if sparse:
+            # decoder: its gather backward writes d(before) = d(bstar) and d(after) = dv densely (a cheap stream)
+            model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                    before=img(bstar), after=img(st["v"]))
+            st["sv"] = None
+            phase(model.head.parameters())
+            dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True)
+            st["tape"] = None
+            bb = model.backbone
+            w1 = ops.ohwi(bb.encoder_step_1[0].conv.weight)
+            w3 = ops.ohwi(bb.decoder_step3.u3.weight)
+            for cloud, pst in ((0, st["p0"]), (1, st["p1"])):
+                N = pst.pts.shape[1]
+                call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
+                     img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, max(1, 256 // B), stream())  # one 16-wave workgroup per CU
+        else:
+            # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
+            model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                    before=img(bstar), after=img(st["v"]))
+            st["sv"] = None
+            phase(model.head.parameters())
+            # UNet: accumulates its own d(bstar) into the same buffer
+            model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads, phase)
+            st["tape"] = None
         # pillar feature net of both clouds (shared weights -> accumulate)
         emb = model.embedder
         g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)

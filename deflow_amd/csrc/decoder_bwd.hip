@@ -449,9 +449,11 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
       a += ld4(dh0 + ((int64_t)b * N + cp) * 128 + sub * 4);
     }
     if (sub < 16) {
-      float* o = bp + (int64_t)cell * dbefore.ld + sub * 4;
-      if (acc_before) a += ld4(o);
-      st4(o, a);
+      if (dbefore.ptr) {   // NULL: the caller takes the `before` gradient sparsely (df_pillar_input_grad)
+        float* o = bp + (int64_t)cell * dbefore.ld + sub * 4;
+        if (acc_before) a += ld4(o);
+        st4(o, a);
+      }
     } else {
       float* o = ap + (int64_t)cell * dafter.ld + (sub - 16) * 4;
       if (acc_after) a += ld4(o);
@@ -534,12 +536,13 @@ extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const i
 extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
                              int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
                              int nblk, void* stream) {
-  DF_REQUIRE(dh0 && idx_sorted && cell_rng && cpos && dbefore.ptr && dafter.ptr && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
-  DF_REQUIRE(dbefore.n == B && dafter.n == B && dbefore.c == 64 && dafter.c == 64 && dbefore.h == dafter.h &&
-                 dbefore.w == dafter.w && (dbefore.ld % 4) == 0 && (dafter.ld % 4) == 0,
-             DF_E_SHAPE);
+  DF_REQUIRE(dh0 && idx_sorted && cell_rng && cpos && dafter.ptr && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(dafter.n == B && dafter.c == 64 && (dafter.ld % 4) == 0, DF_E_SHAPE);
+  if (dbefore.ptr)
+    DF_REQUIRE(dbefore.n == B && dbefore.c == 64 && dbefore.h == dafter.h && dbefore.w == dafter.w && (dbefore.ld % 4) == 0,
+               DF_E_SHAPE);
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dh0,
-                     idx_sorted, cell_rng, cpos, N, dbefore.h * dbefore.w, dbefore, dafter, accumulate_before,
+                     idx_sorted, cell_rng, cpos, N, dafter.h * dafter.w, dbefore, dafter, accumulate_before,
                      accumulate_after);
   DF_CHECK_LAUNCH();
   return DF_OK;

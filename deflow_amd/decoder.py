@@ -145,7 +145,9 @@ class ConvGRUDecoder(nn.Module):
         else:
             call("df_colsum_finalize", ptr(bias_partial), nblocks, 772, 1, ptr(bias_g), 0, s)
         # image gradients: per-cell segmented sum (no atomics)
-        ncell = dbefore.h * dbefore.w
+        ncell = dafter.h * dafter.w
+        if dbefore is None:   # the caller evaluates d(before) sparsely from dh0 (df_pillar_input_grad)
+            dbefore = DfImg(0, 0, 0, 0, 0, 0, 1, 0, 0)
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
              int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
         side = ops.SIDE
@@ -203,6 +205,7 @@ class ConvGRUDecoder(nn.Module):
         grads[self.offset_encoder.bias] = bias_g[608:672]
         grads[self.decoder[2].weight] = bias_g[672:768].view(3, 32)
         grads[self.decoder[2].bias] = bias_g[768:771]
+        return dh0   # [B*N,128] gradient of the gathered rows (for a sparse d(before); see df_pillar_input_grad)
 
     # -- reference-compatible call ------------------------------------------------------------------------------
     def forward(self, before_pseudoimages: torch.Tensor, after_pseudoimages: torch.Tensor,
@@ -257,7 +260,9 @@ class LinearDecoder(nn.Module):
              ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(w1),
              ptr(d[0].bias.detach()), ptr(d[2].weight.detach()), ptr(wt_1), ptr(vx), ptr(dh0), ptr(dxe), ptr(dpre1),
              ptr(hid), s)
-        ncell = dbefore.h * dbefore.w
+        ncell = dafter.h * dafter.w
+        if dbefore is None:
+            dbefore = DfImg(0, 0, 0, 0, 0, 0, 1, 0, 0)
         call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
              int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
         # dW1^T [256,32] = vx^T dpre1 (row GEMM with the validity mask), then transpose back
@@ -273,6 +278,7 @@ class LinearDecoder(nn.Module):
         offs = ps.offs.view(BN, 3)
         grads[self.offset_encoder.weight] = torch.cat([so(dxe, 128, 64, offs, 3, 3), so(dxe[:, 64:], 128, 64, offs, 3, 3)], 0)
         grads[self.offset_encoder.bias] = so(dxe, 128, 128, None, 0, 1).view(128)
+        return dh0
 
     def forward(self, before_pseudoimages, after_pseudoimages, voxelizer_infos):
         from .autograd import GruHeadFn

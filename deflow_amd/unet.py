@@ -179,9 +179,12 @@ class FastFlow3DUNet(nn.Module):
                 wgrad()
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict,
-                     phase=None) -> torch.Tensor:
+                     phase=None, sparse_input_grad: bool = False):
         """Consumes the tape of run(train=True).  dv [B,H,W,64].  Returns d(bstar) [B,H,W,64] (added to `dbstar`
-        if given).  Parameter gradients go to `grads` {param: tensor}."""
+        if given).  Parameter gradients go to `grads` {param: tensor}.
+        sparse_input_grad: do NOT produce d(bstar); return (dy1, dskip) instead -- the output gradient of the first
+        encoder conv [2B,H/2,W/2,64] and of the skip conv on bstar (a [B,H,W,64] channel slice) -- for a caller that only
+        needs d(bstar) at occupied pillars (ops.pillar_input_grad)."""
         B, H, W, _ = bstar.shape
         dev = bstar.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -205,7 +208,9 @@ class FastFlow3DUNet(nn.Module):
             _, m, x, ks = pop("conv")
             self._conv_bwd(m, img(x), img(dy), ks, 1, dx, acc, grads)
 
-        def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: DfImg, acc_b: bool):
+        retained = {}
+
+        def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: Optional[DfImg], acc_b: bool):
             # reverse of: u1(a)->t ; up(t)->cat[:lat] ; u3(b)->cat[lat:] ; u4(cat) ; u5(u4)
             _, m5, x5, _ = tape[-1]
             du4 = hold(torch.empty_like(x5))
@@ -217,6 +222,8 @@ class FastFlow3DUNet(nn.Module):
             # u3
             _, m3, xb, ks = pop("conv")
             self._conv_bwd(m3, img(xb), img(dcat, lat, lat), 1, 1, db, acc_b, grads)
+            if db is None:
+                retained["dskip"] = (dcat, lat)
             _, h, w, lat_ = pop("up")
             dt = hold(torch.empty(B, h, w, lat, **f32))
             ops.upsample2x_bwd(img(dcat, lat, 0), img(dt), self.align_corners)
@@ -228,13 +235,15 @@ class FastFlow3DUNet(nn.Module):
         du = hold(torch.empty_like(xu))
         plain_conv_bwd(dv, img(du), False)
         # decoder_step3: a = T, b = bstar
-        if dbstar is None:
+        if sparse_input_grad:
+            acc_b = False
+        elif dbstar is None:
             dbstar = torch.empty(B, H, W, 64, **f32)
             acc_b = False
         else:
             acc_b = True
         dT = hold(torch.empty(B, H // 2, W // 2, 128, **f32))
-        upsample_skip_bwd(du, img(dT), False, img(dbstar), acc_b)
+        upsample_skip_bwd(du, img(dT), False, None if sparse_input_grad else img(dbstar), acc_b)
         dF = hold(torch.empty(B, H // 2, W // 2, 128, **f32))   # d(fstar)
         dS = hold(torch.empty(B, H // 4, W // 4, 256, **f32))
         upsample_skip_bwd(dT, img(dS), False, img(dF), False)
@@ -257,6 +266,9 @@ class FastFlow3DUNet(nn.Module):
                 if i > 0:
                     dxt = torch.empty(2 * B, x.h, x.w, x.c, **f32)
                     dx, acc = img(dxt), False
+                elif sidx == 1 and sparse_input_grad:
+                    dx, acc = None, False
+                    retained["dy1"] = dy
                 else:
                     buf, c = stage_in_grads[sidx]
                     dx, acc = img_pair(buf, c), True
@@ -265,6 +277,8 @@ class FastFlow3DUNet(nn.Module):
             if phase is not None:
                 phase(stage.parameters())
         assert not tape
+        if sparse_input_grad:
+            return retained["dy1"], retained["dskip"]
         return dbstar
 
     # -- reference-compatible call: backbone(pc0_img, pc1_img) on NCHW tensors (no autograd) -----------

@@ -100,6 +100,15 @@ int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const u
                        const float* w_pfn, const float* bn_ss, int bn_sample_stride, const float* coef, df_img gout,
                        float* dw_partial, int nblk_stat, void* stream);
 
+/* Gradient of the pillar canvas [B,H,W,32] of one cloud (cloud 0 = pc0 = channels 0..31 of the network input, cloud 1 =
+ * pc1) evaluated ONLY at that cloud's occupied cells -- the only cells df_pfn_bwd_* read.  Adds (accumulate != 0) or
+ * writes the two conv consumers of the canvas in FastFlow3DUNet: the first encoder conv (3x3, stride 2, 32 -> 64:
+ * dy1 [2B,H/2,W/2,64] with image = cloud * B + b, w1 [64,3,3,32]) and the decoder's 1x1 skip conv on the 64-channel
+ * input (dskip [B,H,W,64], w3 [64,64]).  Replaces two dense data-gradient convolutions.  Unoccupied cells are untouched. */
+int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* counts, int B, int H, int W, int cloud,
+                         const float* dy1, const float* w1, df_img dskip, const float* w3, df_img dcanvas,
+                         int accumulate, int nblk, void* stream);
+
 /* ------------------------------------------------------------- BEV convolutions (A5) ---
  * Replaces torch.nn.Conv2d / BatchNorm2d / GELU / interpolate inside FastFlow3DUNet and
  * ConvWithNorms ([REF decoder.py:202-220]).  fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM. */
@@ -200,7 +209,7 @@ int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B
                  int nsplit, void* stream);
 /* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
  * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
- * with accumulate_* != 0, added to. */
+ * with accumulate_* != 0, added to.  dbefore.ptr == NULL skips the `before` image. */
 int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
                   int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
                   int nblk, void* stream);
