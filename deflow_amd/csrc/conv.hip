@@ -4,15 +4,17 @@
 // 157 TFLOP/s chip peak).  Activations are NHWC so the reduction axis (input channels) is
 // contiguous: a tile row is one 128-byte run of 32 channels of one (shifted) pixel.
 //
-//   conv_kernel   y[m, co] = sum_{tap, ci} x[pix(m, tap), ci] * w[co, tap, ci]      (fwd and dgrad)
-//   wgrad_kernel  dw[co, tap, ci] = sum_m dy[m, co] * x[pix(m, tap), ci]            (split over m)
+//   conv_dma_kernel     y[m, co] = sum_{tap, ci} x[pix(m, tap), ci] * w[co, tap, ci]   (fwd and dgrad; operands by
+//                       LDS-DMA; 8-wave workgroups for the 128 x 128 and 128 x 64 tiles)          -- the default
+//   conv_kernel         the same with register-staged global -> LDS copies (tensors beyond 32-bit DMA offsets, A/B)
+//   wgrad3_ring_kernel  dw[co, tap, ci] = sum_m dy[m, co] * x[pix(m, tap), ci], 3x3 stride 1, 12-wave workgroups
+//   wgrad_kernel / wgrad1x1_kernel / wgrad_dma_kernel   the other kernel sizes / strides and the 4-wave DMA form
 //
 // LDS tiles are [row][32] floats, unpadded, with the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7:
 // ds_read_b128 fragments are conflict-free (each 16-lane service group hits 16 distinct (row parity, slot)
-// pairs = all 64 banks) and a 256x64 tile double-buffers in 80 KB, i.e. two workgroups per CU.  k is
-// permuted inside each group of 8: MFMA step s of group g uses k = 8g + s on lanes 0-31 and k = 8g + 4 + s
-// on lanes 32-63 for BOTH operands, so one b128 read feeds four MFMA steps.  Global->LDS goes through
-// registers, issued one stage ahead (T14).
+// pairs = all 64 banks; SQ_LDS_BANK_CONFLICT = 0 measured) and a 128x128 tile double-buffers in 64 KB, i.e. two
+// workgroups per CU.  k is permuted inside each group of 8: MFMA step s of group g uses k = 8g + s on lanes 0-31
+// and k = 8g + 4 + s on lanes 32-63 for BOTH operands, so one b128 read feeds four MFMA steps.
 #include <cstdlib>
 
 #include "common.h"
@@ -1303,9 +1305,10 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // Measured on MI355X (bs16 step): the DMA form wins for 3x3 stride 1 (124.7 -> 128.4 TFLOP/s); for 1x1 and stride 2
-  // the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step; s2 needs 116 KB LDS = 1 workgroup/CU), so
-  // those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere (A/B runs, tests).
+  // Measured on MI355X (bs16 step): DMA-fed kernels win for 3x3 stride 1 (register-staged 124.7 -> 4-wave DMA 128.4 ->
+  // 12-wave 131-132 TFLOP/s); for 1x1 and stride 2 the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step;
+  // s2 needs 116 KB LDS = 1 workgroup/CU), so those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere and
+  // DF_WGRAD_RING=0 the 4-wave DMA form for 3x3 (A/B runs, tests).
   static const int dma_all = getenv("DF_WGRAD_DMA_ALL") ? atoi(getenv("DF_WGRAD_DMA_ALL")) : 0;
   if (p.x_bytes && ((dma_all && !(bias_ws && ksize == 1 && (dy.c % 128) == 0)) || (ksize == 3 && stride == 1))) {
     if (wgrad_use_1x1(ksize, dy.c)) {
