@@ -519,16 +519,18 @@ bool geom_ok(const df_pillar_geom& g) {
 // d(canvas) is only ever read at OCCUPIED pillars (the canvas is a scatter of pillar features; empty cells are constants
 // with nothing upstream), yet dense kernels used to produce it for all H*W cells: the stride-2 data gradient of the first
 // encoder conv (32 <- 64 channels) and the data gradient of the decoder's 1x1 skip conv on the canvas -- 3.1 ms per step
-// for a tensor that is 85-90 % dead.  This kernel evaluates both only at the occupied cells of one cloud and adds them
+// for a tensor that is 80-90 % dead.  This kernel evaluates both only at the occupied cells of one cloud and adds them
 // to what is already there (the decoder's gather backward, which is a cheap dense stream):
 //   dcanvas[b,y,x,c] += sum_{ky,kx of (y,x)'s parity} sum_co dy1[g*B+b, (y+1-ky)/2, (x+1-kx)/2, co] w1[co,ky,kx,c]  (conv, s2, pad 1)
 //                     + sum_j dskip[b,y,x,j] w3[j, 32 g + c]                                                      (1x1 skip conv)
-// One workgroup of 16 waves per CU keeps both weight matrices in LDS (82 KB).  A wave scans 64 consecutive sorted points,
-// ballots the pillar heads and deals them two at a time to its half-waves (lane = channel c); the five gradient rows of
-// the NEXT pair are fetched while the current pair is multiplied (broadcast LDS reads x weight rows).  Cells nobody
-// reads keep whatever the dense producers left there.  Measured 1.0 ms per cloud at the bench shape, of which 0.78 ms is
-// the FMA loop (LDS-bound: one 4-byte weight read per FMA); an MFMA form over class-sorted cells is the next step.
-constexpr int PG_THREADS = 1024, PG_SLOTS = PG_THREADS / 32;
+// as small MFMA GEMMs: a wave scans 64 consecutive sorted points, ballots the pillar heads, and for each of the four
+// output-parity classes (which fix the reachable taps: 1, 2, 2 or 4 of 9) multiplies batches of up to 16 cells
+// [16 x (taps + 1) * 64] by the weight rows [(taps + 1) * 64 x 32] with v_mfma_f32_16x16x4_f32.  A-operand rows come
+// straight from global memory (lane (cell, q) holds 16 consecutive channels of its cell's gradient row: the MFMA k index
+// is the pair (q, step)), the weights of both convs sit in LDS (82 KB, one 16-wave workgroup per CU).  The first version
+// did the same sums as per-lane FMAs with one LDS weight read each and was LDS-bound at 1.0 ms per cloud.
+// Cells nobody reads keep whatever the dense producers left there.
+constexpr int PG_THREADS = 1024;
 struct PillarGradParams {
   const uint32_t* key_sorted;
   const int32_t* counts;
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W1s = lds;                       // [9][64][32]
   float* W3s = W1s + 9 * 64 * 32;         // [64][32]
-  float* Stg = W3s + 64 * 32;             // [PG_SLOTS][5][64]
-  const int tid = threadIdx.x, c = tid & 31, slot = tid >> 5;
+  int* RowCell = reinterpret_cast<int*>(W3s + 64 * 32);   // [16 waves][16]
+  const int tid = threadIdx.x;
   const int b = blockIdx.y, g = p.cloud;
   for (int i = tid; i < 9 * 64 * 32; i += PG_THREADS) {
     const int cc = i & 31, co = (i >> 5) & 63, tap = i >> 11;
@@ -553,95 +555,75 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
   }
   for (int i = tid; i < 64 * 32; i += PG_THREADS) W3s[i] = p.w3[(i >> 5) * 64 + 32 * g + (i & 31)];
   __syncthreads();
-  float* st = Stg + slot * 5 * 64;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  int* rowcell = RowCell + wave * 16;
   const int ncell = p.H * p.W, h2 = p.H >> 1, w2 = p.W >> 1;
   const float* dy1 = p.dy1 + (int64_t)(g * p.B + b) * h2 * w2 * 64;
   const float* dsk = reinterpret_cast<const float*>(p.dskip.ptr) + df_img_base(p.dskip, b);
   float* out = reinterpret_cast<float*>(p.dcanvas.ptr) + df_img_base(p.dcanvas, b);
   const SampleRange sr = sample_range(p.counts, b);
-  const int lane = tid & 63, half = lane >> 5, wave = tid >> 6;
   const int end = sr.off + sr.cnt;
-
-  struct Cell {       // one pillar's inputs, in flight
-    int cell;         // -1: none
-    int tapid[4];
-    float2 sk, tv[4];
-    float old;
-  };
-  auto fetch = [&](int mine, uint32_t key, Cell& cd) {
-    cd.cell = -1;
-    const uint32_t ckey = (uint32_t)__shfl((int)key, mine < 0 ? 0 : mine);
-    if (mine < 0) return;
-    const int cell = (int)(ckey - (uint32_t)b * (uint32_t)ncell);
-    cd.cell = cell;
-    const int y = cell / p.W, x = cell - y * p.W;
-    cd.sk = *reinterpret_cast<const float2*>(dsk + (int64_t)cell * p.dskip.ld + 2 * c);
-    cd.old = p.accumulate ? out[(int64_t)cell * p.dcanvas.ld + c] : 0.f;
-    const int ky0 = (y + 1) & 1, kx0 = (x + 1) & 1;        // taps with (y + 1 - ky), (x + 1 - kx) even
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ky = ky0 + 2 * (t >> 1), kx = kx0 + 2 * (t & 1);
-      const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
-      const bool ok = ky < 3 && kx < 3 && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
-      cd.tapid[t] = ok ? ky * 3 + kx : -1;
-      cd.tv[t] = ok ? *reinterpret_cast<const float2*>(dy1 + ((int64_t)oy * w2 + ox) * 64 + 2 * c) : float2{0.f, 0.f};
-    }
-  };
-  auto pop2 = [&](unsigned long long& mask) -> int {   // this half-wave's next head (bit index) or -1
-    const int b0 = __ffsll((long long)mask) - 1;
-    const unsigned long long m1 = mask & (mask - 1);
-    const int b1 = m1 ? __ffsll((long long)m1) - 1 : -1;
-    mask = m1 & (m1 - 1);
-    return half ? b1 : b0;
-  };
-  auto lds_fence = [&]() {   // a half-wave's own LDS writes are visible to its reads in program order; stop compiler reordering
+  auto lds_fence = [&]() {   // a wave's own LDS writes are visible to its reads in program order; stop compiler reordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // acc[nt] += A_row(li)[16 lq .. 16 lq + 15] x Ws[(16 lq + s) * 32 + 16 nt + li], s = 0..15
+  auto mma_row = [&](const float* src /* this lane's cell row, or nullptr */, const float* Ws, f32x4 (&acc)[2]) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = src ? ld4(src + 16 * lq + 4 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = Ws + 16 * lq * 32 + li;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float av = a4[s >> 2][s & 3];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[s * 32], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[s * 32 + 16], acc[1], 0, 0, 0);
+    }
   };
 
   for (int base = sr.off + (blockIdx.x * (PG_THREADS / 64) + wave) * 64; base < end; base += gridDim.x * (PG_THREADS / 64) * 64) {
     const int i = base + lane;
     const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
     const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
-    unsigned long long mask = __ballot(head);
-    if (!mask) continue;
-    Cell cur, nxt;
-    fetch(pop2(mask), key, cur);
-    for (;;) {
-      const bool more = mask != 0;   // wave-uniform
-      if (more) fetch(pop2(mask), key, nxt);
-      if (cur.cell >= 0) {
-        *reinterpret_cast<float2*>(st + 2 * c) = cur.sk;
+    const int mycell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int my_y = mycell / p.W, my_x = mycell - my_y * p.W;
+    const int mycls = (((my_y + 1) & 1) << 1) | ((my_x + 1) & 1);   // (ky0, kx0): first reachable tap per axis
+    for (int cls = 0; cls < 4; ++cls) {
+      unsigned long long m = __ballot(head && mycls == cls);
+      const int ky0 = cls >> 1, kx0 = cls & 1;
+      const int nky = ky0 ? 1 : 2, nkx = kx0 ? 1 : 2;
+      while (m) {   // batches of up to 16 cells of this class
+        const bool in = (m >> lane) & 1;
+        const int rank = __popcll(m & ((1ull << lane) - 1));
+        if (in && rank < 16) rowcell[rank] = mycell;
+        const int nrows = min(16, (int)__popcll(m));
+        m = __ballot(in && rank >= 16);
+        lds_fence();
+        const int cell = li < nrows ? rowcell[li] : -1;
+        int crow[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) *reinterpret_cast<float2*>(st + (1 + t) * 64 + 2 * c) = cur.tv[t];
-      }
-      lds_fence();
-      if (cur.cell >= 0) {
-        float acc = cur.old;
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-          const f32x4 d4 = ld4(st + 4 * q);   // broadcast read
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc = fmaf(d4[k], W3s[(4 * q + k) * 32 + c], acc);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (cur.tapid[t] < 0) continue;
-          const float* wt = W1s + cur.tapid[t] * 64 * 32 + c;
-          const float* dv = st + (1 + t) * 64;
-#pragma unroll 4
-          for (int q = 0; q < 16; ++q) {
-            const f32x4 d4 = ld4(dv + 4 * q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc = fmaf(d4[k], wt[(4 * q + k) * 32], acc);
+        for (int r = 0; r < 4; ++r) crow[r] = (4 * lq + r) < nrows ? rowcell[4 * lq + r] : -1;
+        lds_fence();
+        const int y = cell / p.W, x = cell - y * p.W;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mma_row(cell >= 0 ? dsk + (int64_t)cell * p.dskip.ld : nullptr, W3s, acc);
+        for (int iy = 0; iy < nky; ++iy)
+          for (int ix = 0; ix < nkx; ++ix) {
+            const int ky = ky0 + 2 * iy, kx = kx0 + 2 * ix;
+            const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
+            const bool ok = cell >= 0 && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
+            mma_row(ok ? dy1 + ((int64_t)oy * w2 + ox) * 64 : nullptr, W1s + (ky * 3 + kx) * 64 * 32, acc);
           }
+        // C layout: acc[nt][r] = row 4 lq + r, channel 16 nt + li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (crow[r] < 0) continue;
+          float* o = out + (int64_t)crow[r] * p.dcanvas.ld + li;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) o[16 * nt] = (p.accumulate ? o[16 * nt] : 0.f) + acc[nt][r];
         }
-        out[(int64_t)cur.cell * p.dcanvas.ld + c] = acc;
       }
-      lds_fence();
-      if (!more) break;
-      cur = nxt;
     }
   }
 }
@@ -803,7 +785,7 @@ extern "C" int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* c
   PillarGradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.accumulate = accumulate;
   p.dy1 = dy1; p.w1 = w1; p.dskip = dskip; p.w3 = w3; p.dcanvas = dcanvas;
-  const size_t lds_bytes = (size_t)(9 * 64 * 32 + 64 * 32 + PG_SLOTS * 5 * 64) * sizeof(float);
+  const size_t lds_bytes = (size_t)(9 * 64 * 32 + 64 * 32 + (PG_THREADS / 64) * 16) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pillar_input_grad_kernel),
