@@ -100,7 +100,8 @@ class DeFlowFn(torch.autograd.Function):
                                     before=img(bstar), after=img(st["v"]))
             st["sv"] = None
             phase(model.head.parameters())
-            dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True)
+            dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True,
+                                                           dv_cells=st["p0"])
             st["tape"] = None
             bb = model.backbone
             w1 = ops.ohwi(bb.encoder_step_1[0].conv.weight)

@@ -628,6 +628,99 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
   }
 }
 
+
+// ------------------------------------------------------------------------------ sparse-output-gradient weight grad ---
+// The UNet's last conv (3x3, 64 -> 64 at full resolution) receives its output gradient from the decoder's gather
+// backward: exact zeros everywhere except at the cells pc0 points looked up (~20 % of H*W).  Its weight gradient
+//   dW[co, ky, kx, ci] = sum_p dy[p, co] x[p + (ky - 1, kx - 1), ci]
+// therefore only needs the occupied pixels p: 5x fewer FLOPs than the dense kernel (2.5 ms per step).  One wave per
+// tap: every wave of a workgroup scans the same 64-point windows of the sorted pillar keys, ballots the pillar heads into
+// its own pixel list and accumulates its tap's [64 co x 64 ci] block as 16 x (16 x 16 x 4) MFMA tiles, four pixels per
+// step, both operands read straight from global memory (64-byte row segments, shared through L1/L2 by the nine waves).
+// No workgroup synchronisation at all.  Partials [workgroup][64][9][64] are summed by df_conv2d_wgrad_reduce (fixed order);
+// the centre-tap wave also produces the bias gradient partial.
+struct SparseWgradParams {
+  const uint32_t* key_sorted;
+  const int32_t* counts;
+  int H, W;
+  df_img dy, x;
+  float* ws;        // [gridDim.y * gridDim.x][64][9][64]
+  float* bias_ws;   // [gridDim.y * gridDim.x][64] or nullptr
+};
+
+__global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams p) {
+  __shared__ int Plist[9 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y, ncell = p.H * p.W;
+  const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+  int* plist = Plist + tap * 64;
+  const float* dy = reinterpret_cast<const float*>(p.dy.ptr) + df_img_base(p.dy, b);
+  const float* xp = reinterpret_cast<const float*>(p.x.ptr) + df_img_base(p.x, b);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const SampleRange sr = sample_range(p.counts, b);
+  const int end = sr.off + sr.cnt;
+  for (int base = sr.off + blockIdx.x * 64; base < end; base += gridDim.x * 64) {
+    const int i = base + lane;
+    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
+    const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
+    const unsigned long long m = __ballot(head);
+    const int n = (int)__popcll(m);
+    if (head) plist[__popcll(m & ((1ull << lane) - 1))] = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int s0 = 0; s0 < n; s0 += 4) {
+      const int k = s0 + lq;
+      const int cell = k < n ? plist[k] : -1;
+      const int y = cell / p.W, x = cell - y * p.W;
+      const int qy = y + ty, qx = x + tx;
+      const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+      const float* ar = dy + (int64_t)(cell < 0 ? 0 : cell) * p.dy.ld + li;
+      const float* br = xp + (int64_t)(okq ? qy * p.W + qx : 0) * p.x.ld + li;
+      float a[4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = cell >= 0 ? ar[16 * t] : 0.f;
+        bv[t] = okq ? br[16 * t] : 0.f;
+      }
+      if (tap == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bsum[t] += a[t];
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], bv[nt], acc[ct][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  float* o = p.ws + blk * 64 * 9 * 64;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[((16 * ct + 4 * lq + r) * 9 + tap) * 64 + 16 * nt + li] = acc[ct][nt][r];
+  if (tap == 4 && p.bias_ws) {   // bsum[t] on lane (li, lq) = sum over this lane's pixels of dy[.., 16 t + li]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = bsum[t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lq == 0) p.bias_ws[blk * 64 + 16 * t + li] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt,
@@ -795,6 +888,19 @@ extern "C" int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* c
   }
   hipLaunchKernelGGL(pillar_input_grad_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
+                                  float* bias_ws, int nblk, void* stream) {
+  DF_REQUIRE(key_sorted && counts && x.ptr && dy.ptr && ws && B > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(x.n == B && dy.n == B && x.c == 64 && dy.c == 64 && x.h == dy.h && x.w == dy.w && x.grp_size == x.n &&
+                 dy.grp_size == dy.n,
+             DF_E_SHAPE);
+  SparseWgradParams p;
+  p.key_sorted = key_sorted; p.counts = counts; p.H = dy.h; p.W = dy.w; p.dy = dy; p.x = x; p.ws = ws; p.bias_ws = bias_ws;
+  hipLaunchKernelGGL(sparse_wgrad3x3_kernel, dim3(nblk, B), dim3(576), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

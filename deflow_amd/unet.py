@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import DfImg, img, img_pair, ptr
+from ._lib import DfImg, call, img, img_pair, ptr, stream
 
 import os
 _NO_FUSED_BIAS = bool(int(os.environ.get("DF_NO_FUSED_BIAS", "0")))  # A/B switch: separate column-sum pass for conv bias grads
@@ -179,12 +179,14 @@ class FastFlow3DUNet(nn.Module):
                 wgrad()
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict,
-                     phase=None, sparse_input_grad: bool = False):
+                     phase=None, sparse_input_grad: bool = False, dv_cells=None):
         """Consumes the tape of run(train=True).  dv [B,H,W,64].  Returns d(bstar) [B,H,W,64] (added to `dbstar`
         if given).  Parameter gradients go to `grads` {param: tensor}.
         sparse_input_grad: do NOT produce d(bstar); return (dy1, dskip) instead -- the output gradient of the first
         encoder conv [2B,H/2,W/2,64] and of the skip conv on bstar (a [B,H,W,64] channel slice) -- for a caller that only
-        needs d(bstar) at occupied pillars (ops.pillar_input_grad)."""
+        needs d(bstar) at occupied pillars (df_pillar_input_grad).
+        dv_cells: PillarState of the cloud whose occupied cells are the ONLY non-zero pixels of dv (the decoder's gather
+        backward wrote it): the last conv's weight gradient then sums over those cells only (df_sparse_wgrad3x3)."""
         B, H, W, _ = bstar.shape
         dev = bstar.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -233,7 +235,23 @@ class FastFlow3DUNet(nn.Module):
         # decoder_step4
         _, m, xu, _ = tape[-1]
         du = hold(torch.empty_like(xu))
-        plain_conv_bwd(dv, img(du), False)
+        if dv_cells is None:
+            plain_conv_bwd(dv, img(du), False)
+        else:
+            _, m, xu, _ = pop("conv")
+            w4 = ops.ohwi(m.weight)
+            ops.conv2d(img(dv), ops.weight_transpose(w4), None, img(du), 3, 1, mode=ops.CONV_DGRAD)
+            nblk = max(1, 256 // B)
+            ws = torch.empty(nblk * B, 64 * 9 * 64, **f32)
+            bws = torch.empty(nblk * B, 64, **f32)
+            call("df_sparse_wgrad3x3", ptr(dv_cells.key_sorted), ptr(dv_cells.counts), B, img(xu), img(dv), ptr(ws), ptr(bws),
+                 nblk, stream())
+            dw4 = torch.empty_like(w4)
+            call("df_conv2d_wgrad_reduce", ptr(ws), nblk * B, 64, 9, 64, ptr(dw4), 9 * 64, 0, stream())
+            db4 = torch.empty(64, **f32)
+            call("df_colsum_finalize", ptr(bws), nblk * B, 64, 1, ptr(db4), 0, stream())
+            grads[m.weight] = dw4.permute(0, 3, 1, 2)
+            grads[m.bias] = db4
         # decoder_step3: a = T, b = bstar
         if sparse_input_grad:
             acc_b = False

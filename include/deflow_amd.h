@@ -109,6 +109,13 @@ int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* counts, int 
                          const float* dy1, const float* w1, df_img dskip, const float* w3, df_img dcanvas,
                          int accumulate, int nblk, void* stream);
 
+/* Weight (and bias) gradient of a 3x3 stride-1 64 -> 64 conv whose OUTPUT gradient dy [B,H,W,64] is exactly zero outside
+ * the occupied cells of a pillarised cloud (the UNet's last conv: dy comes from the decoder's gather backward): sums only
+ * over those cells.  ws [nblk*B][64][9][64] / bias_ws [nblk*B][64] partials; finish with
+ * df_conv2d_wgrad_reduce(ws, nblk*B, 64, 9, 64, ...) and df_colsum_finalize(bias_ws, nblk*B, 64, 1, ...). */
+int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
+                       float* bias_ws, int nblk, void* stream);
+
 /* ------------------------------------------------------------- BEV convolutions (A5) ---
  * Replaces torch.nn.Conv2d / BatchNorm2d / GELU / interpolate inside FastFlow3DUNet and
  * ConvWithNorms ([REF decoder.py:202-220]).  fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM. */
