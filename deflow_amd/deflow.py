@@ -8,6 +8,7 @@ valid-point counts) happens per forward, after every kernel has been queued.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -63,7 +64,9 @@ class DeFlow(nn.Module):
         self.timer[1].stop()
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None
-        v = self.backbone.run(bstar, train, tape)
+        # `v` is consumed by the decoder's gather alone: only pc0's occupied cells of it are computed
+        sparse_out = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(self.backbone, FastFlow3DUNet)
+        v = self.backbone.run(bstar, train, tape, out_cells=p0 if sparse_out else None)
         self.timer[2].stop()
         self.timer[3].start("Decoder")
         ps = PointSet(p0.coords_c, p0.offs_c, p0.counts, p0.idx_sorted, p0.cell_rng, p0.cpos)

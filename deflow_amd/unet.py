@@ -97,8 +97,11 @@ class FastFlow3DUNet(nn.Module):
                 p.data = p.data.contiguous(memory_format=torch.channels_last)
 
     # ------------------------------------------------------------------------------- forward ----
-    def run(self, bstar: torch.Tensor, train: bool, tape: Optional[list]) -> torch.Tensor:
-        """bstar [B,H,W,64] = cat(pc0 canvas, pc1 canvas) -> [B,H,W,64].  Appends what backward needs to `tape`."""
+    def run(self, bstar: torch.Tensor, train: bool, tape: Optional[list], out_cells=None) -> torch.Tensor:
+        """bstar [B,H,W,64] = cat(pc0 canvas, pc1 canvas) -> [B,H,W,64].  Appends what backward needs to `tape`.
+        out_cells: PillarState of the cloud whose occupied cells are the only pixels of the output anyone reads (the
+        decoder gathers at pc0's cells): the last conv is then evaluated there only (df_sparse_conv3x3) and the rest of
+        the returned tensor is NOT written."""
         B, H, W, _ = bstar.shape
         assert H % 8 == 0 and W % 8 == 0
         dev = bstar.device
@@ -130,7 +133,14 @@ class FastFlow3DUNet(nn.Module):
         t = self._upsample_skip(self.decoder_step2, s, fstar, tape)
         u = self._upsample_skip(self.decoder_step3, t, bstar, tape)
         v = torch.empty(B, H, W, 64, **f32)
-        self._conv(self.decoder_step4, u, img(v), 3, tape)
+        if out_cells is None:
+            self._conv(self.decoder_step4, u, img(v), 3, tape)
+        else:
+            m4 = self.decoder_step4
+            call("df_sparse_conv3x3", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, img(u), ptr(ops.ohwi(m4.weight)),
+                 ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
+            if tape is not None:
+                tape.append(("conv", m4, u, 3))
         return v
 
     def _conv(self, m: nn.Conv2d, x: torch.Tensor, y: DfImg, ks: int, tape: Optional[list]):

@@ -116,6 +116,12 @@ int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* counts, int 
 int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
                        float* bias_ws, int nblk, void* stream);
 
+/* The same conv's forward where only those cells of the OUTPUT are consumed (the `after` image is read by the decoder's
+ * gather alone): y[p] = bias + conv3x3(x)[p] for the occupied cells p of the pillarised cloud; other cells of y are not
+ * written.  x, y [B,H,W,64]; w [64,3,3,64]. */
+int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const float* w,
+                      const float* bias, df_img y, int nblk, void* stream);
+
 /* ------------------------------------------------------------- BEV convolutions (A5) ---
  * Replaces torch.nn.Conv2d / BatchNorm2d / GELU / interpolate inside FastFlow3DUNet and
  * ConvWithNorms ([REF decoder.py:202-220]).  fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM. */
