@@ -687,28 +687,36 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int s0 = 0; s0 < n; s0 += 4) {
-      const int k = s0 + lq;
-      const int cell = k < n ? plist[k] : -1;
-      const int y = cell / p.W, x = cell - y * p.W;
-      const int qy = y + ty, qx = x + tx;
-      const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
-      const float* ar = dy + (int64_t)(cell < 0 ? 0 : cell) * p.dy.ld + li;
-      const float* br = xp + (int64_t)(okq ? qy * p.W + qx : 0) * p.x.ld + li;
-      float a[4], bv[4];
+    for (int s0 = 0; s0 < n; s0 += 16) {   // 16 pixels = four MFMA k steps; all 32 loads are issued before the 64 MFMAs
+      float a[4][4], bv[4][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = cell >= 0 ? ar[16 * t] : 0.f;
-        bv[t] = okq ? br[16 * t] : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const int k = s0 + 4 * u + lq;
+        const int cell = k < n ? plist[k] : -1;
+        const int y = cell / p.W, x = cell - y * p.W;
+        const int qy = y + ty, qx = x + tx;
+        const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+        const float* ar = dy + (int64_t)(cell < 0 ? 0 : cell) * p.dy.ld + li;
+        const float* br = xp + (int64_t)(okq ? qy * p.W + qx : 0) * p.x.ld + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a[u][t] = cell >= 0 ? ar[16 * t] : 0.f;
+          bv[u][t] = okq ? br[16 * t] : 0.f;
+        }
       }
       if (tap == 4) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bsum[t] += a[t];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bsum[t] += a[u][t];
       }
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], bv[nt], acc[ct][nt], 0, 0, 0);
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ct], bv[u][nt], acc[ct][nt], 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
