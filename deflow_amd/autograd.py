@@ -106,10 +106,17 @@ class DeFlowFn(torch.autograd.Function):
             bb = model.backbone
             w1 = ops.ohwi(bb.encoder_step_1[0].conv.weight)
             w3 = ops.ohwi(bb.decoder_step3.u3.weight)
+            nb = max(1, 256 // B)
+            dw1 = torch.empty_like(w1)   # [64,3,3,32] memory
             for cloud, pst in ((0, st["p0"]), (1, st["p1"])):
                 N = pst.pts.shape[1]
+                ws1 = torch.empty(nb * B, 64 * 9 * 32, dtype=torch.float32, device=dev)
+                call("df_sparse_in_wgrad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1),
+                     img(bstar, 32, 32 * cloud), ptr(ws1), nb, stream())
+                call("df_conv2d_wgrad_reduce", ptr(ws1), nb * B, 64, 9, 32, ptr(dw1), 9 * 32, cloud, stream())
                 call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
-                     img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, max(1, 256 // B), stream())  # one 16-wave workgroup per CU
+                     img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, nb, stream())  # one 16-wave workgroup per CU
+            grads[bb.encoder_step_1[0].conv.weight] = dw1.permute(0, 3, 1, 2)
         else:
             # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
             model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,

@@ -856,6 +856,88 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_kernel(SparseConvPa
   }
 }
 
+
+// ---------------------------------------------------------------------------------- sparse-input weight gradient ---
+// Weight gradient of the FIRST encoder conv (3x3, stride 2, pad 1, 32 -> 64) whose input is the pillar canvas: only the
+// occupied cells q of a cloud contribute,
+//   dW[co, ky, kx, ci] = sum_q [ (q + 1 - k) even and in range ] dy1[g*B+b, (q + 1 - k) / 2, co] canvas[b, q, 32 g + ci].
+// One wave per tap (as sparse_wgrad3x3_kernel): every wave scans the same 64-point windows of the sorted pillar keys and
+// keeps the heads whose parity admits its tap; four cells per MFMA k step, [64 co x 32 ci] accumulators per wave.
+// Partials [workgroup][64][9][32]; the two clouds share the weights (second launch reduced with accumulate).
+struct SparseInWgradParams {
+  const uint32_t* key_sorted;
+  const int32_t* counts;
+  int B, H, W, cloud;
+  const float* dy1;   // [2B][H/2][W/2][64]
+  df_img canvas;      // [B][H][W][32] channel slice of the network input
+  float* ws;          // [gridDim.y * gridDim.x][64][9][32]
+};
+
+__global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParams p) {
+  __shared__ int Plist[9 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y, ncell = p.H * p.W, h2 = p.H >> 1, w2 = p.W >> 1;
+  const int ky = tap / 3, kx = tap % 3;
+  int* plist = Plist + tap * 64;
+  const float* dy1 = p.dy1 + (int64_t)(p.cloud * p.B + b) * h2 * w2 * 64;
+  const float* cv = reinterpret_cast<const float*>(p.canvas.ptr) + df_img_base(p.canvas, b);
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const SampleRange sr = sample_range(p.counts, b);
+  const int end = sr.off + sr.cnt;
+  for (int base = sr.off + blockIdx.x * 64; base < end; base += gridDim.x * 64) {
+    const int i = base + lane;
+    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
+    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int y = cell / p.W, x = cell - y * p.W;
+    const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
+    const bool mine = i < end && (i == sr.off || p.key_sorted[i - 1] != key) && (((y + 1 - ky) & 1) == 0) &&
+                      (((x + 1 - kx) & 1) == 0) && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
+    const unsigned long long m = __ballot(mine);
+    const int n = (int)__popcll(m);
+    if (mine) plist[__popcll(m & ((1ull << lane) - 1))] = cell;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int s0 = 0; s0 < n; s0 += 8) {   // 8 cells = two MFMA k steps
+      float a[2][4], bv[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = s0 + 4 * u + lq;
+        const int c2 = k < n ? plist[k] : -1;
+        const int y2 = c2 / p.W, x2 = c2 - y2 * p.W;
+        const float* ar = dy1 + ((int64_t)((y2 + 1 - ky) >> 1) * w2 + ((x2 + 1 - kx) >> 1)) * 64 + li;
+        const float* br = cv + (int64_t)c2 * p.canvas.ld + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[u][t] = c2 >= 0 ? ar[16 * t] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[u][t] = c2 >= 0 ? br[16 * t] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ct], bv[u][nt], acc[ct][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  float* o = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 * 9 * 32;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[((16 * ct + 4 * lq + r) * 9 + tap) * 32 + 16 * nt + li] = acc[ct][nt][r];
+}
+
 }  // namespace
 
 extern "C" int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt,
@@ -1058,6 +1140,18 @@ extern "C" int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* coun
   }
   hipLaunchKernelGGL(sparse_conv3x3_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_sparse_in_wgrad(const uint32_t* key_sorted, const int32_t* counts, int B, int H, int W, int cloud,
+                                  const float* dy1, df_img canvas, float* ws, int nblk, void* stream) {
+  DF_REQUIRE(key_sorted && counts && dy1 && canvas.ptr && ws && B > 0 && nblk > 0 && (cloud == 0 || cloud == 1), DF_E_ARG);
+  DF_REQUIRE((H % 2) == 0 && (W % 2) == 0 && canvas.n == B && canvas.h == H && canvas.w == W && canvas.c == 32, DF_E_SHAPE);
+  SparseInWgradParams p;
+  p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.dy1 = dy1; p.canvas = canvas;
+  p.ws = ws;
+  hipLaunchKernelGGL(sparse_in_wgrad_kernel, dim3(nblk, B), dim3(576), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -300,7 +300,10 @@ class FastFlow3DUNet(nn.Module):
                 else:
                     buf, c = stage_in_grads[sidx]
                     dx, acc = img_pair(buf, c), True
-                self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False)
+                if sidx == 1 and i == 0 and sparse_input_grad:
+                    pass  # neither data nor weight gradient here: the caller evaluates both at occupied pillars only
+                else:
+                    self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False)
                 dz = dx
             if phase is not None:
                 phase(stage.parameters())

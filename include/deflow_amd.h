@@ -122,6 +122,12 @@ int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B,
 int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const float* w,
                       const float* bias, df_img y, int nblk, void* stream);
 
+/* Weight gradient of the first encoder conv (3x3, stride 2, pad 1, 32 -> 64; dy1 [2B,H/2,W/2,64], image = cloud*B + b)
+ * summed over the occupied cells of one cloud's canvas [B,H,W,32] only.  ws [nblk*B][64][9][32] partials; finish with
+ * df_conv2d_wgrad_reduce(ws, nblk*B, 64, 9, 32, ..., accumulate = cloud). */
+int df_sparse_in_wgrad(const uint32_t* key_sorted, const int32_t* counts, int B, int H, int W, int cloud,
+                       const float* dy1, df_img canvas, float* ws, int nblk, void* stream);
+
 /* ------------------------------------------------------------- BEV convolutions (A5) ---
  * Replaces torch.nn.Conv2d / BatchNorm2d / GELU / interpolate inside FastFlow3DUNet and
  * ConvWithNorms ([REF decoder.py:202-220]).  fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM. */
