@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (the metric is quoted at 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="also time BASELINE configs[1] (B=1 inference) after the training steps; off by default so that a\n"
+                         "rocprofv3 trace of the default command holds training launches only")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events of the conv kernels")
     args = ap.parse_args()
 
@@ -140,7 +143,7 @@ def main():
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
                                                     "ms_per_step": v["ms"] / args.steps,
                                                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}}
-    if world == 1:
+    if world == 1 and args.forward_only:
         # forward-only pairs/s of BASELINE configs[1] (one 80k-point pair, eval mode) beside the headline
         model.eval()
         b1 = synth_batch(1, N_POINTS, seed=20240116, device=dev)
