@@ -112,6 +112,40 @@ def test_train_step_vs_oracle(dev):
     print(f"[parity] worst parameter-gradient rel err: {worst:.3e}")
 
 
+def test_full_size_train_step_vs_oracle(dev):
+    """the BASELINE shape itself (512 x 512 grid, 80 000 points per cloud, 4 GRU iterations; one pair): loss, flow and
+    every parameter gradient of a training step against the oracle's autograd (about 15 s of CPU time).  This is the
+    shape at which the 8/12-wave tiles, the two-stage reductions and the sparse edge kernels are actually exercised."""
+    import deflow_amd
+    from oracle import ref_torch as O
+    from deflow_amd.synth import synth_batch
+    torch.manual_seed(11)
+    ref = O.DeFlow()
+    mine = deflow_amd.DeFlow()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    ref.train(); mine.train()
+    batch = synth_batch(1, 80000)
+    res_r = ref(batch)
+    loss_r = O.training_loss(res_r, batch)
+    loss_r.backward()
+    bd = to_dev(batch, dev)
+    res_m = mine(bd)
+    check("full-size flow", res_m["flow"][0], res_r["flow"][0], 2e-4)
+    loss_m = O.training_loss(res_m, bd)
+    check("full-size loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    loss_m.backward()
+    pr = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in mine.named_parameters():
+        if k.endswith("conv.bias") and "encoder_step" in k:   # cancelled exactly by BatchNorm: noise / noise
+            continue
+        e = rel_err(p.grad, pr[k].grad)
+        worst = max(worst, e)
+        assert e <= 2e-3, (k, e)
+    print(f"[parity] full-size worst parameter-gradient rel err: {worst:.3e}")
+
+
 def test_fastflow3d_train_step_vs_oracle(dev):
     """decoder_option=linear (the fastflow3d head): training step gradients vs the oracle"""
     from oracle import ref_torch as O
