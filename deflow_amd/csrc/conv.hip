@@ -480,6 +480,144 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
   return DF_OK;
 }
 
+// 3x3 stride-1 convolution (forward, and data gradient = correlation with flipped taps) with a HALOED A tile: the 128
+// output pixels of a tile are consecutive pixels of one image row (W % 128 == 0), so the A operands of the three
+// horizontal taps are the same 130 input pixels shifted by one row of the LDS tile.  One A tile [130 x 32] per
+// (vertical tap, k chunk) serves three stages; only the weight tile changes per stage: a third less DMA volume and
+// DMA instructions than the per-tap im2col tiles of conv_dma_kernel (the in-loop DMA costs ~9 % there).  The XOR slot
+// swizzle is keyed on the PHYSICAL tile row, and the b128 fragment reads stay conflict-free for any row shift (every
+// 16-lane service group still touches 16 rows that are distinct mod 16).  8 waves, 2 workgroups per CU (66 KB LDS).
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HR = 136;                 // halo tile rows: 130 used, padded to whole 8-row DMA instructions
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RB = BN / 64;                       // B rows per thread (64 rows per DMA pass of 8 waves)
+  static_assert(WM * WN == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][HR][LDT]
+  float* Bs = lds + 2 * HR * LDT;       // [2][BN][LDT]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int c4 = tid & 7, r0 = tid >> 3;            // DMA lane: physical slot, row within the 64-row pass
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BK;
+  const bool fwd = p.mode == DF_CONV_FWD;
+  RowDecode dec;
+  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = 0; dec.py = dec.px = 0; dec.hh = dec.wh = 0;
+  int n, oy, ox0;
+  dec(m0, n, oy, ox0);
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // A halo: physical row j = 64 i + r0 (i = 0, 1, 2; rows >= 130 unused) holds input pixel (oy - 1 + ty, ox0 - 1 + j)
+  unsigned aoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 64 * i + r0;
+    const int ix = ox0 - 1 + j;
+    const bool ok = j < BM + 2 && ix >= 0 && ix < wx;
+    const int slot = c4 ^ ((j >> 1) & 7);
+    aoff[i] = ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + slot * 4) * 4 + p.dshift) : DMA_BAD;
+  }
+  const int c4b = c4 ^ ((r0 >> 1) & 7);
+  unsigned boff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + 64 * i) * 9 * p.K + c4b * 4) * 4);
+
+  auto load_a = [&](int ty, int kc, int abuf) {     // A halo of group (ty, kc)
+    const bool row_ok = (unsigned)(oy - 1 + ty) < (unsigned)hx;
+    const unsigned soff = (unsigned)((ty * wx * ldx + kc * BK) * 4);
+    float* a = As + abuf * HR * LDT + wave * 8 * LDT;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || wave == 0)   // rows 128..135 ride on wave 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * 64 * LDT), 16, row_ok ? aoff[i] : DMA_BAD, soff, 0, 0);
+  };
+  auto load_b = [&](int ty, int tx, int kc, int bbuf) {
+    const int wtap = fwd ? ty * 3 + tx : (2 - ty) * 3 + (2 - tx);
+    const unsigned soff = (unsigned)((wtap * p.K + kc * BK) * 4);
+    float* b = Bs + bbuf * BN * LDT + wave * 8 * LDT;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 64 * LDT), 16, boff[i], soff, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int ngroups = 3 * KC;
+  load_a(0, 0, 0);
+  load_b(0, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int st = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const int ty = g / KC, kc = g - ty * KC;
+#pragma unroll 1
+    for (int tx = 0; tx < 3; ++tx, ++st) {
+      // prefetch: the next stage's weights; at the first stage of a group also the next group's A halo
+      if (tx < 2) load_b(ty, tx + 1, kc, (st + 1) & 1);
+      else if (g + 1 < ngroups) load_b((g + 1) / KC, 0, (g + 1) % KC, (st + 1) & 1);
+      if (tx == 0 && g + 1 < ngroups) load_a((g + 1) / KC, (g + 1) % KC, (g + 1) & 1);
+      const float* a = As + (g & 1) * HR * LDT + (wm * TM * 32 + li + tx) * LDT;
+      const float* b = Bs + (st & 1) * BN * LDT + (wn * TN * 32 + li) * LDT;
+      const int sa = ((li + tx) >> 1) & 7, sb = (li >> 1) & 7;
+      f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDT + ((kh ^ sa) * 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDT + ((kh ^ sb) * 4));
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        if (q + 1 < BK / 8) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = ld4(a + i * 32 * LDT + (((2 * (q + 1) + kh) ^ sa) * 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[(q + 1) & 1][j] = ld4(b + j * 32 * LDT + (((2 * (q + 1) + kh) ^ sb) * 4));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i][s2], bf[q & 1][j][s2], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
+#endif
+}
+
+template <int BN, int WM, int WN>
+static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * (136 + BN) * LDT * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 // 8-wave forms (512 threads; wave tile 64 x 32 resp. 32 x 32, 32 / 16 accumulator registers): the same LDS footprint
 // and DMA traffic as the 4-wave kernels but twice the waves per SIMD to cover each other's barrier and DMA waits
 // (measured +2..4 % on the 128 x 128 tile).  DMA path only.
@@ -1225,11 +1363,16 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   }
   g_last_dma = p.x_bytes != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // haloed-A kernel: 3x3 stride 1 (fwd / dgrad), rows of 128 output pixels inside one image row, full tiles only
+  static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
+  const bool halo_ok = use_halo && p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && (y.w % 128) == 0 &&
+                       x.w == y.w && x.h == y.h && (var == 128128 || var == 128064);
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
     case 64064: return launch_conv<64, 64, 2, 2>(p, s);
     case 128128: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
+      if (halo_ok) return launch_conv_halo<128, 2, 4>(p, s);
       if ((w8 & 1) && p.x_bytes) return launch_conv_w8<128, 128, 2, 4>(p, s);
       return launch_conv<128, 128, 2, 2>(p, s);
     }
@@ -1240,6 +1383,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
     }
     default: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
+      if (halo_ok) return launch_conv_halo<64, 4, 2>(p, s);
       if ((w8 & 2) && p.x_bytes) return launch_conv_w8<128, 64, 4, 2>(p, s);
       return launch_conv<128, 64, 2, 2>(p, s);
     }

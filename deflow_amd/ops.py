@@ -80,6 +80,10 @@ def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int)
     bm, bn = v // 1000, v % 1000
     wm, wn = {(128, 32): (4, 1), (256, 64): (4, 1)}.get((bm, bn), (2, 2))
     kern = "conv_dma_kernel" if call("df_conv2d_last_dma") else "conv_kernel"
+    halo = (kern == "conv_dma_kernel" and os.environ.get("DF_CONV_HALO", "1") != "0" and ks == 3 and stride == 1 and not cls
+            and y.w % 128 == 0 and x.w == y.w and x.h == y.h and (bm, bn) in ((128, 128), (128, 64)))
+    if halo:  # haloed-A kernel (mirrors df_conv2d's dispatch)
+        return f"conv_halo_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2}>"
     if kern == "conv_dma_kernel":  # 8-wave forms of the two big tiles (DF_CONV_W8 bit 0 / bit 1, default both)
         w8 = int(os.environ.get("DF_CONV_W8", "3"))
         if (bm, bn) == (128, 128) and (w8 & 1):
