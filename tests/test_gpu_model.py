@@ -370,6 +370,46 @@ def test_train_step_gradients_bit_reproducible_under_memory_poison():
     assert float(g0.abs().max()) > 0
 
 
+@pytest.mark.parametrize("B,N,grid", [(1, 1000, 64), (3, 4097, 128), (5, 777, 64), (2, 20000, 256)])
+def test_sparse_edge_kernels_match_dense(B, N, grid):
+    """the four sparse kernels at the UNet's ends (df_pillar_input_grad, df_sparse_in_wgrad, df_sparse_conv3x3,
+    df_sparse_wgrad3x3) against the dense kernels they replace: whole gradient arena of a training step, on odd batch
+    sizes / point counts, with an all-NaN sample and a 5-point sample"""
+    import deflow_amd
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+    dev = torch.device("cuda")
+    torch.manual_seed(B * 7 + N)
+    rng = [-0.1 * grid, -0.1 * grid, -3, 0.1 * grid, 0.1 * grid, 3]
+    m = deflow_amd.DeFlow(grid_feature_size=[grid, grid], point_cloud_range=rng).to(dev).train()
+    tr = Trainer(m, lr=2e-4)
+    batch = synth_batch(B, N, grid_hw=(grid, grid), device=dev)
+    if B >= 3:
+        batch["pc0"][1] = float("nan")
+        batch["pc0"][2, 5:] = float("nan")
+    out = {}
+    old = os.environ.get("DF_DENSE_CANVAS_GRAD")
+    try:
+        for mode in ("0", "1"):
+            os.environ["DF_DENSE_CANVAS_GRAD"] = mode
+            tr.flat.zero_grad()
+            tr.sink.begin()
+            m.forward_padded(batch)
+            loss = tr.loss_on_last_forward(batch)
+            loss.backward()
+            out[mode] = (tr.flat.grad.clone(), float(loss.detach()))
+    finally:
+        if old is None:
+            os.environ.pop("DF_DENSE_CANVAS_GRAD", None)
+        else:
+            os.environ["DF_DENSE_CANVAS_GRAD"] = old
+    g0, g1 = out["0"][0], out["1"][0]
+    assert torch.isfinite(g0).all() and out["0"][1] == pytest.approx(out["1"][1], rel=1e-6)
+    err = float((g0 - g1).abs().max() / g1.abs().max())
+    print(f"[parity] sparse vs dense edge kernels B={B} N={N} grid={grid}: {err:.2e}")
+    assert err < 1e-5
+
+
 @pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1"}, {"DF_WGRAD_DMA_ALL": "1"}, {"DF_WGRAD_RING": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0"}, {"DF_CONV_HALO": "0"}, {"DF_DENSE_CANVAS_GRAD": "1"},
                                  {"DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1"}, {"DF_SIDE_STREAM": "1"}])
 def test_alternate_kernel_paths(env):
