@@ -100,7 +100,9 @@ int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const u
                        const float* w_pfn, const float* bn_ss, int bn_sample_stride, const float* coef, df_img gout,
                        float* dw_partial, int nblk_stat, void* stream);
 
-/* Gradient of the pillar canvas [B,H,W,32] of one cloud (cloud 0 = pc0 = channels 0..31 of the network input, cloud 1 =
+/* (autograd of backbone(pc0_img, pc1_img) [REF deflow.py:87-88] w.r.t. its inputs, which only DynamicEmbedder's pillar
+ * features [REF deflow.py:82-83] consume)
+ * Gradient of the pillar canvas [B,H,W,32] of one cloud (cloud 0 = pc0 = channels 0..31 of the network input, cloud 1 =
  * pc1) evaluated ONLY at that cloud's occupied cells -- the only cells df_pfn_bwd_* read.  Adds (accumulate != 0) or
  * writes the two conv consumers of the canvas in FastFlow3DUNet: the first encoder conv (3x3, stride 2, 32 -> 64:
  * dy1 [2B,H/2,W/2,64] with image = cloud * B + b, w1 [64,3,3,32]) and the decoder's 1x1 skip conv on the 64-channel
@@ -109,7 +111,9 @@ int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* counts, int 
                          const float* dy1, const float* w1, df_img dskip, const float* w3, df_img dcanvas,
                          int accumulate, int nblk, void* stream);
 
-/* Weight (and bias) gradient of a 3x3 stride-1 64 -> 64 conv whose OUTPUT gradient dy [B,H,W,64] is exactly zero outside
+/* (autograd of the integer gather after_pseudoimage[:, y, x] [REF decoder.py:165-168]: the backbone output is read, and
+ * its gradient is non-zero, only at the voxel coordinates of pc0's points)
+ * Weight (and bias) gradient of a 3x3 stride-1 64 -> 64 conv whose OUTPUT gradient dy [B,H,W,64] is exactly zero outside
  * the occupied cells of a pillarised cloud (the UNet's last conv: dy comes from the decoder's gather backward): sums only
  * over those cells.  ws [nblk*B][64][9][64] / bias_ws [nblk*B][64] partials; finish with
  * df_conv2d_wgrad_reduce(ws, nblk*B, 64, 9, 64, ...) and df_colsum_finalize(bias_ws, nblk*B, 64, 1, ...). */
