@@ -64,3 +64,25 @@ def test_state_dict_keys_match_reference_layout():
                      "backbone.decoder_step4.weight": (64, 64, 3, 3)}.items():
         assert tuple(sd[k].shape) == shape, k
     assert sum(p.numel() for p in m.parameters()) == 6891939
+
+
+def test_entry_points_reject_bad_arguments_without_launching(lib_path):
+    """argument validation happens before any kernel launch, so it can be exercised without a GPU: NULL buffers and
+    inconsistent shapes must come back as negative DF_E_* codes, never as a crash or a silent success"""
+    import ctypes as C
+    from deflow_amd._lib import DfImg, load
+    lib = load()
+    null_img = DfImg(0, 0, 0, 0, 0, 0, 1, 0, 0)
+    bad = DfImg(0x1000, 2, 8, 8, 48, 48, 2, 8 * 8 * 48, 0)          # 48 channels: not a multiple of 64
+    ok64 = DfImg(0x1000, 2, 8, 8, 64, 64, 2, 8 * 8 * 64, 0)
+    P = C.c_void_p
+    assert lib.df_sparse_conv3x3(P(0), P(0), 2, null_img, P(0), P(0), null_img, 1, P(0)) < 0
+    assert lib.df_sparse_conv3x3(P(0x1000), P(0x1000), 2, bad, P(0x1000), P(0), ok64, 1, P(0)) < 0
+    assert lib.df_sparse_wgrad3x3(P(0), P(0), 2, null_img, null_img, P(0), P(0), 1, P(0)) < 0
+    assert lib.df_sparse_wgrad3x3(P(0x1000), P(0x1000), 2, bad, ok64, P(0x1000), P(0), 1, P(0)) < 0
+    assert lib.df_pillar_input_grad(P(0), P(0), 2, 8, 8, 0, P(0), P(0), null_img, P(0), null_img, 1, 1, P(0)) < 0
+    assert lib.df_pillar_input_grad(P(0x1000), P(0x1000), 2, 8, 8, 3, P(0x1000), P(0x1000), ok64, P(0x1000), ok64, 1, 1, P(0)) < 0  # cloud 3
+    assert lib.df_sparse_in_wgrad(P(0), P(0), 2, 8, 8, 0, P(0), null_img, P(0), 1, P(0)) < 0
+    assert lib.df_gru_wgrad(P(0), P(0), P(0), 2, 100, 4, P(0), 1, P(0)) < 0
+    assert lib.df_colsum_stage(P(0x1000), 4, 16, 8, P(0x1000), P(0)) < 0                                     # groups > rows
+    assert lib.df_conv2d_wgrad(bad, ok64, 3, 1, 1, P(0), 1, P(0), 0, P(0), P(0)) < 0
