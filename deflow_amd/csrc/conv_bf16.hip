@@ -1,0 +1,242 @@
+// bf16 forward convolutions for the inference path of BASELINE configs[4] ("bf16 MFMA"): implicit GEMM on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulation), NHWC bf16 activations, [Cout,kh,kw,Cin] bf16 weights.
+//
+// Same structure as conv_dma_kernel (conv.hip): 8-wave workgroups, 128 x BN tiles, operands by LDS-DMA into
+// double-buffered unpadded tiles whose 16-byte slots are XOR-swizzled by (row >> 1) & 7, zero-fill of padding taps by
+// out-of-range buffer offsets, (tap, k chunk) offsets in soffset.  A tile row is still 128 bytes -- now 64 bf16 of k --
+// and one ds_read_b128 is exactly one MFMA operand (lane (row, kh) holds k = 16 s + 8 kh .. + 7 of k step s), so a stage
+// is 4 MFMA k steps instead of 16: the matrix work per byte moved is 8x that of the fp32 kernel and the kernel is bound
+// by the DMA / LDS path, not by the MFMA pipe.  Epilogues: bias, or bias + folded BatchNorm + exact-erf GELU (fp32 math),
+// stored as bf16 or fp32.  Inference only (no statistics, no accumulate, no data-gradient mode).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BKH = 64;              // k elements per stage (128 bytes)
+constexpr int LDB_ = 32;             // LDS row pitch in floats (128 bytes)
+constexpr unsigned BAD16 = 0xFFFFFFFFu - (8u << 20);
+
+struct ConvHParams {
+  df_img x, y;             // element counts (c, ld, strides) are in bf16 / output elements
+  const __bf16* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  int ks, stride, pad, epi, out_f32;
+  int M, K, N, tiles_m, tiles_n, hw_y;
+  unsigned x_bytes, w_bytes, dshift;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(ConvHParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NW = WM * WN, RP = 8 * NW;
+  constexpr int RA = BM / RP, RB = (BN + RP - 1) / RP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][BM][32 floats = 64 bf16]
+  float* Bs = lds + 2 * BM * LDB_;      // [2][BN][..]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BKH;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const int c4s = c4 ^ ((r0 >> 1) & 7);
+  unsigned aoff[RA], boff[RB];
+  int ay[RA], ax[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + r0 + RP * i;
+    ay[i] = ax[i] = -(1 << 28);
+    aoff[i] = BAD16;
+    if (m < p.M) {
+      const int n = m / p.hw_y, rem = m - n * p.hw_y;
+      const int oy = rem / p.y.w, ox = rem - oy * p.y.w;
+      ay[i] = oy * p.stride - p.pad;
+      ax[i] = ox * p.stride - p.pad;
+      aoff[i] = (unsigned)((df_img_base(p.x, n) + ((int64_t)ay[i] * wx + ax[i]) * ldx + c4s * 8) * 2 + p.dshift);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + RP * i) * p.ks * p.ks * p.K + c4s * 8) * 2);
+
+  int l_kc = 0, l_iky = 0, l_ikx = 0;
+  auto load_stage = [&](int buf) {
+    const int ty = l_iky, tx = l_ikx;
+    const unsigned soffA = (unsigned)(((ty * wx + tx) * ldx + l_kc * BKH) * 2);
+    const unsigned soffB = (unsigned)(((ty * p.ks + tx) * p.K + l_kc * BKH) * 2);
+    float* a = As + buf * BM * LDB_ + wave * 8 * LDB_;
+    float* b = Bs + buf * BN * LDB_ + wave * 8 * LDB_;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const bool ok = (unsigned)(ay[i] + ty) < (unsigned)hx && (unsigned)(ax[i] + tx) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * RP * LDB_), 16, ok ? aoff[i] : BAD16, soffA, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      if (BN % RP == 0 || wave * 8 + RP * i < BN)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * RP * LDB_), 16, boff[i], soffB, 0, 0);
+    if (++l_kc == KC) {
+      l_kc = 0;
+      if (++l_ikx == p.ks) {
+        l_ikx = 0;
+        ++l_iky;
+      }
+    }
+  };
+  int rslot[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rslot[s] = ((2 * s + kh) ^ ((li >> 1) & 7)) * 4;   // float offset of the 16-byte slot
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nst = p.ks * p.ks * KC;
+  load_stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) load_stage(buf ^ 1);
+    const float* a = As + buf * BM * LDB_ + (wm * TM * 32 + li) * LDB_;
+    const float* b = Bs + buf * BN * LDB_ + (wn * TN * 32 + li) * LDB_;
+    f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDB_ + rslot[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDB_ + rslot[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = ld4(a + i * 32 * LDB_ + rslot[s + 1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = ld4(b + j * 32 * LDB_ + rslot[s + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s & 1][i]),
+                                                              __builtin_bit_cast(bf16x8, bf[s & 1][j]), acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- epilogue: row -> output element offset table in LDS, then per-lane stores -----------------------------------
+  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      const int n = m / p.hw_y, rem = m - n * p.hw_y;
+      off = df_img_base(p.y, n) + (int64_t)rem * p.y.ld;
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + li;
+    const float bia = p.bias ? p.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.epi == DF_EPI_BN_GELU) {
+      sc = p.scale[co];
+      sh = p.shift[co];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int64_t off = rowoff[row];
+        if (off < 0) continue;
+        float v = acc[i][j][e] + bia;
+        if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+        if (p.out_f32) reinterpret_cast<float*>(p.y.ptr)[off + co] = v;
+        else reinterpret_cast<__bf16*>(p.y.ptr)[off + co] = (__bf16)v;
+      }
+  }
+#endif
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_bf16(const ConvHParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * (BM + BN) * LDB_ * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t rows, int cin, int ldx,
+                                 int cout) {
+  // y[row][c] = c < cin ? bf16(x[row * ldx + c]) : 0   (channel padding for the 32-channel network input)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cout) return;
+  const int64_t r = i / cout;
+  const int c = (int)(i - r * cout);
+  y[i] = c < cin ? (__bf16)x[r * ldx + c] : (__bf16)0.f;
+}
+
+}  // namespace
+
+extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img y, int ksize, int stride, int pad, int epi,
+                              const float* scale, const float* shift, int out_f32, void* stream) {
+  DF_REQUIRE(x.ptr && y.ptr && w && df_aligned16(x.ptr) && df_aligned16(w), DF_E_ALIGN);
+  DF_REQUIRE(x.n == y.n && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
+  DF_REQUIRE(y.h == (x.h + 2 * pad - ksize) / stride + 1 && y.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
+  DF_REQUIRE((x.c % 64) == 0 && (y.c % 64) == 0 && (x.ld % 8) == 0 && x.grp_size > 0 && y.grp_size > 0, DF_E_SHAPE);
+  DF_REQUIRE(epi == DF_EPI_BIAS || (epi == DF_EPI_BN_GELU && scale && shift), DF_E_ARG);
+  ConvHParams p;
+  p.x = x; p.y = y; p.w = reinterpret_cast<const __bf16*>(w); p.bias = bias; p.scale = scale; p.shift = shift;
+  p.ks = ksize; p.stride = stride; p.pad = pad; p.epi = epi; p.out_f32 = out_f32;
+  p.hw_y = y.h * y.w;
+  const int64_t M = (int64_t)y.n * p.hw_y;
+  DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
+  p.M = (int)M; p.K = x.c; p.N = y.c;
+  const int bn = (p.N % 128 == 0) ? 128 : 64;
+  p.tiles_m = (int)((M + 127) / 128);
+  p.tiles_n = p.N / bn;
+  const int64_t groups = x.n / x.grp_size;
+  const int64_t ext = ((int64_t)(x.grp_size - 1) * x.img_stride + (groups - 1) * x.grp_off + (int64_t)x.h * x.w * x.ld) * 2;
+  const int64_t dsh = (int64_t)pad * ((int64_t)x.w + 1) * x.ld * 2;
+  const int64_t wb = (int64_t)p.N * ksize * ksize * p.K * 2;
+  DF_REQUIRE(x.img_stride >= 0 && x.grp_off >= 0 && ext + dsh < (int64_t)BAD16 - (16 << 20) && wb < (1ll << 31), DF_E_SHAPE);
+  p.x_bytes = (unsigned)(ext + dsh); p.w_bytes = (unsigned)wb; p.dshift = (unsigned)dsh;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (bn == 128) return launch_bf16<128, 128, 2, 4>(p, s);
+  return launch_bf16<128, 64, 4, 2>(p, s);
+}
+
+extern "C" int df_cast_bf16(const float* x, void* y, int64_t rows, int cin, int ldx, int cout, void* stream) {
+  DF_REQUIRE(x && y && rows > 0 && cin > 0 && cout >= cin && ldx >= cin, DF_E_ARG);
+  const int64_t total = rows * cout;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<__bf16*>(y), rows, cin, ldx, cout);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

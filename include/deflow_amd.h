@@ -189,6 +189,13 @@ int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* 
                     const int32_t* row_counts, int rows_per_seg, float* bias_ws, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
+/* bf16 inference convolution (BASELINE configs[4], "bf16 MFMA"): x, w bf16 (NHWC / [Cout,kh,kw,Cin]), fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, epilogue DF_EPI_BIAS or DF_EPI_BN_GELU in fp32, output bf16 (out_f32 = 0) or fp32.
+ * df_img element counts (c, ld, strides) are in elements of the respective type; Cin, Cout multiples of 64.
+ * df_cast_bf16: y[row][c] = bf16(x[row*ldx + c]) for c < cin, 0 for cin <= c < cout (channel padding). */
+int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img y, int ksize, int stride, int pad, int epi,
+                   const float* scale, const float* shift, int out_f32, void* stream);
+int df_cast_bf16(const float* x, void* y, int64_t rows, int cin, int ldx, int cout, void* stream);
 /* bilinear x2 (PyTorch F.interpolate semantics, align_corners selectable), forward and backward */
 int df_upsample2x(df_img x, df_img y, int align_corners, void* stream);
 int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* stream);
