@@ -62,6 +62,7 @@ _SIGS = {
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],
     "df_cast_bf16": [P, P, L, I, I, I, P],
+    "df_upsample2x_bf16": [DfImg, DfImg, I, P],
     "df_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, I, P],
     "df_bn_gelu_apply": [P, P, I, DfImg, P],
     "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],

@@ -340,6 +340,32 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
   }
 }
 
+// bf16 activations (inference path): the same PyTorch lerp semantics evaluated in fp32, 8 channels (16 bytes) per thread
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void upsample2x_bf16_kernel(df_img x, df_img y, int align_corners, int64_t total8) {
+  const int C8 = y.c >> 3;
+  const __bf16* __restrict__ xp = reinterpret_cast<const __bf16*>(x.ptr);
+  __bf16* __restrict__ yp = reinterpret_cast<__bf16*>(y.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    const int X = (int)(m % y.w);
+    m /= y.w;
+    const int Y = (int)(m % y.h), n = (int)(m / y.h);
+    const Lerp ly = lerp_src(Y, x.h, y.h, align_corners), lx = lerp_src(X, x.w, y.w, align_corners);
+    const __bf16* b = xp + df_img_base(x, n) + c;
+    const bf16x8_t v00 = *reinterpret_cast<const bf16x8_t*>(b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld);
+    const bf16x8_t v01 = *reinterpret_cast<const bf16x8_t*>(b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld);
+    const bf16x8_t v10 = *reinterpret_cast<const bf16x8_t*>(b + ((int64_t)ly.i1 * x.w + lx.i0) * x.ld);
+    const bf16x8_t v11 = *reinterpret_cast<const bf16x8_t*>(b + ((int64_t)ly.i1 * x.w + lx.i1) * x.ld);
+    bf16x8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      o[k] = (__bf16)(ly.l0 * (lx.l0 * (float)v00[k] + lx.l1 * (float)v01[k]) + ly.l1 * (lx.l0 * (float)v10[k] + lx.l1 * (float)v11[k]));
+    *reinterpret_cast<bf16x8_t*>(yp + df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c) = o;
+  }
+}
+
 // gather form of the transpose: every input pixel sums the <= 6x6 output pixels that read it
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(df_img dy, df_img dx, int align_corners, int64_t total4) {
   const int C4 = dx.c >> 2;
@@ -497,6 +523,17 @@ extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
   hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                      y, align_corners, total4);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_upsample2x_bf16(df_img x, df_img y, int align_corners, void* stream) {
+  DF_REQUIRE(x.ptr && y.ptr && df_aligned16(x.ptr) && df_aligned16(y.ptr), DF_E_ARG);
+  DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w && (x.c % 8) == 0 && (x.ld % 8) == 0 && (y.ld % 8) == 0,
+             DF_E_SHAPE);
+  const int64_t total8 = (int64_t)y.n * y.h * y.w * (y.c / 8);
+  hipLaunchKernelGGL(upsample2x_bf16_kernel, dim3(grid_for(total8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     y, align_corners, total8);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

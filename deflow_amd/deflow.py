@@ -43,6 +43,7 @@ class DeFlow(nn.Module):
         self.timer = Timing()
         self.timer.start("Total")
         self._state_tmp: Optional[dict] = None
+        self.inference_dtype = "fp32"  # "bf16": eval-mode forwards run the UNet on bf16 MFMA (BASELINE configs[4])
         self.last_state: Optional[dict] = None  # padded device-side tensors of the last forward (fast trainer path)
 
     def load_from_checkpoint(self, ckpt_path):
@@ -64,9 +65,13 @@ class DeFlow(nn.Module):
         self.timer[1].stop()
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None
-        # `v` is consumed by the decoder's gather alone: only pc0's occupied cells of it are computed
-        sparse_out = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(self.backbone, FastFlow3DUNet)
-        v = self.backbone.run(bstar, train, tape, out_cells=p0 if sparse_out else None)
+        if self.inference_dtype == "bf16" and not train and not save:
+            # BASELINE configs[4]: UNet on bf16 MFMA (fp32 accumulation and epilogues); pillars and decoder stay fp32
+            v = self.backbone.run_bf16(bstar)
+        else:
+            # `v` is consumed by the decoder's gather alone: only pc0's occupied cells of it are computed
+            sparse_out = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(self.backbone, FastFlow3DUNet)
+            v = self.backbone.run(bstar, train, tape, out_cells=p0 if sparse_out else None)
         self.timer[2].stop()
         self.timer[3].start("Decoder")
         ps = PointSet(p0.coords_c, p0.offs_c, p0.counts, p0.idx_sorted, p0.cell_rng, p0.cpos)

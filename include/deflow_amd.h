@@ -196,6 +196,7 @@ int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int 
 int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img y, int ksize, int stride, int pad, int epi,
                    const float* scale, const float* shift, int out_f32, void* stream);
 int df_cast_bf16(const float* x, void* y, int64_t rows, int cin, int ldx, int cout, void* stream);
+int df_upsample2x_bf16(df_img x, df_img y, int align_corners, void* stream); /* bf16 in / out, fp32 lerp */
 /* bilinear x2 (PyTorch F.interpolate semantics, align_corners selectable), forward and backward */
 int df_upsample2x(df_img x, df_img y, int align_corners, void* stream);
 int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* stream);

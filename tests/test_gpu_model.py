@@ -319,6 +319,32 @@ def test_edge_cases_empty_ragged_and_big_grid(dev):
     assert torch.equal(f, r2["flow"][0])
 
 
+def test_bf16_inference_path_vs_oracle(dev):
+    """BASELINE configs[4] ("bf16 MFMA"): eval-mode forward with the UNet on v_mfma_f32_32x32x16_bf16 (bf16 activations and
+    weights, fp32 accumulation / BatchNorm / GELU; pillars and GRU decoder fp32) against the fp32 CPU oracle.
+    Stated tolerance: 2e-2 of the largest flow component (bf16 carries 8 mantissa bits through ~30 conv layers;
+    measured 3e-4 .. 1e-3), integer outputs still bit-exact."""
+    ref, mine = build_pair(dev, 21, decoder_option="gru", num_iters=4)
+    ref.eval(); mine.eval()
+    mine.inference_dtype = "bf16"
+    batch = make_batch(2, 1500, 300)
+    with torch.no_grad():
+        want = ref(batch)
+        got = mine(to_dev(batch, dev))
+    for b in range(2):
+        assert torch.equal(got["pc0_valid_point_idxes"][b].cpu(), want["pc0_valid_point_idxes"][b])
+        w, g = want["flow"][b], got["flow"][b].cpu()
+        err = float((g - w).abs().max() / w.abs().max())
+        print(f"[parity] bf16 inference flow b{b}: max abs err / max |flow| = {err:.2e} (tol 2e-2)")
+        assert err <= 2e-2
+    # the switch only affects eval-mode forwards: a training step still runs (and matches) the fp32 kernels
+    mine.train(); ref.train()
+    from oracle import ref_torch as O
+    lr_ = O.training_loss(ref(batch), batch)
+    lm_ = O.training_loss(mine(to_dev(batch, dev)), to_dev(batch, dev))
+    check("loss with bf16 inference switch set", lm_.reshape(1), lr_.reshape(1), 1e-4)
+
+
 def test_train_mode_forward_without_grad_is_repeatable():
     """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
     (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
