@@ -192,14 +192,29 @@ int launch_bf16(const ConvHParams& p, hipStream_t s) {
   return DF_OK;
 }
 
-__global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t rows, int cin, int ldx,
-                                 int cout) {
-  // y[row][c] = c < cin ? bf16(x[row * ldx + c]) : 0   (channel padding for the 32-channel network input)
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cout) return;
-  const int64_t r = i / cout;
-  const int c = (int)(i - r * cout);
-  y[i] = c < cin ? (__bf16)x[r * ldx + c] : (__bf16)0.f;
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t rows,
+                                                         int cin, int ldx, int cout) {
+  // y[row][c] = c < cin ? bf16(x[row * ldx + c]) : 0   (channel padding for the 32-channel network input);
+  // 8 channels (two 16-byte loads, one 16-byte store) per thread; cin, cout, ldx multiples of 8
+  const int C8 = cout >> 3;
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    bf16x8 o;
+    if (c < cin) {
+      const f32x4 a = ld4(x + r * ldx + c), b = ld4(x + r * ldx + c + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = (__bf16)a[k];
+        o[4 + k] = (__bf16)b[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+  }
 }
 
 }  // namespace
@@ -234,8 +249,10 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
 
 extern "C" int df_cast_bf16(const float* x, void* y, int64_t rows, int cin, int ldx, int cout, void* stream) {
   DF_REQUIRE(x && y && rows > 0 && cin > 0 && cout >= cin && ldx >= cin, DF_E_ARG);
-  const int64_t total = rows * cout;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  DF_REQUIRE((cin % 8) == 0 && (cout % 8) == 0 && (ldx % 4) == 0 && df_aligned16(x) && df_aligned16(y), DF_E_ALIGN);
+  const int64_t total = rows * (cout / 8);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<__bf16*>(y), rows, cin, ldx, cout);
   DF_CHECK_LAUNCH();
   return DF_OK;
