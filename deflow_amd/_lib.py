@@ -78,6 +78,7 @@ _SIGS = {
     "df_upsample2x": [DfImg, DfImg, I, P],
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],
     "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],
+    "df_gru_decoder_fwd_bf16": [DfImg, DfImg, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
     "df_gru_wgrad_splits": [],
     "df_gru_wgrad": [P, P, P, I, I, I, P, I, P],

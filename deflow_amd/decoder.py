@@ -117,6 +117,26 @@ class ConvGRUDecoder(nn.Module):
              ptr(sv), stream())
         return flow, sv
 
+    def run_bf16(self, before: DfImg, after: DfImg, ps: PointSet):
+        """Inference forward with the gate GEMMs and the head's first layer on bf16 MFMA (fp32 state, gates and
+        accumulation; BASELINE configs[4]).  bf16 weight copies are cached until a parameter changes."""
+        B, N, _ = ps.coords.shape
+        flow = torch.empty(B, N, 3, dtype=torch.float32, device=ps.coords.device)
+        W, (w_zr, b_zr, w_q) = self._weights()
+        key = (ops.PARAM_GEN[0],) + tuple(p._version for p in self.parameters())
+        c = getattr(self, "_df_bf16", None)
+        if c is None or c[0] != key:
+            c = (key, w_zr.to(torch.bfloat16).contiguous(), w_q.to(torch.bfloat16).contiguous(),
+                 self.decoder[0].weight.detach().to(torch.bfloat16).contiguous())
+            self._df_bf16 = c
+        _, wzr16, wq16, w116 = c
+        g, d = self.gru, self.decoder
+        call("df_gru_decoder_fwd_bf16", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, self.num_iters,
+             ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(wzr16), ptr(b_zr), ptr(wq16),
+             ptr(g.convq.bias.detach()), ptr(w116), ptr(d[0].bias.detach()), ptr(d[2].weight.detach()), ptr(d[2].bias.detach()),
+             ptr(flow), stream())
+        return flow, None
+
     def run_backward(self, dflow: torch.Tensor, ps: PointSet, sv: torch.Tensor, dbefore: DfImg, dafter: DfImg,
                      acc_before: bool, acc_after: bool, grads: dict, before: DfImg = None, after: DfImg = None):
         B, N, _ = ps.coords.shape

@@ -75,7 +75,10 @@ class DeFlow(nn.Module):
         self.timer[2].stop()
         self.timer[3].start("Decoder")
         ps = PointSet(p0.coords_c, p0.offs_c, p0.counts, p0.idx_sorted, p0.cell_rng, p0.cpos)
-        flow, sv = self.head.run(img(bstar), img(v), ps, save)
+        if self.inference_dtype == "bf16" and not train and not save and hasattr(self.head, "run_bf16"):
+            flow, sv = self.head.run_bf16(img(bstar), img(v), ps)
+        else:
+            flow, sv = self.head.run(img(bstar), img(v), ps, save)
         self.timer[3].stop()
         return flow, {"bstar": bstar, "v": v, "p0": p0, "p1": p1, "ps": ps, "tape": tape, "sv": sv}
 

@@ -248,6 +248,13 @@ int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* c
  * r % rows_per_seg < counts[(r / rows_per_seg) % nseg].  na*nb <= 256.  Sum with df_colsum_finalize. */
 int df_small_outer(const float* a, int lda, int na, const float* b, int ldb, int nb, const int32_t* counts,
                    int rows_per_seg, int nseg, int64_t rows, float* partial, int nblk, void* stream);
+/* ConvGRUDecoder forward with the gate GEMMs and the first head layer on bf16 MFMA (inference, BASELINE configs[4]):
+ * w_zr [256,192], w_q [128,192], w_1 [32,192] bf16; everything else (images, biases, offset encoder, last layer, state,
+ * gate non-linearities, accumulation) fp32. */
+int df_gru_decoder_fwd_bf16(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
+                            int B, int N, int num_iters, const float* w_off, const float* b_off, const void* w_zr,
+                            const float* b_zr, const void* w_q, const float* b_q, const void* w_1, const float* b_1,
+                            const float* w_2, const float* b_2, float* flow, void* stream);
 /* LinearDecoder ([REF decoder.py:72-120]) forward: w_off [128,3], w_1 [32,256], w_2 [3,32] */
 int df_linear_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
                           const int32_t* counts, int B, int N, const float* w_off, const float* b_off,
