@@ -31,6 +31,49 @@ struct ConvHParams {
 };
 
 template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_bf16(const ConvHParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* lds, int m0,
+                                              int n0) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  // ---- epilogue: row -> output element offset table in LDS, then per-lane stores -----------------------------------
+  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      const int n = m / p.hw_y, rem = m - n * p.hw_y;
+      off = df_img_base(p.y, n) + (int64_t)rem * p.y.ld;
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + li;
+    const float bia = p.bias ? p.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (p.epi == DF_EPI_BN_GELU) {
+      sc = p.scale[co];
+      sh = p.shift[co];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int64_t off = rowoff[row];
+        if (off < 0) continue;
+        float v = acc[i][j][e] + bia;
+        if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+        if (p.out_f32) reinterpret_cast<float*>(p.y.ptr)[off + co] = v;
+        else reinterpret_cast<__bf16*>(p.y.ptr)[off + co] = (__bf16)v;
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -140,41 +183,137 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(ConvHParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  // ---- epilogue: row -> output element offset table in LDS, then per-lane stores -----------------------------------
-  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int64_t off = -1;
-    if (m < p.M) {
-      const int n = m / p.hw_y, rem = m - n * p.hw_y;
-      off = df_img_base(p.y, n) + (int64_t)rem * p.y.ld;
-    }
-    rowoff[tid] = off;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + (wn * TN + j) * 32 + li;
-    const float bia = p.bias ? p.bias[co] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (p.epi == DF_EPI_BN_GELU) {
-      sc = p.scale[co];
-      sh = p.shift[co];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int64_t off = rowoff[row];
-        if (off < 0) continue;
-        float v = acc[i][j][e] + bia;
-        if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-        if (p.out_f32) reinterpret_cast<float*>(p.y.ptr)[off + co] = v;
-        else reinterpret_cast<__bf16*>(p.y.ptr)[off + co] = (__bf16)v;
-      }
-  }
+  epilogue_bf16<BM, BN, WM, WN>(p, acc, lds, m0, n0);
 #endif
+}
+
+// Haloed-A form for 3x3 stride 1 (see conv_halo_kernel in conv.hip): one [130 px x 64 ch] A tile per (vertical tap, k chunk)
+// serves the three horizontal taps -- for this DMA-bound kernel a third less traffic is worth proportionally more.
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_halo_bf16_kernel(ConvHParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HR = 136;                 // halo tile rows: 130 used, padded to whole 8-row DMA instructions
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RB = BN / 64;                       // B rows per thread (64 rows per DMA pass of 8 waves)
+  static_assert(WM * WN == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][HR][128 bytes]
+  float* Bs = lds + 2 * HR * LDB_;      // [2][BN][128 bytes]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int c4 = tid & 7, r0 = tid >> 3;            // DMA lane: physical slot, row within the 64-row pass
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BKH;
+  const int n = m0 / p.hw_y, rem0 = m0 - n * p.hw_y;
+  const int oy = rem0 / p.y.w, ox0 = rem0 - oy * p.y.w;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // A halo: physical row j = 64 i + r0 (i = 0, 1, 2; rows >= 130 unused) holds input pixel (oy - 1 + ty, ox0 - 1 + j)
+  unsigned aoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 64 * i + r0;
+    const int ix = ox0 - 1 + j;
+    const bool ok = j < BM + 2 && ix >= 0 && ix < wx;
+    const int slot = c4 ^ ((j >> 1) & 7);
+    aoff[i] = ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + slot * 8) * 2 + p.dshift) : BAD16;
+  }
+  const int c4b = c4 ^ ((r0 >> 1) & 7);
+  unsigned boff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + 64 * i) * 9 * p.K + c4b * 8) * 2);
+
+  auto load_a = [&](int ty, int kc, int abuf) {     // A halo of group (ty, kc)
+    const bool row_ok = (unsigned)(oy - 1 + ty) < (unsigned)hx;
+    const unsigned soff = (unsigned)((ty * wx * ldx + kc * BKH) * 2);
+    float* a = As + abuf * HR * LDB_ + wave * 8 * LDB_;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || wave == 0)   // rows 128..135 ride on wave 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * 64 * LDB_), 16, row_ok ? aoff[i] : BAD16, soff, 0, 0);
+  };
+  auto load_b = [&](int ty, int tx, int kc, int bbuf) {
+    const unsigned soff = (unsigned)(((ty * 3 + tx) * p.K + kc * BKH) * 2);
+    float* b = Bs + bbuf * BN * LDB_ + wave * 8 * LDB_;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 64 * LDB_), 16, boff[i], soff, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int ngroups = 3 * KC;
+  load_a(0, 0, 0);
+  load_b(0, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int st = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const int ty = g / KC, kc = g - ty * KC;
+#pragma unroll 1
+    for (int tx = 0; tx < 3; ++tx, ++st) {
+      // prefetch: the next stage's weights; at the first stage of a group also the next group's A halo
+      if (tx < 2) load_b(ty, tx + 1, kc, (st + 1) & 1);
+      else if (g + 1 < ngroups) load_b((g + 1) / KC, 0, (g + 1) % KC, (st + 1) & 1);
+      if (tx == 0 && g + 1 < ngroups) load_a((g + 1) / KC, (g + 1) % KC, (g + 1) & 1);
+      const float* a = As + (g & 1) * HR * LDB_ + (wm * TM * 32 + li + tx) * LDB_;
+      const float* b = Bs + (st & 1) * BN * LDB_ + (wn * TN * 32 + li) * LDB_;
+      const int sa = ((li + tx) >> 1) & 7, sb = (li >> 1) & 7;
+      f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDB_ + ((kh ^ sa) * 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDB_ + ((kh ^ sb) * 4));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // four k steps of 16
+        if (q + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = ld4(a + i * 32 * LDB_ + (((2 * (q + 1) + kh) ^ sa) * 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[(q + 1) & 1][j] = ld4(b + j * 32 * LDB_ + (((2 * (q + 1) + kh) ^ sb) * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q & 1][i]),
+                                                                __builtin_bit_cast(bf16x8, bf[q & 1][j]), acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  epilogue_bf16<BM, BN, WM, WN>(p, acc, lds, m0, n0);
+#endif
+}
+
+
+template <int BN, int WM, int WN>
+int launch_halo_bf16(const ConvHParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * (136 + BN) * LDB_ * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf16_kernel<BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo_bf16_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -243,6 +382,11 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
   DF_REQUIRE(x.img_stride >= 0 && x.grp_off >= 0 && ext + dsh < (int64_t)BAD16 - (16 << 20) && wb < (1ll << 31), DF_E_SHAPE);
   p.x_bytes = (unsigned)(ext + dsh); p.w_bytes = (unsigned)wb; p.dshift = (unsigned)dsh;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
+  if (use_halo && ksize == 3 && stride == 1 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {
+    if (bn == 128) return launch_halo_bf16<128, 2, 4>(p, s);
+    return launch_halo_bf16<64, 4, 2>(p, s);
+  }
   if (bn == 128) return launch_bf16<128, 128, 2, 4>(p, s);
   return launch_bf16<128, 64, 4, 2>(p, s);
 }
