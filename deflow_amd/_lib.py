@@ -49,9 +49,9 @@ _SIGS = {
     "df_pfn_stats": [P, P, P, P, I, DfGeom, P, P, I, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
     "df_pfn_canvas": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
-    "df_pfn_bwd_stats": [P, P, P, P, I, DfGeom, P, P, I, DfImg, P, I, P],
+    "df_pfn_bwd_stats": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, P, I, P],
     "df_pfn_bwd_finalize": [P, I, I, P, P, P, I, P, P],
-    "df_pfn_bwd_weights": [P, P, P, P, I, DfGeom, P, P, I, P, DfImg, P, I, P],
+    "df_pfn_bwd_weights": [P, P, P, P, I, DfGeom, P, P, I, I, P, DfImg, P, I, P],
     "df_sparse_in_wgrad": [P, P, I, I, I, I, P, DfImg, P, I, P],
     "df_sparse_conv3x3": [P, P, I, DfImg, P, P, DfImg, I, P],
     "df_sparse_wgrad3x3": [P, P, I, DfImg, DfImg, P, P, I, P],

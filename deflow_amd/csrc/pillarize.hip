@@ -204,6 +204,25 @@ __device__ __forceinline__ void pfn_linear(const PfnCtx& c, const float (&f)[9],
   }
 }
 
+
+// mode 1 (DynamicScatter 'max'): the pillar's gradient goes, per channel, to the FIRST point (lowest input index; the
+// stable sort keeps input order inside a pillar) whose post-ReLU feature equals the pillar maximum -- the traceback rule
+// of mmcv's dynamic_point_to_voxel_backward.  Returns that sorted position per channel.
+__device__ __forceinline__ void pfn_argmax(const PfnCtx& c, const float* __restrict__ pts, int s, int e, float mx, float my,
+                                           float mz, float ctx, float cty, float ctz, int (&am)[4]) {
+  float best[4];
+  for (int i = s; i < e; ++i) {
+    float f[9], u[4];
+    pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
+    pfn_linear(c, f, u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = fmaxf(fmaf(u[k], c.sc[k], c.sh[k]), 0.f);
+      if (i == s || v > best[k]) { best[k] = v; am[k] = i; }
+    }
+  }
+}
+
 constexpr int CELLS_PER_BLOCK = 32;
 
 // Sparse iteration: the feature-net kernels visit OCCUPIED pillars only.  The sorted key array is globally ordered by
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict
 }
 
 // backward pass A: per-sample sums of (g_hat, g_hat * xhat) where g_hat = dL/d(BN output) after the ReLU mask
+template <int MODE>
 __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restrict__ pts,
                                                             const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
@@ -392,7 +412,9 @@ __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restr
     pfn_mean(pts, s, e, mx, my, mz);
     pfn_centre(g, cell, ctx, cty, ctz);
     const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
-    const float inv = 1.f / (float)(e - s);
+    const float inv = MODE == 0 ? 1.f / (float)(e - s) : 1.f;
+    int am[4] = {0, 0, 0, 0};
+    if (MODE == 1) pfn_argmax(c, pts, s, e, mx, my, mz, ctx, cty, ctz, am);
     for (int i = s; i < e; ++i) {
       float f[9], u[4];
       pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_stats_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float yh = fmaf(u[k], c.sc[k], c.sh[k]);
-        const float gh = yh > 0.f ? gc[k] * inv : 0.f;
+        const float gh = (yh > 0.f && (MODE == 0 || i == am[k])) ? gc[k] * inv : 0.f;
         acc[k] += gh;
         acc[4 + k] += gh * ((u[k] - c.mu[k]) * c.is[k]);
       }
@@ -452,6 +474,7 @@ __global__ void pfn_bwd_finalize_kernel(const float* __restrict__ partial, int B
 }
 
 // backward pass B: dW[32][9] partial sums of du (x) f
+template <int MODE>
 __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __restrict__ pts,
                                                               const int32_t* __restrict__ cell_rng,
     const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
@@ -486,7 +509,9 @@ __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __res
     pfn_mean(pts, s, e, mx, my, mz);
     pfn_centre(g, cell, ctx, cty, ctz);
     const f32x4 gc = ld4(gp + (int64_t)cell * gout.ld + 4 * sub);
-    const float inv = 1.f / (float)(e - s);
+    const float inv = MODE == 0 ? 1.f / (float)(e - s) : 1.f;
+    int am[4] = {0, 0, 0, 0};
+    if (MODE == 1) pfn_argmax(c, pts, s, e, mx, my, mz, ctx, cty, ctz, am);
     for (int i = s; i < e; ++i) {
       float f[9], u[4];
       pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
@@ -494,7 +519,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_weights_kernel(const float* __res
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float yh = fmaf(u[k], c.sc[k], c.sh[k]);
-        const float gh = yh > 0.f ? gc[k] * inv : 0.f;
+        const float gh = (yh > 0.f && (MODE == 0 || i == am[k])) ? gc[k] * inv : 0.f;
         const float xh = (u[k] - c.mu[k]) * c.is[k];
         const float du = c.sc[k] * (gh - c1[k] - xh * c2[k]);
 #pragma unroll
@@ -1052,11 +1077,14 @@ extern "C" int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, c
 extern "C" int df_pfn_bwd_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                                 df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
-                                df_img gout, float* partial, int nblk_stat, void* stream) {
+                                int mode, df_img gout, float* partial, int nblk_stat, void* stream) {
   DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && gout.ptr && partial && nblk_stat > 0 && geom_ok(g),
              DF_E_ARG);
+  DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
-  hipLaunchKernelGGL(pfn_bwd_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
+  const auto kern = mode == 0 ? pfn_bwd_stats_kernel<0> : pfn_bwd_stats_kernel<1>;
+  hipLaunchKernelGGL(kern, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng,
+                     key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, gout, partial);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1073,12 +1101,15 @@ extern "C" int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, c
 extern "C" int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B,
                                   df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride,
-                                  const float* coef, df_img gout, float* dw_partial, int nblk_stat, void* stream) {
+                                  int mode, const float* coef, df_img gout, float* dw_partial, int nblk_stat,
+                                  void* stream) {
   DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && coef && gout.ptr && dw_partial && nblk_stat > 0 &&
                  geom_ok(g),
              DF_E_ARG);
+  DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
   DF_REQUIRE(gout.n == B && gout.h == g.gy && gout.w == g.gx && gout.c == 32 && (gout.ld % 4) == 0, DF_E_SHAPE);
-  hipLaunchKernelGGL(pfn_bwd_weights_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  const auto kern = mode == 0 ? pfn_bwd_weights_kernel<0> : pfn_bwd_weights_kernel<1>;
+  hipLaunchKernelGGL(kern, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, coef, gout, dw_partial);
   DF_CHECK_LAUNCH();
   return DF_OK;

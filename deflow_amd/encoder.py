@@ -134,7 +134,6 @@ class DynamicEmbedder(nn.Module):
 
     def pillarize_bwd(self, st: PillarState, gout: DfImg, grads: Optional[Tuple[torch.Tensor, ...]]):
         """Accumulates (dW [32,9], dgamma [32], dbeta [32]) for one cloud set; grads=None starts from zero."""
-        assert self.mode == 0, "backward is implemented for mode='avg' (the reference's setting)"
         B, N, _ = st.pts.shape
         dev, g, s = st.pts.device, self.geom, stream()
         w = self._lin.weight.detach()
@@ -146,12 +145,12 @@ class DynamicEmbedder(nn.Module):
         dW, dgamma, dbeta = grads
         partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_stats", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
-             st.bn_stride, gout, ptr(partial), nbs, s)
+             st.bn_stride, self.mode, gout, ptr(partial), nbs, s)
         coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
         dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_weights", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
-             st.bn_stride, ptr(coef), gout, ptr(dwp), nbs, s)
+             st.bn_stride, self.mode, ptr(coef), gout, ptr(dwp), nbs, s)
         call("df_colsum_finalize", ptr(dwp), B * nbs, 288, 1, ptr(dW), int(acc), s)
         return grads
 

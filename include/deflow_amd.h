@@ -87,18 +87,19 @@ int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, const uint32
     const int32_t* counts, int B, df_pillar_geom g,
                   const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, df_img out, int nblk,
                   void* stream);
-/* backward (mean mode): pass A partial sums [B,nblk_stat,32,2] of (g_hat, g_hat*xhat); finalize -> dgamma, dbeta,
+/* backward; mode as df_pfn_canvas (0 'avg': every point of a pillar gets g / count; 1 'max': per channel the pillar's
+ * first maximal point gets g, mmcv's traceback rule): pass A partial sums [B,nblk_stat,32,2] of (g_hat, g_hat*xhat); finalize -> dgamma, dbeta,
  * coef [B,2,32] = (S1/M_b, S2/M_b); pass B dW partials [B*nblk_stat,32,9] (sum with df_colsum_finalize). */
 int df_pfn_bwd_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
-                     const float* w_pfn, const float* bn_ss, int bn_sample_stride, df_img gout, float* partial,
-                     int nblk_stat, void* stream);
+                     const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, df_img gout,
+                     float* partial, int nblk_stat, void* stream);
 int df_pfn_bwd_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, float* dgamma,
                         float* dbeta, int accumulate, float* coef, void* stream);
 int df_pfn_bwd_weights(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
     const int32_t* counts, int B, df_pillar_geom g,
-                       const float* w_pfn, const float* bn_ss, int bn_sample_stride, const float* coef, df_img gout,
-                       float* dw_partial, int nblk_stat, void* stream);
+                       const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, const float* coef,
+                       df_img gout, float* dw_partial, int nblk_stat, void* stream);
 
 /* (autograd of backbone(pc0_img, pc1_img) [REF deflow.py:87-88] w.r.t. its inputs, which only DynamicEmbedder's pillar
  * features [REF deflow.py:82-83] consume)

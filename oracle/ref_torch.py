@@ -153,10 +153,17 @@ class DynamicPillarFeatureNet(nn.Module):
         point_feats = self.pfn_layers[0](feats)
         if self.mode == "avg":
             voxel_feats, voxel_coors, _ = _scatter_mean(point_feats, coors)
-        else:  # 'max'
+        else:  # 'max' -- mmcv DynamicScatter(reduce 'max'): the backward traces each (pillar, channel) maximum back
+            # to the FIRST point that attains it (dynamic_point_to_voxel_backward), so select that point explicitly
             uc, inv2 = torch.unique(coors, dim=0, return_inverse=True)
-            voxel_feats = torch.full((uc.shape[0], point_feats.shape[1]), -float("inf"), dtype=point_feats.dtype)
-            voxel_feats = voxel_feats.scatter_reduce(0, inv2[:, None].expand_as(point_feats), point_feats, "amax")
+            M, C = point_feats.shape
+            idx = inv2[:, None].expand(M, C)
+            vmax = torch.full((uc.shape[0], C), -float("inf"), dtype=point_feats.dtype)
+            vmax = vmax.scatter_reduce(0, idx, point_feats.detach(), "amax")
+            order = torch.arange(M)[:, None].expand(M, C)
+            cand = torch.where(point_feats.detach() == vmax[inv2], order, torch.full_like(order, M))
+            first = torch.full((uc.shape[0], C), M, dtype=torch.long).scatter_reduce(0, idx, cand, "amin")
+            voxel_feats = point_feats.gather(0, first)
             voxel_coors = uc
         return voxel_feats, voxel_coors
 

@@ -112,6 +112,38 @@ def test_train_step_vs_oracle(dev):
     print(f"[parity] worst parameter-gradient rel err: {worst:.3e}")
 
 
+def test_train_step_scatter_max_vs_oracle(dev):
+    """DynamicScatter reduce 'max' (the embedder's mode="max"): forward canvas and the whole training step against the
+    oracle, whose backward follows mmcv's rule (the first maximal point of a pillar takes the channel's gradient)."""
+    from oracle import ref_torch as O
+    ref, mine = build_pair(dev, 5, decoder_option="gru", num_iters=2)
+    ref.embedder.feature_net.mode = "max"
+    mine.embedder.mode = 1
+    ref.train(); mine.train()
+    batch = make_batch(2, 3000, 700)       # ~0.7 points per cell on average: many multi-point pillars
+    res_r = ref(batch)
+    loss_r = O.training_loss(res_r, batch)
+    loss_r.backward()
+    bd = to_dev(batch, dev)
+    res_m = mine(bd)
+    for b in range(2):
+        check(f"max-mode flow b{b}", res_m["flow"][b], res_r["flow"][b], 2e-4)
+    loss_m = O.training_loss(res_m, bd)
+    check("max-mode loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    loss_m.backward()
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        e = rel_err(p.grad, pr[k].grad)
+        if k.startswith("embedder"):
+            print(f"[parity] max-mode grad {k}: rel_err={e:.3e}")
+        if not (k.endswith("conv.bias") and "encoder_step" in k):
+            assert e <= 2e-3, (k, e)
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        want, got = ref.embedder(batch["pc0"])[0], mine.embedder(bd["pc0"])[0]
+    check("max-mode eval canvas", got, want, 1e-5)
+
+
 def test_full_size_train_step_vs_oracle(dev):
     """the BASELINE shape itself (512 x 512 grid, 80 000 points per cloud, 4 GRU iterations; one pair): loss, flow and
     every parameter gradient of a training step against the oracle's autograd (about 15 s of CPU time).  This is the

@@ -162,3 +162,33 @@ def test_deflow_loss_hand_example():
     assert abs(float(got) - want) < 1e-6
     # empty bins are skipped, not NaN
     assert abs(float(O.deflow_loss(est[:1], gt[:1])) - 0.1) < 1e-7
+
+
+def test_scatter_max_restatement_selects_first_maximal_point():
+    """oracle self-check for mode='max' (no reference source for mmcv's DynamicScatter): values equal a plain loop
+    maximum; gradients land on exactly one point per (pillar, channel), the first maximal one, also under exact ties."""
+    import torch
+    from oracle import ref_torch as O
+    torch.manual_seed(3)
+    net = O.DynamicPillarFeatureNet(3, (32,), [0.2, 0.2, 6], [-6.4, -6.4, -3, 6.4, 6.4, 3], mode="max")
+    pts = torch.randn(300, 3)
+    pts[10:20] = pts[0:10]                                   # exact duplicates -> exact ties
+    co = torch.stack([torch.zeros(300, dtype=torch.long), torch.randint(0, 6, (300,)), torch.randint(0, 6, (300,))], 1)
+    co[10:20] = co[0:10]
+    feats = {}
+    def keep(_m, _i, o):
+        o.retain_grad()
+        feats["y"] = o
+    h = net.pfn_layers[0].register_forward_hook(keep)
+    vf, vc = net(pts, co)
+    h.remove()
+    vf.sum().backward()
+    y, gy = feats["y"].detach(), feats["y"].grad
+    for p in range(vc.shape[0]):
+        members = torch.nonzero((co == vc[p]).all(1)).flatten()
+        want = y[members].max(0).values
+        assert torch.equal(vf[p].detach(), want)
+        for c in range(0, 32, 5):
+            hit = torch.nonzero(gy[members, c]).flatten()
+            first = int(torch.nonzero(y[members, c] == want[c]).flatten()[0])
+            assert hit.tolist() == [first], (p, c)
