@@ -13,6 +13,8 @@ Semantics = torch.optim.Adam(params, lr) defaults (no weight decay, no amsgrad) 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -84,8 +86,9 @@ class GradSink:
     Overwrite semantics: one backward per Trainer.step (the Trainer zero-fills the arena first); plain autograd users
     (no sink installed) keep the usual accumulate-into-.grad behaviour."""
 
-    def __init__(self, flat: "FlatParams", dist=None, pg=None, world: int = 1):
+    def __init__(self, flat: "FlatParams", dist=None, pg=None, world: int = 1, collective: bool = None):
         self.flat, self.dist, self.pg, self.world = flat, dist, pg, world
+        self.collective = (world > 1) if collective is None else collective
         self.slot_of = {p.data_ptr(): flat.slots[n] for n, p in flat.named}
         self.delivered = set()
         self.works: list = []
@@ -112,7 +115,7 @@ class GradSink:
         if not dsts:
             return
         torch._foreach_copy_(dsts, srcs)
-        if self.world > 1:
+        if self.collective:
             slots.sort()
             lo, hi = slots[0][0], slots[0][0] + slots[0][1]
             runs = []
@@ -171,10 +174,12 @@ class Trainer:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
-        if self.dist and self.world > 1:  # identical replicas: broadcast rank 0's arena once
+        # DF_FORCE_COLLECTIVES=1 issues the broadcast / all-reduces also on a 1-rank group: the RCCL path of a 1-GPU box
+        self.collective = self.dist is not None and (self.world > 1 or os.environ.get("DF_FORCE_COLLECTIVES") == "1")
+        if self.collective:  # identical replicas: broadcast rank 0's arena once
             self.dist.broadcast(self.flat.param, src=0, group=process_group)
         # models whose backward is hand-sequenced (DeFlowFn) deliver gradients phase by phase through the sink
-        self.sink = GradSink(self.flat, self.dist, process_group, self.world)
+        self.sink = GradSink(self.flat, self.dist, process_group, self.world, self.collective)
         model._grad_sink = self.sink
 
     def loss_on_last_forward(self, batch) -> torch.Tensor:
@@ -191,7 +196,7 @@ class Trainer:
     def reduce_gradients(self) -> float:
         """Sum the gradient arena over the data-parallel ranks (ONE collective over 27.6 MB); returns the scale that
         turns the sum into DDP's mean (folded into the Adam kernel instead of a separate divide pass)."""
-        if self.world > 1:
+        if self.collective:
             if self.sink.delivered:   # bucketed, already in flight: wait; then whatever did not go through the sink
                 self.sink.finish()
                 rest = [p for p in self.flat.params if not self.sink.was_delivered(p)]

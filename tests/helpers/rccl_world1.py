@@ -1,0 +1,56 @@
+"""Run under `python -m torch.distributed.run --nproc-per-node 1` on a 1-GPU box: the data-parallel code path over RCCL
+(process-group init on the device, rank-0 broadcast of the parameter arena, the phase-wise asynchronous all-reduces issued
+from inside the backward, the wait before Adam) on a 1-rank group, where the sum is the identity -- so two training steps
+must leave exactly the parameters a trainer without collectives leaves."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def run(force: bool):
+    import deflow_amd
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+    if force:
+        os.environ["DF_FORCE_COLLECTIVES"] = "1"
+    else:
+        os.environ.pop("DF_FORCE_COLLECTIVES", None)
+    torch.manual_seed(0)
+    dev = torch.device("cuda", 0)
+    model = deflow_amd.DeFlow(grid_feature_size=[128, 128], point_cloud_range=[-12.8, -12.8, -3, 12.8, 12.8, 3],
+                              num_iters=2).to(dev).train()
+    tr = Trainer(model, lr=2e-4)
+    assert tr.collective == force
+    batch = synth_batch(2, 6000, seed=5, device=dev, grid_hw=(128, 128))
+    issued = 0
+    for _ in range(2):
+        tr.flat.zero_grad()
+        tr.sink.begin()
+        model.forward_padded(batch)
+        loss = tr.loss_on_last_forward(batch)
+        loss.backward()
+        issued += len(tr.sink.works)
+        tr.opt.step(grad_scale=tr.reduce_gradients())
+    torch.cuda.synchronize()
+    return tr.flat.param.clone(), tr.flat.grad.clone(), float(loss.detach()), issued
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]),
+                            device_id=torch.device("cuda", 0))
+    p1, g1, l1, n1 = run(True)
+    p0, g0, l0, n0 = run(False)
+    dist.barrier()
+    dist.destroy_process_group()
+    assert n1 >= 4 and n0 == 0, (n1, n0)          # several bucketed all-reduces per backward were really issued
+    assert torch.equal(g1, g0) and torch.equal(p1, p0) and l1 == l0, (float((p1 - p0).abs().max()), l1, l0)
+    print(f"RCCL_WORLD1_OK works={n1} loss={l1:.6f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -481,3 +481,21 @@ def test_alternate_kernel_paths(env):
                         "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rccl_collective_path_on_a_one_rank_group():
+    """the data-parallel path over RCCL itself (not gloo): process group on the device, arena broadcast, the bucketed
+    asynchronous all-reduces issued inside the backward, the wait before Adam -- on the 1-rank group a 1-GPU box allows,
+    where the result must be bit-identical to a trainer that issues no collectives (tests/helpers/rccl_world1.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "helpers", "rccl_world1.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout
