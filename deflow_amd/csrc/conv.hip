@@ -37,6 +37,7 @@ struct ConvParams {
   // can reach it (1, 2, 2 or 4 of 9) instead of multiplying zeros.  cls_tiles = row tiles per class (0 = off).
   int cls_tiles;
   unsigned x_bytes, w_bytes, dshift;  // DMA path: buffer extents (bytes) and the base shift that keeps offsets >= 0
+  unsigned y_bytes;                   // extent of y in bytes if it fits 32-bit buffer offsets (branch-free epilogue), else 0
   int dbg;  // ablation switch (env DF_CONV_DBG): 1 = no global loads after the prologue, 2 = also no LDS stores
 };
 
@@ -83,39 +84,93 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   }
   __syncthreads();
   float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
+  if (p.y_bytes) {
+    // Straight-line stores: buffer stores whose offset is out of range for rows past the end (dropped by the hardware)
+    // instead of a branch per element.  With the branch the compiler had to re-wait for the bias / scale loads inside every
+    // element block -- s_waitcnt vmcnt(0), which also waits for the PREVIOUS element's store: 16 TM serialised write
+    // round trips per wave.
+    constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + (wn * TN + j) * 32 + li;
-    const float bia = p.bias ? p.bias[co] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (p.epi == DF_EPI_BN_GELU) {
-      sc = p.scale[co];
-      sh = p.shift[co];
-    }
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + (wn * TN + j) * 32 + li;
+      const float bia = p.bias ? p.bias[co] : 0.f;
+      float sc = 1.f, sh = 0.f;
+      if (p.epi == DF_EPI_BN_GELU) {
+        sc = p.scale[co];
+        sh = p.shift[co];
+      }
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
+        unsigned ob[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int64_t off = rowoff[row];
-        float v = acc[i][j][e] + bia;
-        if (off >= 0) {
+        for (int e = 0; e < 16; ++e) {
+          const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+          ob[e] = off >= 0 ? (unsigned)((off + co) * 4) : ROW_BAD;
+        }
+        float old[16];
+        if (p.accumulate) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] + bia;
           if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-          if (p.accumulate) v += yp[off + co];
-          yp[off + co] = v;
-          s1 += v;
-          s2 += v * v;
+          if (p.accumulate) v += old[e];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
+          if (ob[e] != ROW_BAD) {
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (p.epi == DF_EPI_STATS) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (kh == 0) {
+          const int cl = (wn * TN + j) * 32 + li;
+          red[(wm * BN + cl) * 2 + 0] = s1;
+          red[(wm * BN + cl) * 2 + 1] = s2;
         }
       }
     }
-    if (p.epi == DF_EPI_STATS) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (kh == 0) {
-        const int cl = (wn * TN + j) * 32 + li;
-        red[(wm * BN + cl) * 2 + 0] = s1;
-        red[(wm * BN + cl) * 2 + 1] = s2;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + (wn * TN + j) * 32 + li;
+      const float bia = p.bias ? p.bias[co] : 0.f;
+      float sc = 1.f, sh = 0.f;
+      if (p.epi == DF_EPI_BN_GELU) {
+        sc = p.scale[co];
+        sh = p.shift[co];
+      }
+      float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) {
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          const int64_t off = rowoff[row];
+          float v = acc[i][j][e] + bia;
+          if (off >= 0) {
+            if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+            if (p.accumulate) v += yp[off + co];
+            yp[off + co] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (p.epi == DF_EPI_STATS) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (kh == 0) {
+          const int cl = (wn * TN + j) * 32 + li;
+          red[(wm * BN + cl) * 2 + 0] = s1;
+          red[(wm * BN + cl) * 2 + 1] = s2;
+        }
       }
     }
   }
@@ -1360,6 +1415,12 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
       p.w_bytes = (unsigned)wb;
       p.dshift = (unsigned)dsh;
     }
+  }
+  {
+    static const int wide_epi = getenv("DF_CONV_WIDE_EPI") ? atoi(getenv("DF_CONV_WIDE_EPI")) : 0;
+    const int64_t ygroups = y.n / y.grp_size;
+    const int64_t yext = ((int64_t)(y.grp_size - 1) * y.img_stride + (ygroups - 1) * y.grp_off + (int64_t)y.h * y.w * y.ld) * 4;
+    p.y_bytes = (!wide_epi && y.img_stride >= 0 && y.grp_off >= 0 && yext < (int64_t)0xFFFFFFFFll - (16 << 20)) ? (unsigned)yext : 0u;
   }
   g_last_dma = p.x_bytes != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -28,6 +28,7 @@ struct ConvHParams {
   int ks, stride, pad, epi, out_f32;
   int M, K, N, tiles_m, tiles_n, hw_y;
   unsigned x_bytes, w_bytes, dshift;
+  unsigned y_bytes;        // extent of y in bytes (32-bit buffer offsets for the branch-free epilogue)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -49,6 +50,11 @@ __device__ __forceinline__ void epilogue_bf16(const ConvHParams& p, f32x16 (&acc
     rowoff[tid] = off;
   }
   __syncthreads();
+  // straight-line buffer stores (rows past the end get an out-of-range offset and are dropped): a branch per element made
+  // the compiler re-wait for the bias / scale loads -- and with them for the previous element's store -- 16 TM times
+  constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
+  const int esz = p.out_f32 ? 4 : 2;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + (wn * TN + j) * 32 + li;
@@ -59,17 +65,25 @@ __device__ __forceinline__ void epilogue_bf16(const ConvHParams& p, f32x16 (&acc
       sh = p.shift[co];
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      unsigned ob[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int64_t off = rowoff[row];
-        if (off < 0) continue;
+        const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+        ob[e] = off >= 0 ? (unsigned)((off + co) * esz) : ROW_BAD;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
         float v = acc[i][j][e] + bia;
         if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-        if (p.out_f32) reinterpret_cast<float*>(p.y.ptr)[off + co] = v;
-        else reinterpret_cast<__bf16*>(p.y.ptr)[off + co] = (__bf16)v;
+        if (p.out_f32) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
+        } else {
+          const __bf16 h = (__bf16)v;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), yr, ob[e], 0, 0);
+        }
       }
+    }
   }
 }
 
@@ -160,26 +174,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(ConvHParams p) 
     if (st + 1 < nst) load_stage(buf ^ 1);
     const float* a = As + buf * BM * LDB_ + (wm * TM * 32 + li) * LDB_;
     const float* b = Bs + buf * BN * LDB_ + (wn * TN * 32 + li) * LDB_;
-    f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDB_ + rslot[0]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDB_ + rslot[0]);
+    f32x4 af[4][TM], bf[4][TN];   // all fragments of the stage first, then the MFMAs behind counted lgkmcnt waits
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[(s + 1) & 1][i] = ld4(a + i * 32 * LDB_ + rslot[s + 1]);
+      for (int i = 0; i < TM; ++i) af[s][i] = ld4(a + i * 32 * LDB_ + rslot[s]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = ld4(b + j * 32 * LDB_ + rslot[s + 1]);
-      }
+      for (int j = 0; j < TN; ++j) bf[s][j] = ld4(b + j * 32 * LDB_ + rslot[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s & 1][i]),
-                                                              __builtin_bit_cast(bf16x8, bf[s & 1][j]), acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][i]),
+                                                              __builtin_bit_cast(bf16x8, bf[s][j]), acc[i][j], 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -272,26 +282,23 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(ConvHParams p) {
       const float* a = As + (g & 1) * HR * LDB_ + (wm * TM * 32 + li + tx) * LDB_;
       const float* b = Bs + (st & 1) * BN * LDB_ + (wn * TN * 32 + li) * LDB_;
       const int sa = ((li + tx) >> 1) & 7, sb = (li >> 1) & 7;
-      f32x4 af[2][TM], bf[2][TN];
+      // all fragments of the stage first (4 k steps x (TM + TN) b128 reads), then the MFMAs behind counted lgkmcnt waits
+      f32x4 af[4][TM], bf[4][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDB_ + ((kh ^ sa) * 4));
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[0][j] = ld4(b + j * 32 * LDB_ + ((kh ^ sb) * 4));
+        for (int i = 0; i < TM; ++i) af[q][i] = ld4(a + i * 32 * LDB_ + (((2 * q + kh) ^ sa) * 4));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {   // four k steps of 16
-        if (q + 1 < 4) {
+        for (int j = 0; j < TN; ++j) bf[q][j] = ld4(b + j * 32 * LDB_ + (((2 * q + kh) ^ sb) * 4));
+      }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[(q + 1) & 1][i] = ld4(a + i * 32 * LDB_ + (((2 * (q + 1) + kh) ^ sa) * 4));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bf[(q + 1) & 1][j] = ld4(b + j * 32 * LDB_ + (((2 * (q + 1) + kh) ^ sb) * 4));
-        }
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q & 1][i]),
-                                                                __builtin_bit_cast(bf16x8, bf[q & 1][j]), acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -381,6 +388,12 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
   const int64_t wb = (int64_t)p.N * ksize * ksize * p.K * 2;
   DF_REQUIRE(x.img_stride >= 0 && x.grp_off >= 0 && ext + dsh < (int64_t)BAD16 - (16 << 20) && wb < (1ll << 31), DF_E_SHAPE);
   p.x_bytes = (unsigned)(ext + dsh); p.w_bytes = (unsigned)wb; p.dshift = (unsigned)dsh;
+  {
+    const int64_t ygroups = y.n / y.grp_size, esz = out_f32 ? 4 : 2;
+    const int64_t yext = ((int64_t)(y.grp_size - 1) * y.img_stride + (ygroups - 1) * y.grp_off + (int64_t)y.h * y.w * y.ld) * esz;
+    DF_REQUIRE(y.img_stride >= 0 && y.grp_off >= 0 && yext < (int64_t)0xFFFFFFFFll - (16 << 20), DF_E_SHAPE);
+    p.y_bytes = (unsigned)yext;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
   if (use_halo && ksize == 3 && stride == 1 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {

@@ -25,5 +25,6 @@ def run(n, h, cin, cout, ks=3, stride=1, check=False):
     ms = e0.elapsed_time(e1) / 10
     print(f"bf16 conv {cin}->{cout} k{ks} s{stride} @{h}^2 x{n}: {ms:.3f} ms  {2.0 * n * ho * ho * ks * ks * cin * cout / ms / 1e9:.0f} TF/s")
 run(2, 32, 64, 64, check=True); run(2, 32, 128, 128, check=True); run(2, 32, 64, 128, 3, 2, check=True); run(2, 32, 128, 64, 1, 1, check=True)
-for (n, h, cin, cout) in [(32, 128, 128, 128), (32, 64, 256, 256), (16, 512, 64, 64), (16, 256, 256, 128)]:
+run(2, 128, 64, 64, check=True); run(2, 128, 128, 128, check=True); run(1, 256, 192, 64, check=True)   # haloed kernels (W % 128 == 0)
+for (n, h, cin, cout) in [(32, 128, 128, 128), (32, 256, 64, 64), (16, 512, 64, 64), (16, 512, 128, 64), (16, 256, 256, 128), (32, 128, 256, 256)]:
     run(n, h, cin, cout)
