@@ -210,15 +210,17 @@ class FastFlow3DUNet(nn.Module):
                 call("df_conv2d_bf16", x, ptr(wd[m]), ptr(m.bias.detach()), y, ks, stride, ks // 2, ops.EPI_BN_GELU, ptr(scale),
                      ptr(shift), out_f32, s)
 
-        # network input: per-cloud canvases zero-padded to 64 channels (the first conv's bf16 weights are padded alike),
-        # and the 64-channel concatenation for the skip conv
-        x0 = torch.empty(2 * B, H, W, 64, **bf)
-        for g in range(2):
-            call("df_cast_bf16", bstar.data_ptr() + 4 * 32 * g, ptr(x0[g * B:]), B * H * W, 32, 64, 64, s)
-        bstar16 = torch.empty(B, H, W, 64, **bf)
+        # network input: the two 32-channel canvases are the halves of one [B,H,W,64] tensor.  The first conv reads them
+        # in place as 2B images whose 64-deep k chunk runs 32 channels past the cloud's own (into the other cloud / the
+        # next pixel, zeros past the end of the buffer): its bf16 weights are zero-padded to 64 input channels, and the
+        # canvas is finite, so those products are exact zeros -- no padded copy of the input.  (The last pixel of cloud 1
+        # reaches 32 elements past the tensor: the allocation carries a zeroed tail so that those are zeros too.)
+        buf16 = torch.empty(B * H * W * 64 + 64, **bf)
+        buf16[-64:].zero_()
+        bstar16 = buf16[:B * H * W * 64].view(B, H, W, 64)
         call("df_cast_bf16", ptr(bstar), ptr(bstar16), B * H * W, 64, 64, 64, s)
-        x = dimg(x0)
-        cats, alive = [], [x0, bstar16]
+        x = DfImg(bstar16.data_ptr(), 2 * B, H, W, 64, 64, B, bstar16.stride(0), 32)
+        cats, alive = [], [buf16]
         h, w = H, W
         for stage in (self.encoder_step_1, self.encoder_step_2, self.encoder_step_3):
             for i, m in enumerate(stage):
