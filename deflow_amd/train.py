@@ -6,8 +6,11 @@
 hydra-style ``key=value`` overrides (lists in brackets, dotted ``model.target.*`` keys), data-parallel under
 ``torch.distributed.run`` (one process per GPU, RCCL), checkpoints in the Lightning layout the reference's
 ``load_from_checkpoint`` expects ({"state_dict": {"model.<name>": tensor}, "hyper_parameters": cfg, ...}
-[REF deflow.py:41-47]).  The HDF5 dataset is out of scope (h5py absent, section 8(f) N2): ``train_data=synthetic``
-draws seeded Argoverse-2-shaped pairs (deflow_amd/synth.py).  wandb / slurm keys are accepted and ignored."""
+[REF deflow.py:41-47]).  ``train_data=<dir>`` / ``val_data=<dir>`` read the preprocessed scene files the reference trains
+on (``<scene>.h5`` + ``index_total.pkl``, section 8(f) N2) through deflow_amd/data.py (in-tree HDF5 reader, NaN-pad
+collate, per-rank sharding, ``num_workers`` reader threads prefetching to the GPU; ``stage_dir=<scratch>`` first copies
+the files node-local as 1_train.sh does); ``train_data=synthetic`` draws seeded Argoverse-2-shaped pairs
+(deflow_amd/synth.py).  wandb / slurm keys are accepted and ignored."""
 from __future__ import annotations
 
 import ast
@@ -24,7 +27,7 @@ DEFAULTS: Dict[str, Any] = {
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
     "model.target.num_iters": 4, "model.target.decoder_option": "gru",
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
-    "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 1,
+    "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 1,
 }
 
 
@@ -89,12 +92,36 @@ def main(argv=None):
     model.train()
     trainer = Trainer(model, lr=float(cfg["lr"]))
     B, N, H = int(cfg["batch_size"]), int(cfg["points_per_cloud"]), grid_from(cfg)[0]
-    steps_per_epoch = max(1, int(cfg["pairs_per_epoch"]) // (B * world))
-    gstep = 0
-    for epoch in range(int(cfg["epochs"])):
+
+    def scene_loader(path, shuffle):
+        from deflow_amd.data import HDF5Dataset, SceneLoader, ShardedSampler, stage_to_local
+        if cfg["stage_dir"]:
+            dst = os.path.join(str(cfg["stage_dir"]), os.path.basename(os.path.normpath(path)))
+            if local == 0:
+                stage_to_local(path, dst, workers=max(4, int(cfg["num_workers"])))
+            if world > 1:
+                dist.barrier()
+            path = dst
+        ds = HDF5Dataset(path)
+        sampler = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=int(cfg["seed"]))
+        return SceneLoader(ds, B, sampler, device=dev, num_workers=max(1, int(cfg["num_workers"])), drop_last=shuffle), sampler
+
+    def synthetic_epoch(epoch):
         for it in range(steps_per_epoch):
             seed = Trainer.shard_seed(int(cfg["seed"]) + (epoch * steps_per_epoch + it) * B * world, rank, B)
-            batch = synth_batch(B, N, seed=seed, grid_hw=(H, H), device=dev)
+            yield synth_batch(B, N, seed=seed, grid_hw=(H, H), device=dev)
+
+    steps_per_epoch = max(1, int(cfg["pairs_per_epoch"]) // (B * world))
+    train_loader = val_loader = None
+    if cfg["train_data"] != "synthetic":
+        train_loader, train_sampler = scene_loader(str(cfg["train_data"]), shuffle=True)
+    if cfg["val_data"] != "synthetic":
+        val_loader, _ = scene_loader(str(cfg["val_data"]), shuffle=False)
+    gstep = 0
+    for epoch in range(int(cfg["epochs"])):
+        if train_loader is not None:
+            train_sampler.set_epoch(epoch)
+        for batch in (train_loader if train_loader is not None else synthetic_epoch(epoch)):
             t0 = time.perf_counter()
             loss = trainer.step(batch)
             gstep += 1
@@ -104,8 +131,12 @@ def main(argv=None):
                                   "pairs_per_s": B * world / (time.perf_counter() - t0)}), flush=True)
         model.eval()
         with torch.no_grad():
-            vb = synth_batch(min(B, 4), N, seed=int(cfg["seed"]) + 10 ** 6 + epoch, grid_hw=(H, H), device=dev)
-            metrics = evaluate_batch(model(vb), vb)
+            if val_loader is not None:
+                per_batch = [evaluate_batch(model(vb), vb) for vb in val_loader]
+                metrics = {k: float(sum(m[k] for m in per_batch) / max(len(per_batch), 1)) for k in (per_batch[0] if per_batch else {})}
+            else:
+                vb = synth_batch(min(B, 4), N, seed=int(cfg["seed"]) + 10 ** 6 + epoch, grid_hw=(H, H), device=dev)
+                metrics = evaluate_batch(model(vb), vb)
         model.train()
         if rank == 0:
             print(json.dumps({"epoch": epoch, "val": metrics}), flush=True)

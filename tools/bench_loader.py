@@ -1,0 +1,55 @@
+"""Loader-fed training throughput (section 8(f) N2): AV2-sized scene files (90-110k points per sweep, written at run time
+by the image's conda python3.9 + h5py -- a tool-side generator, the product only READS them) -> SceneLoader -> Trainer.step,
+bs 16, against the same model stepping on one resident batch."""
+import os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GEN = r'''
+import h5py, numpy as np, pickle, os, sys
+rng = np.random.default_rng(0); root = sys.argv[1]; index = []
+for s in range(4):
+    name = f"big_{s}"
+    with h5py.File(os.path.join(root, name + ".h5"), "w") as f:
+        for i in range(41):
+            ts = str(315968000000000000 + i * 100000000); n = int(rng.integers(90000, 110000)); g = f.create_group(ts)
+            pc = (rng.normal(0, 20, (n, 3)) * [1, 1, 0.08]).astype(np.float32)
+            g.create_dataset("lidar", data=pc); g.create_dataset("ground_mask", data=(rng.random(n) < 0.2))
+            g.create_dataset("pose", data=np.eye(4, dtype=np.float32))
+            if i < 40:
+                g.create_dataset("flow", data=np.where(rng.random((n, 1)) < 0.1, rng.normal(0, 0.1, (n, 3)), 0).astype(np.float32))
+                g.create_dataset("flow_is_valid", data=np.ones(n, bool))
+                g.create_dataset("flow_category_indices", data=rng.integers(0, 30, n).astype(np.uint8))
+                g.create_dataset("ego_motion", data=np.eye(4, dtype=np.float32)); index.append([name, ts])
+pickle.dump(index, open(os.path.join(root, "index_total.pkl"), "wb"), protocol=4)
+'''
+root = "/tmp/df_bigscenes"
+os.makedirs(root, exist_ok=True)
+if not os.path.exists(os.path.join(root, "index_total.pkl")):
+    subprocess.run(["/opt/conda/bin/python3.9", "-c", GEN, root], check=True)
+import torch, deflow_amd
+from deflow_amd.data import HDF5Dataset, SceneLoader, ShardedSampler
+from deflow_amd.optim import Trainer
+dev = torch.device("cuda")
+torch.manual_seed(0)
+model = deflow_amd.DeFlow().to(dev).train()
+tr = Trainer(model, lr=2e-4)
+ds = HDF5Dataset(root)
+ds.data_index = ds.data_index * 4              # 640 pairs = 40 steps per epoch: steady state, not worker start-up
+for workers in (0, 4, 16):
+    sampler = ShardedSampler(len(ds), shuffle=True, seed=1)
+    n, t0 = 0, None
+    for ep in range(1):
+        sampler.set_epoch(ep)
+        for k, b in enumerate(SceneLoader(ds, 16, sampler, device=dev, num_workers=workers, prefetch=3)):
+            loss = tr.step(b)
+            if k == 4:                         # first steps = warm-up (worker start, file maps, allocator)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            elif k > 4:
+                n += 16
+    torch.cuda.synchronize()
+    print(f"loader-fed, {workers} reader processes: {n / (time.perf_counter() - t0):.1f} pairs/s  (N padded {b['pc0'].shape[1]}, loss {float(loss.detach()):.3f})")
+b = {k: v for k, v in b.items()}
+for _ in range(2): tr.step(b)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): tr.step(b)
+torch.cuda.synchronize()
+print(f"same model, one resident batch: {160 / (time.perf_counter() - t0):.1f} pairs/s")
