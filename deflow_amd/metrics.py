@@ -34,12 +34,22 @@ def epe_metrics(est_flow: torch.Tensor, gt_flow: torch.Tensor, pose_flow: Option
 
 
 def evaluate_batch(res: dict, batch: dict) -> Dict[str, float]:
-    """Average the metrics of one model(batch) result dict over its samples (final flow = pose_flow[valid] + flow)."""
+    """Average the metrics of one model(batch) result dict over its samples (final flow = pose_flow[valid] + flow).
+    With labelled scene files the batch also carries ``flow_is_valid`` (points without a usable label are left out) and
+    ``flow_category_indices`` (0 = background / no object, anything else foreground -- the Argoverse-2 split)."""
     acc: Dict[str, list] = {}
     for b in range(len(res["flow"])):
         vi = res["pc0_valid_point_idxes"][b]
         pf = res["pose_flow"][b][vi]
-        m = epe_metrics(pf + res["flow"][b].detach(), batch["flow"][b][vi], pf)
+        est, gt = pf + res["flow"][b].detach(), batch["flow"][b][vi]
+        fg = None
+        if "flow_category_indices" in batch:
+            fg = batch["flow_category_indices"][b][vi] != 0
+        if "flow_is_valid" in batch:
+            ok = batch["flow_is_valid"][b][vi].bool()
+            est, gt, pf = est[ok], gt[ok], pf[ok]
+            fg = fg[ok] if fg is not None else None
+        m = epe_metrics(est, gt, pf, fg)
         for k, v in m.items():
             if v == v:
                 acc.setdefault(k, []).append(v)

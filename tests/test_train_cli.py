@@ -48,3 +48,19 @@ def test_epe_metrics():
     assert m["n"] == 3 and abs(m["EPE"] - (0.03 + 0.2 + 0.04) / 3) < 1e-6
     assert abs(m["AccS"] - 2 / 3) < 1e-6 and abs(m["AccR"] - 2 / 3) < 1e-6
     assert abs(m["EPE_FD"] - 0.12) < 1e-6 and abs(m["EPE_FS"] - 0.03) < 1e-6
+
+
+def test_epe_metrics_use_scene_file_labels():
+    """labelled batches: points whose label is invalid are left out; category 0 is background, the rest foreground"""
+    import torch
+    from deflow_amd.metrics import evaluate_batch
+    N = 50
+    res = {"flow": [torch.zeros(40, 3)], "pc0_valid_point_idxes": [torch.arange(40)], "pose_flow": [torch.zeros(N, 3)]}
+    gt = torch.zeros(1, N, 3)
+    gt[0, :10, 0] = 1.0                                   # ten moving points (1 m / frame), all foreground
+    batch = {"flow": gt, "flow_is_valid": torch.ones(1, N, dtype=torch.bool),
+             "flow_category_indices": torch.cat([torch.ones(20), torch.zeros(30)]).to(torch.uint8)[None]}
+    batch["flow_is_valid"][0, 0] = False
+    m = evaluate_batch(res, batch)
+    assert m["n"] == 39 and m["EPE_FD"] == 1.0 and m["EPE_FS"] == 0.0 and m["EPE_BS"] == 0.0
+    assert abs(m["EPE_3way"] - 1 / 3) < 1e-9 and abs(m["EPE"] - 9 / 39) < 1e-6
