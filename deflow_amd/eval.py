@@ -1,0 +1,67 @@
+"""``python -m deflow_amd.eval checkpoint=<ckpt> av2_mode=val val_data=<dir>``: the reference's evaluation entry for this
+model plugin ([REF README.md:88]: "python eval.py checkpoint=... av2_mode=val  # it will directly prints all metric").
+
+The checkpoint carries its training configuration (``hyper_parameters``, as Lightning checkpoints do), so only the
+checkpoint and the data need naming.  Metrics: deflow_amd/metrics.py (EPE, accuracy, 3-way EPE) averaged over the sweeps
+of ``val_data`` (preprocessed scene files, deflow_amd/data.py) or over seeded synthetic pairs with ``val_data=synthetic``.
+``av2_mode=test`` (leaderboard submission zips) is the reference's control plane and is not built."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import torch
+
+from .train import DEFAULTS, build_model, grid_from, parse_overrides
+
+
+def main(argv=None):
+    args = list(sys.argv[1:] if argv is None else argv)
+    over = dict(a.split("=", 1) for a in args if "=" in a)
+    if over.get("av2_mode", "val") != "val":
+        raise SystemExit("only av2_mode=val is implemented (test-split submission files are out of scope)")
+    if not over.get("checkpoint"):
+        raise SystemExit("usage: python -m deflow_amd.eval checkpoint=<path> [av2_mode=val] [val_data=<dir>|synthetic]")
+    ckpt = torch.load(over["checkpoint"], map_location="cpu", weights_only=False)
+    saved = dict(ckpt.get("hyper_parameters", {}).get("cfg", {}))
+    cfg = dict(DEFAULTS)
+    cfg.update(saved)
+    for k, v in parse_overrides([a for a in args if not a.startswith(("av2_mode=", "leaderboard_version="))]).items():
+        if k in over or k.lstrip("+") in over:
+            cfg[k] = v
+    assert torch.cuda.is_available(), "evaluation runs on the HIP engine only"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    from .metrics import evaluate_batch
+    model = build_model(cfg).to(dev)
+    model.load_from_checkpoint(over["checkpoint"])
+    model.eval()
+    if "inference_dtype" in over:
+        model.inference_dtype = over["inference_dtype"]
+    B = int(cfg["batch_size"])
+    if cfg["val_data"] != "synthetic":
+        from .data import HDF5Dataset, SceneLoader, ShardedSampler
+        ds = HDF5Dataset(str(cfg["val_data"]))
+        batches = SceneLoader(ds, B, ShardedSampler(len(ds), shuffle=False), device=dev,
+                              num_workers=max(1, int(cfg["num_workers"])), drop_last=False)
+    else:
+        from .synth import synth_batch
+        H = grid_from(cfg)[0]
+        batches = (synth_batch(B, int(cfg["points_per_cloud"]), seed=int(cfg["seed"]) + 10 ** 6 + i * B, grid_hw=(H, H), device=dev)
+                   for i in range(max(1, int(cfg["pairs_per_epoch"]) // B)))
+    tot, wsum = {}, {}
+    with torch.no_grad():
+        for batch in batches:
+            m = evaluate_batch(model(batch), batch)
+            w = len(batch["pose0"])
+            for k, v in m.items():
+                tot[k] = tot.get(k, 0.0) + v * w
+                wsum[k] = wsum.get(k, 0) + w
+    out = {k: tot[k] / wsum[k] for k in tot}
+    print(json.dumps({"checkpoint": over["checkpoint"], "model": cfg["model"], "val_data": cfg["val_data"], "metrics": out}), flush=True)
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -519,10 +519,14 @@ def test_training_from_scene_files(dev, tmp_path, capsys):
             break
     T.main(["model=deflow", "lr=2e-4", "epochs=1", "batch_size=4", "loss_fn=deflowLoss", "model.target.num_iters=2",
             "voxel_size=[0.4, 0.4, 6]", f"train_data={root}", f"val_data={root}", "num_workers=4",
-            f"stage_dir={tmp_path / 'scratch'}", "log_every=1"])
+            f"stage_dir={tmp_path / 'scratch'}", "log_every=1", f"save_checkpoint={tmp_path / 'm.ckpt'}"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     steps = [l for l in lines if "trainer/loss" in l]
     assert len(steps) == 95 // 4 and all(np.isfinite(l["trainer/loss"]) for l in steps)
     val = [l for l in lines if "val" in l]
     assert val and np.isfinite(val[-1]["val"]["EPE"])
     assert sorted(os.listdir(tmp_path / "scratch" / "train")) == sorted(os.listdir(root))
+    # the reference's evaluation entry: checkpoint + data, configuration restored from the checkpoint
+    from deflow_amd import eval as E
+    m = E.main([f"checkpoint={tmp_path / 'm.ckpt'}", "av2_mode=val", f"val_data={root}", "num_workers=2"])
+    assert np.isfinite(m["EPE"]) and abs(m["EPE"] - val[-1]["val"]["EPE"]) < 5e-2 and m["n"] > 0
