@@ -18,27 +18,27 @@ from .train import DEFAULTS, build_model, grid_from, parse_overrides
 
 def main(argv=None):
     args = list(sys.argv[1:] if argv is None else argv)
-    over = dict(a.split("=", 1) for a in args if "=" in a)
-    if over.get("av2_mode", "val") != "val":
+    given = {a.split("=", 1)[0].lstrip("+"): a for a in args if "=" in a}
+    if given.get("av2_mode", "av2_mode=val") != "av2_mode=val":
         raise SystemExit("only av2_mode=val is implemented (test-split submission files are out of scope)")
-    if not over.get("checkpoint"):
+    if "checkpoint" not in given:
         raise SystemExit("usage: python -m deflow_amd.eval checkpoint=<path> [av2_mode=val] [val_data=<dir>|synthetic]")
-    ckpt = torch.load(over["checkpoint"], map_location="cpu", weights_only=False)
-    saved = dict(ckpt.get("hyper_parameters", {}).get("cfg", {}))
+    path = given["checkpoint"].split("=", 1)[1]
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    # configuration: defaults < what the checkpoint was trained with < what this command line names
     cfg = dict(DEFAULTS)
-    cfg.update(saved)
-    for k, v in parse_overrides([a for a in args if not a.startswith(("av2_mode=", "leaderboard_version="))]).items():
-        if k in over or k.lstrip("+") in over:
-            cfg[k] = v
+    cfg.update(ckpt.get("hyper_parameters", {}).get("cfg", {}))
+    typed = parse_overrides([a for k, a in given.items() if k not in ("av2_mode", "leaderboard_version", "inference_dtype")])
+    cfg.update({k: typed[k] for k in given if k in typed})
     assert torch.cuda.is_available(), "evaluation runs on the HIP engine only"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     from .metrics import evaluate_batch
     model = build_model(cfg).to(dev)
-    model.load_from_checkpoint(over["checkpoint"])
+    model.load_from_checkpoint(path)
     model.eval()
-    if "inference_dtype" in over:
-        model.inference_dtype = over["inference_dtype"]
+    if "inference_dtype" in given:
+        model.inference_dtype = given["inference_dtype"].split("=", 1)[1]
     B = int(cfg["batch_size"])
     if cfg["val_data"] != "synthetic":
         from .data import HDF5Dataset, SceneLoader, ShardedSampler
@@ -59,7 +59,7 @@ def main(argv=None):
                 tot[k] = tot.get(k, 0.0) + v * w
                 wsum[k] = wsum.get(k, 0) + w
     out = {k: tot[k] / wsum[k] for k in tot}
-    print(json.dumps({"checkpoint": over["checkpoint"], "model": cfg["model"], "val_data": cfg["val_data"], "metrics": out}), flush=True)
+    print(json.dumps({"checkpoint": path, "model": cfg["model"], "val_data": cfg["val_data"], "metrics": out}), flush=True)
     return out
 
 
