@@ -166,7 +166,10 @@ class Trainer:
     """One data-parallel DeFlow training step: forward (HIP) -> gt gather + deflowLoss (HIP) -> backward (HIP) ->
     all-reduce of the gradient arena (RCCL over xGMI via torch.distributed, or gloo in CPU tests) -> Adam (HIP)."""
 
-    def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None):
+    def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None, loss_fn: str = "deflowLoss"):
+        if loss_fn not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
+            raise ValueError(f"unknown loss_fn {loss_fn!r}")
+        self.loss_fn = loss_fn
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr)
@@ -191,7 +194,15 @@ class Trainer:
         gtf = batch["flow"].contiguous().float()
         call("df_gather_gt", ptr(gtf), ptr(st["pose_flow"]), ptr(st["idx_c0"]), ptr(st["counts0"]), B, N, ptr(gt), 64,
              stream())
-        return DeflowLossFn.apply(flow, gt, st["counts0"])
+        if self.loss_fn == "deflowLoss":
+            return DeflowLossFn.apply(flow, gt, st["counts0"])
+        from . import losses
+        if self.loss_fn == "zeroflowLoss":
+            return losses.zeroflow_loss(flow, gt, st["counts0"])
+        cls = batch.get("flow_category_indices")
+        if cls is not None:   # classes of the compacted valid points, like gt
+            cls = torch.gather(cls.long(), 1, st["idx_c0"].clamp(0, cls.shape[1] - 1))
+        return losses.ff3d_loss(flow, gt, st["counts0"], cls)
 
     def reduce_gradients(self) -> float:
         """Sum the gradient arena over the data-parallel ranks (ONE collective over 27.6 MB); returns the scale that

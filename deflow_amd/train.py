@@ -47,8 +47,8 @@ def parse_overrides(argv: List[str]) -> Dict[str, Any]:
         raise SystemExit(f"unknown model {cfg['model']!r}")
     if cfg["model"] == "fastflow3d":
         cfg["model.target.decoder_option"] = "linear"
-    if cfg["loss_fn"] != "deflowLoss":
-        raise SystemExit("only loss_fn=deflowLoss is implemented (ff3dLoss / zeroflowLoss are ablation baselines)")
+    if cfg["loss_fn"] not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
+        raise SystemExit(f"unknown loss_fn {cfg['loss_fn']!r} (deflowLoss, ff3dLoss, zeroflowLoss)")
     return cfg
 
 
@@ -90,7 +90,7 @@ def main(argv=None):
     if cfg["checkpoint"]:
         model.load_from_checkpoint(cfg["checkpoint"])
     model.train()
-    trainer = Trainer(model, lr=float(cfg["lr"]))
+    trainer = Trainer(model, lr=float(cfg["lr"]), loss_fn=str(cfg["loss_fn"]))
     B, N, H = int(cfg["batch_size"]), int(cfg["points_per_cloud"]), grid_from(cfg)[0]
 
     def scene_loader(path, shuffle):

@@ -408,11 +408,38 @@ def deflow_loss(est_flow: torch.Tensor, gt_flow: torch.Tensor) -> torch.Tensor:
     return total
 
 
-def training_loss(res: dict, batch: dict) -> torch.Tensor:
+def _finite_rows(est_flow, gt_flow):
+    mask = (~gt_flow.isnan() & ~est_flow.isnan() & ~gt_flow.isinf() & ~est_flow.isinf()).all(-1)
+    return est_flow[mask], gt_flow[mask], mask
+
+
+def ff3d_loss(est_flow: torch.Tensor, gt_flow: torch.Tensor, classes: torch.Tensor) -> torch.Tensor:
+    """FastFlow3D: mean L2 error with background points (class 0) down-weighted to 0.1.  UNPINNED (recalled)."""
+    pred, gt, mask = _finite_rows(est_flow, gt_flow)
+    err = torch.linalg.vector_norm(pred - gt, dim=-1)
+    return (err * ((classes[mask] > 0).float() * 0.9 + 0.1)).mean()
+
+
+def zeroflow_loss(est_flow: torch.Tensor, gt_flow: torch.Tensor) -> torch.Tensor:
+    """ZeroFlow: mean L2 error scaled by clamp(1.8 * speed[m/s] - 0.8, 0.1, 1).  UNPINNED (recalled)."""
+    pred, gt, _ = _finite_rows(est_flow, gt_flow)
+    err = torch.linalg.vector_norm(pred - gt, dim=-1)
+    speed = torch.linalg.vector_norm(gt, dim=-1) * 10.0
+    return (err * torch.clamp(1.8 * speed - 0.8, 0.1, 1.0)).mean()
+
+
+def training_loss(res: dict, batch: dict, loss_fn: str = "deflowLoss") -> torch.Tensor:
     """OpenSceneFlow trainer ``training_step``: gt = flow[valid] - pose_flow[valid]; summed over samples."""
     total = 0.0
     for b in range(len(batch["pose0"])):
         vi = res["pc0_valid_point_idxes"][b]
         gt = batch["flow"][b][vi] - res["pose_flow"][b][vi]
-        total = total + deflow_loss(res["flow"][b], gt)
+        if gt.shape[0] == 0:
+            continue
+        if loss_fn == "deflowLoss":
+            total = total + deflow_loss(res["flow"][b], gt)
+        elif loss_fn == "ff3dLoss":
+            total = total + ff3d_loss(res["flow"][b], gt, batch["flow_category_indices"][b][vi])
+        else:
+            total = total + zeroflow_loss(res["flow"][b], gt)
     return total

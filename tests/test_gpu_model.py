@@ -530,3 +530,31 @@ def test_training_from_scene_files(dev, tmp_path, capsys):
     from deflow_amd import eval as E
     m = E.main([f"checkpoint={tmp_path / 'm.ckpt'}", "av2_mode=val", f"val_data={root}", "num_workers=2"])
     assert np.isfinite(m["EPE"]) and abs(m["EPE"] - val[-1]["val"]["EPE"]) < 5e-2 and m["n"] > 0
+
+
+@pytest.mark.parametrize("loss_fn", ["ff3dLoss", "zeroflowLoss"])
+def test_ablation_losses_vs_oracle(dev, loss_fn):
+    """loss_fn=ff3dLoss / zeroflowLoss ([REF 1_train.sh:58-78]) on a labelled batch of the scene fixtures: the trainer's
+    loss on the padded device tensors and the gradients it sends back through the engine vs the oracle's per-sample form."""
+    from oracle import ref_torch as O
+    from deflow_amd.data import HDF5Dataset, collate_fn_pad
+    from deflow_amd.optim import Trainer
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "av2_mini", "train")
+    ds = HDF5Dataset(root)
+    batch = collate_fn_pad([ds[3], ds[40], ds[94], ds[70]])          # item 94 has an empty pc0
+    ref, mine = build_pair(dev, 13, decoder_option="gru", num_iters=2)
+    ref.train(); mine.train()
+    loss_r = O.training_loss(ref(batch), batch, loss_fn)
+    loss_r.backward()
+    tr = Trainer(mine, lr=2e-4, loss_fn=loss_fn)
+    bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    tr.flat.zero_grad(); tr.sink.begin()
+    mine.forward_padded(bd)
+    loss_m = tr.loss_on_last_forward(bd)
+    check(f"{loss_fn}", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    loss_m.backward()
+    pr = dict(ref.named_parameters())
+    for k, p in mine.named_parameters():
+        if not (k.endswith("conv.bias") and "encoder_step" in k):
+            e = rel_err(p.grad, pr[k].grad)
+            assert e <= 2e-3, (k, e)

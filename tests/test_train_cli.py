@@ -13,8 +13,11 @@ def test_parse_overrides_reference_commands():
                          "voxel_size=[0.1, 0.1, 6]", "wandb_mode=online", "slurm_id=123"])            # [REF 1_train.sh:42,66,74]
     assert c["model.target.num_iters"] == 8 and c["voxel_size"] == [0.1, 0.1, 6] and grid_from(c) == [1024, 1024]
     assert parse_overrides(["model=fastflow3d"])["model.target.decoder_option"] == "linear"
+    c = parse_overrides("model=fastflow3d lr=4e-5 epochs=20 batch_size=16 loss_fn=ff3dLoss".split())   # [REF README.md:68]
+    assert c["loss_fn"] == "ff3dLoss" and c["model.target.decoder_option"] == "linear"
+    assert parse_overrides(["loss_fn=zeroflowLoss"])["loss_fn"] == "zeroflowLoss"                       # [REF 1_train.sh:70]
     with pytest.raises(SystemExit):
-        parse_overrides(["loss_fn=zeroflowLoss"])
+        parse_overrides(["loss_fn=chamferLoss"])
 
 
 def test_checkpoint_roundtrip_lightning_layout(tmp_path):
