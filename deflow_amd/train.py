@@ -27,7 +27,7 @@ DEFAULTS: Dict[str, Any] = {
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
     "model.target.num_iters": 4, "model.target.decoder_option": "gru",
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
-    "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 1,
+    "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 50,   # Lightning's log_every_n_steps default; each log line syncs
 }
 
 
