@@ -117,18 +117,19 @@ def main(argv=None):
         train_loader, train_sampler = scene_loader(str(cfg["train_data"]), shuffle=True)
     if cfg["val_data"] != "synthetic":
         val_loader, _ = scene_loader(str(cfg["val_data"]), shuffle=False)
-    gstep = 0
+    gstep, log_step, log_t = 0, 0, time.perf_counter()
     for epoch in range(int(cfg["epochs"])):
         if train_loader is not None:
             train_sampler.set_epoch(epoch)
         for batch in (train_loader if train_loader is not None else synthetic_epoch(epoch)):
-            t0 = time.perf_counter()
             loss = trainer.step(batch)
             gstep += 1
             if rank == 0 and gstep % int(cfg["log_every"]) == 0:
-                lv = float(loss)  # sync only when logging
+                lv = float(loss)  # reads the loss back: the only host sync of the loop, so the rate below is a true one
+                now = time.perf_counter()
                 print(json.dumps({"epoch": epoch, "step": gstep, "trainer/loss": lv / B,
-                                  "pairs_per_s": B * world / (time.perf_counter() - t0)}), flush=True)
+                                  "pairs_per_s": B * world * (gstep - log_step) / (now - log_t)}), flush=True)
+                log_t, log_step = now, gstep
         model.eval()
         with torch.no_grad():
             if val_loader is not None:
