@@ -7,7 +7,8 @@ from deflow_amd.synth import synth_batch
 dev = torch.device("cuda")
 torch.manual_seed(0)
 m = deflow_amd.DeFlow().to(dev).eval()
-out = {}
+m.inference_dtype = os.environ.get("DF_INFER_DTYPE", "fp32")      # "bf16": UNet + GRU GEMMs on bf16 MFMA
+out = {"dtype": m.inference_dtype}
 for B in (1, 4, 16):
     batch = synth_batch(B, 80000, device=dev)
     with torch.no_grad():

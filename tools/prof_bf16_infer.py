@@ -5,7 +5,7 @@ import torch, deflow_amd
 from deflow_amd.synth import synth_batch
 dev = torch.device("cuda")
 which = sys.argv[1] if len(sys.argv) > 1 else "b16"
-kw, B, N, grid = (dict(), 16, 80000, 512) if which == "b16" else (
+kw, B, N, grid = (dict(), 16, 80000, 512) if which == "b16" else (dict(), 1, 80000, 512) if which == "b1" else (
     dict(grid_feature_size=[1024, 1024], point_cloud_range=[-102.4, -102.4, -3, 102.4, 102.4, 3], num_iters=8), 1, 160000, 1024)
 torch.manual_seed(0)
 m = deflow_amd.DeFlow(**kw).to(dev).eval()
