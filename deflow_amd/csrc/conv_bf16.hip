@@ -396,9 +396,18 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
-  if (use_halo && ksize == 3 && stride == 1 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {
+  // small problems (B = 1 inference: the 64 x 64 and 128 x 128 levels): 64 x 64 tiles put four times the workgroups on
+  // the 256 CUs instead of leaving half of them idle behind 128-row tiles.  DF_BF16_SMALL = tile-count threshold (0 = off)
+  static const int small_tiles = getenv("DF_BF16_SMALL") ? atoi(getenv("DF_BF16_SMALL")) : 384;
+  const bool small = (int64_t)p.tiles_m * p.tiles_n < small_tiles;
+  if (!small && use_halo && ksize == 3 && stride == 1 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {
     if (bn == 128) return launch_halo_bf16<128, 2, 4>(p, s);
     return launch_halo_bf16<64, 4, 2>(p, s);
+  }
+  if (small) {
+    p.tiles_m = (int)((M + 63) / 64);
+    p.tiles_n = p.N / 64;
+    return launch_bf16<64, 64, 2, 2>(p, s);
   }
   if (bn == 128) return launch_bf16<128, 128, 2, 4>(p, s);
   return launch_bf16<128, 64, 4, 2>(p, s);
