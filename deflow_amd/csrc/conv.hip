@@ -1339,7 +1339,10 @@ static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int
   if (force == 128064 && rows > 128 * 256 && (epi != DF_EPI_STATS || rows_per_stat_group % 128 == 0)) return 128064;
   int bm;
   if (epi == DF_EPI_STATS) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
-  else bm = (rows <= 128 * 256) ? 64 : 128;  // small problems: more tiles to fill 256 CUs
+  else {
+    static const int small_rows = getenv("DF_CONV_SMALL_ROWS") ? atoi(getenv("DF_CONV_SMALL_ROWS")) : 64 * 128;
+    bm = (rows <= small_rows) ? 64 : 128;  // small problems: more tiles to fill 256 CUs (8192 rows measured best at B = 1, 4)
+  }
   if (bm == 64) return 64064;
   if (cout % 128 == 0) return 128128;
   // 64 output channels: 128x64 (48 KB LDS -> 3 workgroups/CU) measured 120 vs 115 TFLOP/s for the 256x64 tile
