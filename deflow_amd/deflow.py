@@ -14,7 +14,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from ._lib import call, img, ptr, stream
+from ._lib import DfImg, call, img, ptr, stream
 from .autograd import DeFlowFn
 from .decoder import ConvGRUDecoder, LinearDecoder, PointSet
 from .encoder import DynamicEmbedder
@@ -60,8 +60,16 @@ class DeFlow(nn.Module):
         dev = pc0s.device
         bstar = torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)  # streaming zero-fill; pillars overwrite
         self.timer[1].start("Voxelization")
-        p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train)
-        p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train)
+        if not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0":
+            # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
+            # samples writing the two channel halves of bstar -- half the launches of the ~15-kernel pipeline, which is
+            # what a B = 1 forward spends there.  Same arithmetic sample by sample (BatchNorm statistics are per sample).
+            both = emb.pillarize(torch.cat([pc0s, pc1s], 0), DfImg(bstar.data_ptr(), 2 * B, emb.H, emb.W, 32, 64, B,
+                                                                  bstar.stride(0), 32), train)
+            p0, p1 = both.split(B)
+        else:
+            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train)
+            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train)
         self.timer[1].stop()
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None

@@ -42,6 +42,22 @@ class PillarState:
     bn_ss: torch.Tensor        # [B or 1,4,32]
     bn_stride: int             # 128 (per-sample stats) or 0
 
+    def split(self, B: int):
+        """state of a merged [2B,N,3] set -> (first B samples, last B samples).  Per-sample arrays are sliced; the
+        globally sorted arrays (idx_sorted / key_sorted / pts_sorted: the first set's segment comes first, the second
+        starts at a device-side offset) stay whole in the first half and are dropped from the second -- only the
+        tape-less forward uses merged sets, and it reads them for the first cloud alone."""
+        N = self.pts.shape[1]
+        nc = self.cell_rng.shape[0] // 2
+        per = self.bn_stride != 0
+        a = PillarState(self.pts[:B], self.counts[:B], self.points_c[:B], self.coords_c[:B], self.idx_c[:B], self.offs_c[:B],
+                        self.cpos[:B * N], self.idx_sorted, self.cell_rng[:nc], self.key_sorted, self.pts_sorted,
+                        self.bn_ss[:B] if per else self.bn_ss, self.bn_stride)
+        b = PillarState(self.pts[B:], self.counts[B:], self.points_c[B:], self.coords_c[B:], self.idx_c[B:], self.offs_c[B:],
+                        self.cpos[B * N:], None, self.cell_rng[nc:], None, None,
+                        self.bn_ss[B:] if per else self.bn_ss, self.bn_stride)
+        return a, b
+
 
 class _FeatureNet(nn.Module):
     """Parameter container with the upstream names (DynamicPillarFeatureNet, feat_channels=(32,), mode='avg')."""

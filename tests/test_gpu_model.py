@@ -558,3 +558,35 @@ def test_ablation_losses_vs_oracle(dev, loss_fn):
         if not (k.endswith("conv.bias") and "encoder_step" in k):
             e = rel_err(p.grad, pr[k].grad)
             assert e <= 2e-3, (k, e)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_merged_cloud_pillarisation_is_bit_identical(dev, train):
+    """tape-less forwards pillarise pc0 and pc1 as one set of 2B samples (half the launches): flows, valid indices and --
+    in train mode under no_grad -- the BatchNorm running statistics must equal the two-call form bit for bit"""
+    import copy
+    _, base = build_pair(dev, 21, decoder_option="gru", num_iters=2)
+    batch = to_dev(make_batch(3, 2000, 900), dev)
+    batch["pc0"][1, 700:] = float("nan")                      # ragged validity
+    out = {}
+    for mode in ("0", "1"):
+        m = copy.deepcopy(base)
+        m.train(train)
+        os.environ["DF_MERGE_CLOUDS"] = mode
+        try:
+            with torch.no_grad():
+                st = m.forward_padded(batch)
+                res = m(batch)
+        finally:
+            os.environ.pop("DF_MERGE_CLOUDS", None)
+        out[mode] = (st["flow"].clone(), st["counts0"].clone(), st["counts1"].clone(), res,
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b = out["0"], out["1"]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for s in range(3):
+        n = int(a[1][s])
+        assert torch.equal(a[0][s, :n], b[0][s, :n])
+        for key in ("flow", "pc0_valid_point_idxes", "pc1_valid_point_idxes", "pc1_points_lst", "pc0_points_lst"):
+            assert torch.equal(a[3][key][s], b[3][key][s]), key
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
