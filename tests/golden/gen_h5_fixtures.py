@@ -54,6 +54,21 @@ def write_scene(name, n_sweeps, chunked=False):
                 g.create_dataset("flow_category_indices", data=rng.integers(0, 30, n).astype(np.uint8))
                 g.create_dataset("ego_motion", data=(np.linalg.inv(pose(i + 1)) @ pose(i)).astype(np.float32))
                 index.append([name, ts])
+            if chunked and i == 0:   # constructs beyond the writer's defaults that the reader claims to handle
+                g.create_dataset("x_int64", data=rng.integers(-2 ** 40, 2 ** 40, 17))
+                g.create_dataset("x_int16_be", data=rng.integers(-3000, 3000, (5, 4)).astype(">i2"))
+                g.create_dataset("x_f16", data=rng.normal(0, 1, 33).astype(np.float16))
+                g.create_dataset("x_f64_be", data=rng.normal(0, 1, (3, 3)).astype(">f8"))
+                g.create_dataset("x_chunked_plain", data=rng.normal(0, 1, (50, 7)).astype(np.float32), chunks=(16, 4))
+                g.create_dataset("x_fletcher", data=rng.integers(0, 255, (40, 3)).astype(np.uint8), chunks=(16, 3),
+                                 fletcher32=True, compression="gzip", compression_opts=9)
+                g.create_dataset("x_scalar", data=np.float32(2.5))
+                dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+                dcpl.set_layout(h5py.h5d.COMPACT)
+                arr = rng.integers(0, 100, 12).astype(np.int32)
+                space = h5py.h5s.create_simple(arr.shape)
+                did = h5py.h5d.create(g.id, b"x_compact", h5py.h5t.NATIVE_INT32, space, dcpl=dcpl)
+                did.write(h5py.h5s.ALL, h5py.h5s.ALL, arr)
     with h5py.File(path, "r") as f:   # what h5py reads back is the golden
         for ts in f:
             for k in f[ts]:
