@@ -590,3 +590,27 @@ def test_merged_cloud_pillarisation_is_bit_identical(dev, train):
             assert torch.equal(a[3][key][s], b[3][key][s]), key
     for k in a[4]:
         assert torch.equal(a[4][k], b[4][k]), k
+
+
+def test_config0_fastflow3d_ff3dloss_bs1_from_scene_files(dev, tmp_path, capsys):
+    """BASELINE configs[0] ("fastflow3d model, ... single AV2 scene, batch_size=1", the README's baseline command
+    [REF README.md:68]) as plumbing through this engine: model=fastflow3d (LinearDecoder head) with loss_fn=ff3dLoss at
+    batch size 1 over one scene file, then the evaluation entry on the checkpoint it wrote."""
+    import json
+    import pickle
+    import shutil
+    from deflow_amd import train as T, eval as E
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "av2_mini", "train")
+    one = tmp_path / "one_scene"
+    one.mkdir()
+    shutil.copy(os.path.join(root, "scene_a.h5"), one / "scene_a.h5")
+    index = [e for e in pickle.load(open(os.path.join(root, "index_total.pkl"), "rb")) if e[0] == "scene_a"]
+    pickle.dump(index, open(one / "index_total.pkl", "wb"))
+    ck = tmp_path / "ff3d.ckpt"
+    T.main(["model=fastflow3d", "lr=4e-5", "epochs=1", "batch_size=1", "loss_fn=ff3dLoss", "voxel_size=[0.4, 0.4, 6]",
+            f"train_data={one}", f"val_data={one}", "num_workers=2", "log_every=4", f"save_checkpoint={ck}"])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    steps = [l for l in lines if "trainer/loss" in l]
+    assert len(steps) == len(index) // 4 and all(np.isfinite(l["trainer/loss"]) for l in steps)
+    m = E.main([f"checkpoint={ck}", "av2_mode=val", f"val_data={one}", "num_workers=2"])
+    assert np.isfinite(m["EPE"]) and m["n"] > 0
