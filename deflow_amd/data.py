@@ -27,7 +27,6 @@ from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterator, List, Optional, Sequence
 
-import numpy as np
 import torch
 
 from .h5scene import H5File

@@ -9,7 +9,7 @@ valid-point counts) happens per forward, after every kernel has been queued.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn

@@ -19,9 +19,8 @@ HDF5 1.10.6 (``tests/golden/gen_h5_fixtures.py``): every array must equal what h
 from __future__ import annotations
 
 import mmap
-import struct
 import zlib
-from typing import Dict, List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 

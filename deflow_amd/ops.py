@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import DfImg, call, img, img_pair, ptr, stream
+from ._lib import DfImg, call, ptr, stream
 
 CONV_FWD, CONV_DGRAD = 0, 1
 EPI_BIAS, EPI_STATS, EPI_BN_GELU = 0, 1, 2

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import os
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 import torch.nn as nn
