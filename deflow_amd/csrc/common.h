@@ -45,12 +45,15 @@ __device__ __forceinline__ float df_gelu_grad(float x) {
 __device__ __forceinline__ float df_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Fast forms for the GRU gates (v_exp_f32 + v_rcp_f32, ~1e-7 relative): the decoder kernels run one wave per SIMD,
 // so gate math is not hidden behind another wave's MFMAs and the libm range-reduction versions cost ~30 % of the kernel.
+// v_rcp_f32 (1 ulp) on purpose: __frcp_rn / a plain division expand to the 11-instruction correctly-rounded sequence
+// (div_scale, rcp, 5 fma, div_fmas, div_fixup) -- 14 VALU instructions per gate value instead of 4, and the GRU kernels
+// evaluate 3 x 128 of them per point and iteration
 __device__ __forceinline__ float df_sigmoid_fast(float x) {
-  return __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 __device__ __forceinline__ float df_tanh_fast(float x) {
   // tanh(x) = 1 - 2 / (1 + e^{2x}); saturates correctly for large |x| (exp2 -> inf or 0)
-  return 1.0f - 2.0f * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
