@@ -13,8 +13,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
+// `base` and `bytes` must be wave-uniform (they are: per-wave row blocks).  The explicit readfirstlane matters: 64-bit
+// address arithmetic such as (int64) b * N + row is selected as VALU (v_mad_u64_u32), the descriptor then lives in VGPRs,
+// and EVERY buffer instruction using it gets a "waterfall" loop (4 readfirstlane + 2 v_cmp_eq_u64 + saveexec + branch) --
+// 188 of them in gru_bwd3_kernel, 12 instructions per plane load or store instead of one.
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* ub = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(ub, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 __device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
