@@ -821,7 +821,12 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_kernel(SparseConvPa
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  for (int base = sr.off + (blockIdx.x * (PG_THREADS / 64) + wave) * 64; base < end; base += gridDim.x * (PG_THREADS / 64) * 64) {
+  // contiguous chunk range per workgroup (not grid-strided; its waves take the chunks of the range in turn): the sorted
+  // order is row-major, so a workgroup walks a band of image rows and the x rows of its vertical taps stay in its XCD's
+  // L2 (758 -> 680 us; the same change made sparse_wgrad3x3_kernel 4 % slower and was not kept there)
+  const int nchunk = (sr.cnt + 63) / 64, per = (nchunk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_lo = blockIdx.x * per, c_hi = min(c_lo + per, nchunk);
+  for (int base = sr.off + (c_lo + wave) * 64; base < sr.off + c_hi * 64; base += (PG_THREADS / 64) * 64) {
     const int i = base + lane;
     const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
     const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
