@@ -104,6 +104,12 @@ def test_sharded_sampler_is_torch_distributed_sampler(n, world):
     assert list(ShardedSampler(n, 1 % world, world, shuffle=False)) == list(DistributedSampler(data, world, 1 % world, shuffle=False))
 
 
+def _worker_processes_usable() -> bool:
+    """torch DataLoader workers hand batches over through shared memory: needs a writable /dev/shm"""
+    return os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
+
+
+@pytest.mark.skipif(not _worker_processes_usable(), reason="no writable /dev/shm for DataLoader worker processes")
 def test_loader_prefetches_in_order_and_surfaces_errors():
     ds = HDF5Dataset(ROOT)
     sampler = ShardedSampler(len(ds), rank=1, world=2, shuffle=True, seed=5)
