@@ -129,6 +129,17 @@ def test_loader_prefetches_in_order_and_surfaces_errors():
         list(SceneLoader(ds, 4, sampler, device=None))
 
 
+def test_loader_in_process():
+    """num_workers=0: same batches, read in the calling process"""
+    ds = HDF5Dataset(ROOT)
+    sampler = ShardedSampler(len(ds), rank=0, world=4, shuffle=False)
+    got = list(SceneLoader(ds, 5, sampler, device=None, num_workers=0, drop_last=False))
+    idx = list(sampler)
+    assert len(got) == (len(idx) + 4) // 5 and sum(len(b["timestamp"]) for b in got) == len(idx)
+    want = collate_fn_pad([ds[i] for i in idx[:5]])
+    assert got[0]["timestamp"] == want["timestamp"] and torch.equal(torch.nan_to_num(got[0]["pc1"]), torch.nan_to_num(want["pc1"]))
+
+
 def test_stage_to_local(tmp_path):
     n = stage_to_local(ROOT, str(tmp_path / "scratch"), workers=4)
     names = sorted(os.listdir(tmp_path / "scratch"))
