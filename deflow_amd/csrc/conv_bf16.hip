@@ -9,6 +9,7 @@
 // by the DMA / LDS path, not by the MFMA pipe.  Epilogues: bias, or bias + folded BatchNorm + exact-erf GELU (fp32 math),
 // stored as bf16 or fp32.  Inference only (no statistics, no accumulate, no data-gradient mode).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -363,6 +364,175 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+
+// 3x3 stride-1 convolution for Cin = Cout = 64 as a ROLLING-ROW kernel: a persistent workgroup owns a strip of R output
+// rows x 128 pixels of one image, keeps its share of the 9 x 64 x 64 weights in REGISTERS for the whole strip (144 VGPRs
+// per lane: no weight traffic, no weight LDS reads) and streams the input rows through a 3-slot LDS ring: each haloed input
+// row [130 px x 64 ch] arrives once and is multiplied into the three output rows it touches (vertical taps 0, 1, 2) --
+// 36 MFMAs per wave per 17 KB of DMA, against 12 per group in conv_halo_bf16_kernel, no per-tile prologue, and a third of
+// the input traffic.  Output row o is complete once input row o + 1 has been consumed; three accumulators rotate.
+struct RollParams {
+  ConvHParams c;
+  int rows_per_wg, chunks, segs;
+};
+
+__global__ __launch_bounds__(512) void conv64_roll_bf16_kernel(RollParams rp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const ConvHParams& p = rp.c;
+  constexpr int HR = 136;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [3][HR][128 bytes] + 8 wave-private output tiles
+  float* stage = lds + 3 * HR * LDB_;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id = blockIdx.x;
+  const int chunk = id % rp.chunks, seg = (id / rp.chunks) % rp.segs, n = id / (rp.chunks * rp.segs);
+  const int H = p.x.h, W = p.x.w, ldx = p.x.ld;
+  const int y0 = chunk * rp.rows_per_wg, y1 = min(y0 + rp.rows_per_wg, H);
+  const int ox0 = seg * 128;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
+  // A halo: physical row j = 64 i + r0 holds input pixel x = ox0 - 1 + j of the current input row
+  unsigned aoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 64 * i + r0;
+    const int ix = ox0 - 1 + j;
+    const bool ok = j < 130 && ix >= 0 && ix < W;
+    const int slot = c4 ^ ((j >> 1) & 7);
+    // offsets are taken relative to row -1 (the base shift dshift = one row + one pixel keeps them >= 0)
+    aoff[i] = ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(-1) * W + ix) * ldx + slot * 8) * 2 + p.dshift) : BAD16;
+  }
+  auto load_row = [&](int r, int slot3) {           // input row r -> ring slot (zeros for rows outside the image)
+    const bool row_ok = (unsigned)r < (unsigned)H;
+    const unsigned soff = (unsigned)(((int64_t)(r + 1) * W * ldx) * 2);
+    float* a = lds + slot3 * HR * LDB_ + wave * 8 * LDB_;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || wave == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + i * 64 * LDB_), 16, row_ok ? aoff[i] : BAD16, soff, 0, 0);
+  };
+
+  // this wave's weights: W[co = 32 wn + li][tap][k = 16 q + 8 kh .. + 7]
+  bf16x8 wreg[9][4];
+  {
+    const __bf16* wp = p.w + (int64_t)(32 * wn + li) * 9 * 64 + 8 * kh;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wreg[t][q] = *reinterpret_cast<const bf16x8*>(wp + t * 64 + 16 * q);
+  }
+  const int co = 32 * wn + li;
+  const float bia = p.bias ? p.bias[co] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (p.epi == DF_EPI_BN_GELU) {
+    sc = p.scale[co];
+    sh = p.shift[co];
+  }
+  constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
+  const int64_t ybase = df_img_base(p.y, n);
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  load_row(y0 - 1, 0);
+  load_row(y0, 1);
+  // one input row; PH (compile time) = ring slot of row r = accumulator of output row r - 1; it = r - (y0 - 1)
+  auto step = [&](int r, int it, auto PH) {
+    constexpr int S0 = decltype(PH)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+    // row r has landed once everything issued BEFORE the ops listed here is done: per earlier iteration 4 epilogue stores,
+    // and the DMA of row r + 1 (2 instructions; 3 on wave 0) -- vmcnt retires in order
+    const int newer = (wave == 0 ? 3 : 2) + 4 * min(it, 2);
+    switch (newer) {
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    }
+    // raw barrier: __syncthreads() would first drain vmcnt to 0 (the epilogue's global stores are pending behind its
+    // release fence), i.e. also the prefetched row
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    load_row(r + 2, S2);      // slot of row r - 1, consumed before this barrier (rows past the strip are loaded but never used)
+    const float* a = lds + S0 * HR * LDB_ + (wm * 32 + li) * LDB_;
+    // input row r feeds output rows r - 1 (vertical tap 2), r (tap 1), r + 1 (tap 0) = accumulators S0, S1, S2
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int sa = ((li + tx) >> 1) & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, ld4(a + tx * LDB_ + (((2 * q + kh) ^ sa) * 4)));
+        acc[S0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wreg[6 + tx][q], acc[S0], 0, 0, 0);
+        acc[S1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wreg[3 + tx][q], acc[S1], 0, 0, 0);
+        acc[S2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wreg[0 + tx][q], acc[S2], 0, 0, 0);
+      }
+    }
+    // output row o = r - 1 is complete: bias / BN + GELU in registers, then through a wave-private LDS tile so that a lane
+    // stores 16 contiguous bytes of one pixel (NST store instructions per row instead of 16 two- or four-byte ones).
+    // Always NST stores (out of range when the row is not this strip's) so that the vmcnt bookkeeping above is uniform.
+    const int o = r - 1;
+    const bool row_valid = o >= y0 && o < y1;
+    float* st = stage + wave * (32 * 36);            // [32 px][32 co] floats, pitch 36
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = acc[S0][e] + bia;
+      if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+      st[((e & 3) + 8 * (e >> 2) + 4 * kh) * 36 + li] = v;
+      acc[S0][e] = 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (p.out_f32) {      // 32 px x 128 B: lane -> (px = lane >> 3 + 8 k, 4 channels)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = (lane >> 3) + 8 * k, c0 = (lane & 7) * 4;
+        const f32x4 v = ld4(st + px * 36 + c0);
+        const unsigned ob = row_valid ? (unsigned)((ybase + ((int64_t)o * W + ox0 + wm * 32 + px) * p.y.ld + 32 * wn + c0) * 4) : ROW_BAD;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, ob, 0, 0);
+      }
+    } else {              // 32 px x 64 B: lane -> (px = lane >> 2 + 16 k, 8 channels)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < 2) {
+          const int px = (lane >> 2) + 16 * k, c0 = (lane & 3) * 8;
+          const f32x4 a0 = ld4(st + px * 36 + c0), a1 = ld4(st + px * 36 + c0 + 4);
+          bf16x8 h;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            h[u] = (__bf16)a0[u];
+            h[4 + u] = (__bf16)a1[u];
+          }
+          const unsigned ob = row_valid ? (unsigned)((ybase + ((int64_t)o * W + ox0 + wm * 32 + px) * p.y.ld + 32 * wn + c0) * 2) : ROW_BAD;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), yr, ob, 0, 0);
+        } else {          // two dummy stores: the same count as the fp32 branch
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, yr, ROW_BAD, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int r = y0 - 1, it = 0; r <= y1; r += 3, it += 3) {
+    step(r, it, std::integral_constant<int, 0>{});
+    if (r + 1 > y1) break;
+    step(r + 1, it + 1, std::integral_constant<int, 1>{});
+    if (r + 2 > y1) break;
+    step(r + 2, it + 2, std::integral_constant<int, 2>{});
+  }
+#endif
+}
+
 }  // namespace
 
 extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img y, int ksize, int stride, int pad, int epi,
@@ -400,6 +570,32 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
   // the 256 CUs instead of leaving half of them idle behind 128-row tiles.  DF_BF16_SMALL = tile-count threshold (0 = off)
   static const int small_tiles = getenv("DF_BF16_SMALL") ? atoi(getenv("DF_BF16_SMALL")) : 384;
   const bool small = (int64_t)p.tiles_m * p.tiles_n < small_tiles;
+  static const int use_roll = getenv("DF_BF16_ROLL") ? atoi(getenv("DF_BF16_ROLL")) : 1;
+  // rolling-row kernel: one workgroup per CU walking strips of rows -- needs enough rows per CU to amortise the 2 halo rows
+  // and the weight load of a strip (B = 1 inference stays on the tiled kernel)
+  static const int roll_min = getenv("DF_BF16_ROLL_MIN") ? atoi(getenv("DF_BF16_ROLL_MIN")) : 8192;
+  const bool roll_ok = use_roll && (int64_t)y.n * (y.w / 128) * y.h >= roll_min;
+  if (!small && roll_ok && ksize == 3 && stride == 1 && p.K == 64 && p.N == 64 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {
+    RollParams rp;
+    rp.c = p;
+    rp.segs = y.w / 128;
+    // rows per workgroup: as long as possible (2 extra input rows per strip) while still >= 2 workgroups per CU
+    int R = y.h;
+    while (R > 16 && (int64_t)y.n * rp.segs * ((y.h + R - 1) / R) < 512) R = (R + 1) / 2;
+    rp.rows_per_wg = R;
+    rp.chunks = (y.h + R - 1) / R;
+    const size_t lds_bytes = ((size_t)3 * 136 * LDB_ + 8 * 32 * 36) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_roll_bf16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv64_roll_bf16_kernel, dim3((unsigned)(y.n * rp.segs * rp.chunks)), dim3(512), lds_bytes, s, rp);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   if (!small && use_halo && ksize == 3 && stride == 1 && (y.w % 128) == 0 && x.w == y.w && x.h == y.h) {
     if (bn == 128) return launch_halo_bf16<128, 2, 4>(p, s);
     return launch_halo_bf16<64, 4, 2>(p, s);

@@ -2,6 +2,7 @@
 (torch ops / the oracle).  Tolerance: max |got - want| <= TOL * max |want| (north_star: 1e-4 rel for floating
 point); integer outputs must be bit-exact."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -353,3 +354,45 @@ def test_ego_transform_loss_adam(dev):
         gr_d = gr.to(dev)
         call("df_adam_step", ptr(pd), ptr(gr_d), ptr(m), ptr(v), n, 2e-4, 0.9, 0.999, 1e-8, step, 1.0, stream())
     check("adam 3 steps", pd, pr.detach(), tol=1e-6)
+
+
+@pytest.mark.parametrize("epi_gelu,out_f32,n,h,w", [(False, False, 3, 40, 256), (True, False, 2, 33, 128), (False, True, 2, 64, 384)])
+def test_bf16_conv_kernel_forms_agree(dev, epi_gelu, out_f32, n, h, w):
+    """the bf16 3x3 convolution has three kernel forms for Cin = Cout = 64 (rolling-row strips, haloed tiles, per-tap tiles):
+    same operands, same summation order -> the outputs must be bit-identical, and equal a torch fp32 convolution of the
+    bf16-rounded operands up to the output rounding (bf16: 2^-8 relative)"""
+    import subprocess
+    import sys
+    code = f"""
+import sys, os, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from deflow_amd._lib import DfImg, call, ptr, stream
+torch.manual_seed(5)
+dev = torch.device("cuda")
+n, h, w = {n}, {h}, {w}
+x = torch.randn(n, h, w, 64, device=dev).bfloat16(); wt = (torch.randn(64, 3, 3, 64, device=dev) * 0.05).bfloat16()
+b = torch.randn(64, device=dev); sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev) * 0.1
+y = torch.empty(n, h, w, 64, device=dev, dtype=torch.float32 if {out_f32} else torch.bfloat16)
+xi = DfImg(x.data_ptr(), n, h, w, 64, 64, n, h * w * 64, 0); yi = DfImg(y.data_ptr(), n, h, w, 64, 64, n, h * w * 64, 0)
+call("df_conv2d_bf16", xi, ptr(wt), ptr(b), yi, 3, 1, 1, {2 if epi_gelu else 0}, ptr(sc) if {epi_gelu} else None, ptr(sh) if {epi_gelu} else None, {int(out_f32)}, stream())
+torch.cuda.synchronize()
+torch.save(y.float().cpu(), sys.argv[1])
+"""
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("roll", {"DF_BF16_ROLL_MIN": "0", "DF_BF16_SMALL": "0"}), ("halo", {"DF_BF16_ROLL": "0", "DF_BF16_SMALL": "0"}),
+                         ("tap", {"DF_BF16_ROLL": "0", "DF_CONV_HALO": "0", "DF_BF16_SMALL": "0"})):
+            f = os.path.join(d, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[tag] = torch.load(f)
+    assert torch.equal(outs["roll"], outs["halo"]) and torch.equal(outs["halo"], outs["tap"])
+    torch.manual_seed(5)
+    x = torch.randn(n, h, w, 64, device=dev).bfloat16(); wt = (torch.randn(64, 3, 3, 64, device=dev) * 0.05).bfloat16()
+    b = torch.randn(64, device=dev); sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev) * 0.1
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), b, 1, 1).permute(0, 2, 3, 1)
+    if epi_gelu:
+        ref = F.gelu(ref * sc + sh)
+    err = float((outs["roll"].to(dev) - ref).abs().max() / ref.abs().max())
+    assert err < (2e-5 if out_f32 else 5e-3), err
