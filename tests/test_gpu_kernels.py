@@ -356,7 +356,7 @@ def test_ego_transform_loss_adam(dev):
     check("adam 3 steps", pd, pr.detach(), tol=1e-6)
 
 
-@pytest.mark.parametrize("epi_gelu,out_f32,n,h,w", [(False, False, 3, 40, 256), (True, False, 2, 33, 128), (False, True, 2, 64, 384)])
+@pytest.mark.parametrize("epi_gelu,out_f32,n,h,w", [(True, False, 3, 33, 256), (False, True, 2, 40, 384)])
 def test_bf16_conv_kernel_forms_agree(dev, epi_gelu, out_f32, n, h, w):
     """the bf16 3x3 convolution has three kernel forms for Cin = Cout = 64 (rolling-row strips, haloed tiles, per-tap tiles):
     same operands, same summation order -> the outputs must be bit-identical, and equal a torch fp32 convolution of the
