@@ -86,3 +86,27 @@ def test_entry_points_reject_bad_arguments_without_launching(lib_path):
     assert lib.df_gru_wgrad(P(0), P(0), P(0), 2, 100, 4, P(0), 1, P(0)) < 0
     assert lib.df_colsum_stage(P(0x1000), 4, 16, 8, P(0x1000), P(0)) < 0                                     # groups > rows
     assert lib.df_conv2d_wgrad(bad, ok64, 3, 1, 1, P(0), 1, P(0), 0, P(0), P(0)) < 0
+
+
+def test_counted_vmcnt_kernels_do_not_spill():
+    """kernels that keep LDS-DMA in flight across barriers order it with COUNTED s_waitcnt vmcnt(n); a register spill would add
+    scratch loads/stores (VMEM operations on the same counter) and silently break the count -- the compiler must report no
+    scratch for them"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "deflow_amd", "csrc")
+    for fname, kernels in (("conv_bf16.hip", ["conv64_roll_bf16_kernel"]), ("decoder_wgrad.hip", ["gru_wgrad_kernel"])):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result", "-c",
+                            os.path.join(src, fname), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        blocks = re.split(r"remark: Function Name: ", r.stderr)
+        for k in kernels:
+            blk = next(b for b in blocks if k in b.split("\n", 1)[0])
+            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+            spills = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
+            assert scratch == 0 and spills == 0, (k, scratch, spills)
