@@ -149,9 +149,11 @@ class SceneLoader:
     def __iter__(self):
         from torch.utils.data import DataLoader
         cuda = self.device is not None and torch.device(self.device).type == "cuda"
-        kw = dict(prefetch_factor=2, persistent_workers=False) if self.workers else {}
-        host = iter(DataLoader(self.ds, batch_size=self.bs, sampler=self.sampler, collate_fn=collate_fn_pad,
-                               num_workers=self.workers, pin_memory=cuda, drop_last=self.drop_last, **kw))
+        if getattr(self, "_dl", None) is None:   # one DataLoader for all epochs: its worker processes persist (a restart
+            kw = dict(prefetch_factor=2, persistent_workers=True) if self.workers else {}   # costs seconds per epoch)
+            self._dl = DataLoader(self.ds, batch_size=self.bs, sampler=self.sampler, collate_fn=collate_fn_pad,
+                                  num_workers=self.workers, pin_memory=cuda, drop_last=self.drop_last, **kw)
+        host = iter(self._dl)
         if not cuda:
             yield from host
             return
