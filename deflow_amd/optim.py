@@ -166,10 +166,13 @@ class Trainer:
     """One data-parallel DeFlow training step: forward (HIP) -> gt gather + deflowLoss (HIP) -> backward (HIP) ->
     all-reduce of the gradient arena (RCCL over xGMI via torch.distributed, or gloo in CPU tests) -> Adam (HIP)."""
 
-    def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None, loss_fn: str = "deflowLoss"):
+    def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None, loss_fn: str = "deflowLoss",
+                 gradient_clip_val: float = 0.0):
         if loss_fn not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
             raise ValueError(f"unknown loss_fn {loss_fn!r}")
         self.loss_fn = loss_fn
+        # Lightning's gradient_clip_val (norm clipping of the synchronised gradient, torch.nn.utils.clip_grad_norm_); 0 = off
+        self.gradient_clip_val = float(gradient_clip_val)
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr)
@@ -229,5 +232,9 @@ class Trainer:
         self.model.forward_padded(batch)
         loss = self.loss_on_last_forward(batch)
         loss.backward()
-        self.opt.step(grad_scale=self.reduce_gradients())
+        scale = self.reduce_gradients()
+        if self.gradient_clip_val > 0:       # two launches on the 27.6 MB arena, no host sync
+            total_norm = torch.linalg.vector_norm(self.flat.grad) * scale
+            self.flat.grad.mul_(torch.clamp(self.gradient_clip_val / (total_norm + 1e-6), max=1.0))
+        self.opt.step(grad_scale=scale)
         return loss.detach()

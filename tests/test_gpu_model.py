@@ -614,3 +614,26 @@ def test_config0_fastflow3d_ff3dloss_bs1_from_scene_files(dev, tmp_path, capsys)
     assert len(steps) == len(index) // 4 and all(np.isfinite(l["trainer/loss"]) for l in steps)
     m = E.main([f"checkpoint={ck}", "av2_mode=val", f"val_data={one}", "num_workers=2"])
     assert np.isfinite(m["EPE"]) and m["n"] > 0
+
+
+def test_gradient_clipping_matches_clip_grad_norm(dev):
+    """Trainer(gradient_clip_val=c) = torch.nn.utils.clip_grad_norm_(params, c) before Adam: parameters after two steps vs the
+    oracle trained with torch's own clipping"""
+    from oracle import ref_torch as O
+    from deflow_amd.optim import Trainer
+    ref, m = build_pair(dev, 31, decoder_option="gru", num_iters=2)
+    ref.train(); m.train()
+    tr = Trainer(m, lr=2e-4, gradient_clip_val=0.5)
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
+    batch_cpu = make_batch(2, 1500, 640)
+    batch = to_dev(batch_cpu, dev)
+    for _ in range(2):
+        tr.step(batch)
+        opt.zero_grad()
+        O.training_loss(ref(batch_cpu), batch_cpu).backward()
+        n = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        assert float(n) > 0.5          # the clip is active in this test
+        opt.step()
+    pr = dict(ref.named_parameters())
+    worst = max(rel_err(p_, pr[k]) for k, p_ in m.named_parameters() if not (k.endswith("conv.bias") and "encoder_step" in k))
+    assert worst < 5e-3, worst
