@@ -637,3 +637,51 @@ def test_gradient_clipping_matches_clip_grad_norm(dev):
     pr = dict(ref.named_parameters())
     worst = max(rel_err(p_, pr[k]) for k, p_ in m.named_parameters() if not (k.endswith("conv.bias") and "encoder_step" in k))
     assert worst < 5e-3, worst
+
+
+def test_two_data_parallel_ranks_on_one_gpu(dev, tmp_path):
+    """the N > 1 training step with the real kernels: two ranks share the GPU (gloo carries the collectives), each with its
+    own shard; parameters after two steps must equal the oracle stepping Adam on the AVERAGE of the two per-rank gradients
+    (per-rank BatchNorm statistics), both ranks must end with identical parameters, and the bucketed asynchronous
+    all-reduces must really have been issued from inside the backward"""
+    import socket
+    import subprocess
+    import sys
+    from oracle import ref_torch as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "rank0.pt")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "helpers", "ddp_two_ranks_one_gpu.py"), out],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    got = torch.load(out)
+    r0, r1 = got["ranks"]
+    assert r0["works"] >= 4 and r1["works"] >= 4 and r0["param_sum"] == r1["param_sum"]
+    # oracle: rank 0's initial weights, gradients of the two shards averaged, Adam
+    ref, _ = build_pair(dev, 41, decoder_option="gru", num_iters=2)
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
+    shards = [make_batch(2, 1500, 7000 + 50 * k) for k in range(2)]
+    want_losses = [[], []]
+    for _ in range(2):
+        opt.zero_grad()
+        grads = None
+        for k, b in enumerate(shards):
+            for p in ref.parameters():
+                p.grad = None
+            l = O.training_loss(ref(b), b)
+            l.backward()
+            want_losses[k].append(float(l.detach()))
+            g = [p.grad.clone() for p in ref.parameters()]
+            grads = g if grads is None else [a + c for a, c in zip(grads, g)]
+        for p, g in zip(ref.parameters(), grads):
+            p.grad = g / 2
+        opt.step()
+    for k, rk in enumerate((r0, r1)):
+        for a, w in zip(rk["losses"], want_losses[k]):
+            assert abs(a - w) <= 2e-3 * abs(w), (k, rk["losses"], want_losses[k])
+    pr = dict(ref.named_parameters())
+    worst = max(rel_err(got["state"][k], p.detach()) for k, p in pr.items() if not (k.endswith("conv.bias") and "encoder_step" in k))
+    print(f"[ddp] two ranks on one GPU: worst parameter rel diff after 2 steps {worst:.3e}")
+    assert worst < 5e-3, worst
