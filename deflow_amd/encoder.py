@@ -129,9 +129,12 @@ class DynamicEmbedder(nn.Module):
             nbs = max(1, min(256, (N + 31) // 32))
             partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
             call("df_pfn_stats", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
-            bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
-            call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
-                 bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
+            if ops.SYNC is not None:
+                bn_ss = self._sync_bn_stats(partial, counts)
+            else:
+                bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
+                call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                     bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
             bn.num_batches_tracked.add_(B)
             ops.PARAM_GEN[0] += 1
             bn_stride = 128
@@ -148,6 +151,27 @@ class DynamicEmbedder(nn.Module):
              out, nbc, s)
         return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss, bn_stride)
 
+    def _sync_bn_stats(self, partial: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+        """sync_bn form of df_pfn_bn_finalize: per-sample statistics (the feature net is called once per sample) over the
+        points of sample b on ALL ranks; running statistics in call order, skipped for calls with fewer than two points"""
+        bn = self._bn
+        sums = ops.SYNC.sum(partial.double().sum(1))                             # [B, 32, 2]
+        cnt = ops.SYNC.sum(counts.double())                                      # [B]
+        safe = cnt.clamp_min(1.0)[:, None]
+        mean = sums[:, :, 0] / safe
+        var = (sums[:, :, 1] / safe - mean * mean).clamp_min(0.0)
+        invstd = torch.rsqrt(var + bn.eps)
+        ga, be = bn.weight.detach().double(), bn.bias.detach().double()
+        ss = torch.stack([ga * invstd, be - mean * ga * invstd, mean, invstd], 1)   # [B, 4, 32]
+        ss = torch.where((cnt > 0)[:, None, None], ss, torch.zeros_like(ss)).float().contiguous()
+        m = bn.momentum
+        for b in range(cnt.shape[0]):
+            upd = cnt[b] > 1
+            unb = var[b] * (cnt[b] / (cnt[b] - 1.0).clamp_min(1.0))
+            bn.running_mean.copy_(torch.where(upd, (1.0 - m) * bn.running_mean + (m * mean[b]).float(), bn.running_mean))
+            bn.running_var.copy_(torch.where(upd, (1.0 - m) * bn.running_var + (m * unb).float(), bn.running_var))
+        return ss
+
     def pillarize_bwd(self, st: PillarState, gout: DfImg, grads: Optional[Tuple[torch.Tensor, ...]]):
         """Accumulates (dW [32,9], dgamma [32], dbeta [32]) for one cloud set; grads=None starts from zero."""
         B, N, _ = st.pts.shape
@@ -162,8 +186,17 @@ class DynamicEmbedder(nn.Module):
         partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_stats", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, self.mode, gout, ptr(partial), nbs, s)
-        coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
-        call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
+        if ops.SYNC is not None:   # statistics of sample b are shared with sample b of the other ranks (one module call each)
+            loc = partial.double().sum(1)                                         # [B, 32, (sum g, sum g * xhat)], this rank
+            tb, tg = loc[:, :, 0].sum(0).float(), loc[:, :, 1].sum(0).float()
+            dbeta.copy_(dbeta + tb if acc else tb)
+            dgamma.copy_(dgamma + tg if acc else tg)
+            cnt = ops.SYNC.sum(st.counts.double())
+            glob = ops.SYNC.sum(loc.clone()) / cnt.clamp_min(1.0)[:, None, None]
+            coef = torch.where((cnt > 0)[:, None, None], glob, torch.zeros_like(glob)).permute(0, 2, 1).contiguous().float()
+        else:
+            coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
+            call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
         dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_weights", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, self.mode, ptr(coef), gout, ptr(dwp), nbs, s)

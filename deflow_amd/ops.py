@@ -133,8 +133,42 @@ def folded_bn(bn) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tenso
     return c[1], c[2], c[3], c[4]
 
 
+class SyncBN:
+    """sync_bn (Lightning's sync_batchnorm / torch SyncBatchNorm) for the data-parallel ranks: the per-channel sums behind a
+    BatchNorm's batch statistics -- forward (sum, sum of squares, count) and backward (sum of g, sum of g * xhat) -- are
+    all-reduced between the partial-sum kernels and the finalisation, which then runs as a few fp64 torch ops on [C]-sized
+    tensors instead of the fused finalize kernels.  Parameter gradients (dgamma, dbeta) stay rank-local sums: the
+    gradient all-reduce averages them like every other parameter (as torch's SyncBatchNorm + DDP do)."""
+
+    def __init__(self, dist, group, world: int):
+        self.dist, self.group, self.world = dist, group, world
+
+    def sum(self, t: torch.Tensor) -> torch.Tensor:
+        self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+SYNC: Optional[SyncBN] = None   # set by optim.Trainer(sync_bn=True) on a multi-rank process group
+
+
 def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss):
     PARAM_GEN[0] += 1  # running statistics change under any cached eval-mode fold
+    if SYNC is not None:
+        red = SYNC.sum(partial.view(groups, tiles_per_group, C, 2).to(torch.float64).sum(1))      # [groups, C, 2], all ranks
+        cnt = float(count) * SYNC.world
+        ga = gamma.double() if gamma is not None else torch.ones(C, dtype=torch.float64, device=partial.device)
+        be = beta.double() if beta is not None else torch.zeros(C, dtype=torch.float64, device=partial.device)
+        out = bn_ss.view(groups, 4, C)
+        for g in range(groups):                    # groups = successive calls of the module: running statistics in call order
+            mean = red[g, :, 0] / cnt
+            var = (red[g, :, 1] / cnt - mean * mean).clamp_min(0.0)
+            invstd = torch.rsqrt(var + eps)
+            out[g] = torch.stack([ga * invstd, be - mean * ga * invstd, mean, invstd]).float()
+            if rmean is not None:
+                unb = var * (cnt / (cnt - 1.0)) if cnt > 1 else var
+                rmean.mul_(1.0 - momentum).add_((momentum * mean).float())
+                rvar.mul_(1.0 - momentum).add_((momentum * unb).float())
+        return
     splits = min(64, tiles_per_group // 64)  # two-stage reduction once a group has thousands of tile partials
     scratch = torch.empty(groups * splits * 2 * C, dtype=torch.float64, device=partial.device) if splits > 1 else None
     call("df_bn_finalize", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,
@@ -163,9 +197,15 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
     nblk = nbg * groups
     partial = _f32(nblk, C, 2, device=dev)
     call("df_bn_gelu_bwd_reduce", dz, ptr(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
-    dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
-    coef = _f32(groups, 2, C, device=dev)
-    call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
+    if SYNC is not None:
+        red = partial.view(groups, nbg, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
+        dbeta, dgamma = red[:, :, 0].sum(0).float(), red[:, :, 1].sum(0).float()
+        glob = SYNC.sum(red.clone()) / (float(rows_per_group) * SYNC.world)
+        coef = glob.permute(0, 2, 1).contiguous().float()                        # [groups, 2, C]
+    else:
+        dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
+        coef = _f32(groups, 2, C, device=dev)
+        call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
     dy = torch.empty_like(y)
     dbp = _f32(nblk, C, device=dev)
     call("df_bn_gelu_bwd_apply", dz, ptr(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), ptr(dbp), nblk, stream())

@@ -167,7 +167,7 @@ class Trainer:
     all-reduce of the gradient arena (RCCL over xGMI via torch.distributed, or gloo in CPU tests) -> Adam (HIP)."""
 
     def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None, loss_fn: str = "deflowLoss",
-                 gradient_clip_val: float = 0.0):
+                 gradient_clip_val: float = 0.0, sync_bn: bool = False):
         if loss_fn not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
             raise ValueError(f"unknown loss_fn {loss_fn!r}")
         self.loss_fn = loss_fn
@@ -185,6 +185,9 @@ class Trainer:
         if self.collective:  # identical replicas: broadcast rank 0's arena once
             self.dist.broadcast(self.flat.param, src=0, group=process_group)
         # models whose backward is hand-sequenced (DeFlowFn) deliver gradients phase by phase through the sink
+        # sync_bn: BatchNorm batch statistics over all ranks (ops.SyncBN); a process-wide switch of the engine, like
+        # torch's convert_sync_batchnorm is of the module tree
+        ops.SYNC = ops.SyncBN(self.dist, process_group, self.world) if (sync_bn and self.collective) else None
         self.sink = GradSink(self.flat, self.dist, process_group, self.world, self.collective)
         model._grad_sink = self.sink
 

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    out = sys.argv[1]
+    out, sync_bn = sys.argv[1], len(sys.argv) > 2 and sys.argv[2] == "sync_bn"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda", 0)
     _, model = build_pair(dev, 41 + 100 * rank, decoder_option="gru", num_iters=2)   # different init per rank on purpose:
     model.train()                                                                     # the Trainer broadcasts rank 0's
-    tr = Trainer(model, lr=2e-4)
+    tr = Trainer(model, lr=2e-4, sync_bn=sync_bn)
     assert tr.collective and tr.world == 2
     batch = to_dev(make_batch(2, 1500, 7000 + 50 * rank), dev)                         # rank-specific shard
     losses, works = [], 0
