@@ -25,7 +25,7 @@ import torch
 DEFAULTS: Dict[str, Any] = {
     "model": "deflow", "lr": 2e-4, "epochs": 1, "batch_size": 16, "loss_fn": "deflowLoss", "num_workers": 0,
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
-    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False,
+    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dist_backend": "nccl",
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
     "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 50,   # Lightning's log_every_n_steps default; each log line syncs
 }
@@ -75,12 +75,16 @@ def main(argv=None):
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "training runs on the HIP engine only"
+    local = local % torch.cuda.device_count()      # more ranks than GPUs only in tests (dist_backend=gloo, ranks share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cfg["dist_backend"] == "nccl":          # RCCL
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(str(cfg["dist_backend"]), rank=rank, world_size=world)
     from deflow_amd.metrics import evaluate_batch
     from deflow_amd.optim import Trainer
     from deflow_amd.synth import synth_batch

@@ -764,3 +764,30 @@ def test_sync_bn_two_ranks_on_one_gpu(dev, tmp_path):
     # and it is NOT what per-rank statistics give: the first-step losses of the per-rank-BN run differ from these
     alone = O.training_loss(build_pair(dev, 41, decoder_option="gru", num_iters=2)[0].train()(shards[0]), shards[0])
     assert abs(want[0][0] - float(alone.detach())) > 1e-4
+
+
+def test_cli_two_ranks_share_the_scene_files(dev, tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 -m deflow_amd.train train_data=<dir> sync_bn=true` (both ranks on this GPU,
+    dist_backend=gloo): the ranks read disjoint shards of the index, step in lockstep and finish; the checkpoint loads"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import deflow_amd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(root, "tests", "golden", "av2_mini", "train")
+    ck = str(tmp_path / "ddp.ckpt")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "deflow_amd.train", "model=deflow", "lr=2e-4", "epochs=1", "batch_size=4",
+                        "loss_fn=deflowLoss", "model.target.num_iters=2", "voxel_size=[0.4, 0.4, 6]", f"train_data={data}",
+                        f"val_data={data}", "num_workers=2", "sync_bn=true", "gradient_clip_val=5.0", "dist_backend=gloo", "log_every=2",
+                        f"save_checkpoint={ck}"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    steps = [l for l in lines if "trainer/loss" in l]
+    assert len(steps) == ((95 + 1) // 2 // 4) // 2 and all(np.isfinite(l["trainer/loss"]) for l in steps)   # 48 items per rank, 12 steps
+    assert any("val" in l for l in lines)
+    m = deflow_amd.DeFlow(voxel_size=[0.4, 0.4, 6], grid_feature_size=[256, 256], num_iters=2)
+    res = m.load_from_checkpoint(ck)
+    assert not res.missing_keys and not res.unexpected_keys
