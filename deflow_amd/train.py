@@ -144,6 +144,11 @@ def main(argv=None):
                 vb = synth_batch(min(B, 4), N, seed=int(cfg["seed"]) + 10 ** 6 + epoch, grid_hw=(H, H), device=dev)
                 metrics = evaluate_batch(model(vb), vb)
         model.train()
+        if world > 1 and metrics:      # equal-sized validation shards: the mean over ranks is the mean over the set
+            keys = sorted(metrics)
+            t = torch.tensor([metrics[k] for k in keys], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            metrics = {k: float(v) / world for k, v in zip(keys, t.tolist())}
         if rank == 0:
             print(json.dumps({"epoch": epoch, "val": metrics}), flush=True)
             if cfg["save_checkpoint"]:
