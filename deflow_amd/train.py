@@ -144,11 +144,12 @@ def main(argv=None):
                 vb = synth_batch(min(B, 4), N, seed=int(cfg["seed"]) + 10 ** 6 + epoch, grid_hw=(H, H), device=dev)
                 metrics = evaluate_batch(model(vb), vb)
         model.train()
-        if world > 1 and metrics:      # equal-sized validation shards: the mean over ranks is the mean over the set
-            keys = sorted(metrics)
-            t = torch.tensor([metrics[k] for k in keys], dtype=torch.float64, device=dev)
+        if world > 1:                  # mean over the ranks that have the metric (a fixed key list: every rank reduces alike)
+            keys = ["EPE", "AccS", "AccR", "n", "EPE_FD", "EPE_FS", "EPE_BS", "EPE_3way"]
+            vals = [float(metrics.get(k, float("nan"))) for k in keys]
+            t = torch.tensor([0.0 if v != v else v for v in vals] + [0.0 if v != v else 1.0 for v in vals], dtype=torch.float64, device=dev)
             dist.all_reduce(t)
-            metrics = {k: float(v) / world for k, v in zip(keys, t.tolist())}
+            metrics = {k: float(t[i] / t[len(keys) + i]) for i, k in enumerate(keys) if float(t[len(keys) + i]) > 0}
         if rank == 0:
             print(json.dumps({"epoch": epoch, "val": metrics}), flush=True)
             if cfg["save_checkpoint"]:
