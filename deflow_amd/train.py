@@ -25,7 +25,7 @@ import torch
 DEFAULTS: Dict[str, Any] = {
     "model": "deflow", "lr": 2e-4, "epochs": 1, "batch_size": 16, "loss_fn": "deflowLoss", "num_workers": 0,
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
-    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dist_backend": "nccl",
+    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dist_backend": "nccl", "resume": False,
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
     "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 50,   # Lightning's log_every_n_steps default; each log line syncs
 }
@@ -96,6 +96,15 @@ def main(argv=None):
     model.train()
     trainer = Trainer(model, lr=float(cfg["lr"]), loss_fn=str(cfg["loss_fn"]), gradient_clip_val=float(cfg["gradient_clip_val"]),
                       sync_bn=str(cfg["sync_bn"]).lower() in ("1", "true"))
+    start_epoch, gstep0 = 0, 0
+    if cfg["checkpoint"] and str(cfg["resume"]).lower() in ("1", "true"):
+        # "checkpoints also include parameters and status of that epoch" [REF README.md:76-77]: continue where it stopped --
+        # Adam moments and step count, epoch and global step (weights were loaded above; every rank reads the same file)
+        ck = torch.load(cfg["checkpoint"], map_location="cpu", weights_only=False)
+        if ck.get("optimizer_states"):
+            trainer.opt.load_state_dict(ck["optimizer_states"][0])
+            trainer.opt.lr = float(cfg["lr"])
+        start_epoch, gstep0 = int(ck.get("epoch", -1)) + 1, int(ck.get("global_step", 0))
     B, N, H = int(cfg["batch_size"]), int(cfg["points_per_cloud"]), grid_from(cfg)[0]
 
     def scene_loader(path, shuffle):
@@ -122,8 +131,8 @@ def main(argv=None):
         train_loader, train_sampler = scene_loader(str(cfg["train_data"]), shuffle=True)
     if cfg["val_data"] != "synthetic":
         val_loader, _ = scene_loader(str(cfg["val_data"]), shuffle=False)
-    gstep, log_step, log_t = 0, 0, time.perf_counter()
-    for epoch in range(int(cfg["epochs"])):
+    gstep, log_step, log_t = gstep0, gstep0, time.perf_counter()
+    for epoch in range(start_epoch, int(cfg["epochs"])):
         if train_loader is not None:
             train_sampler.set_epoch(epoch)
         for batch in (train_loader if train_loader is not None else synthetic_epoch(epoch)):

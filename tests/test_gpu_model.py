@@ -791,3 +791,22 @@ def test_cli_two_ranks_share_the_scene_files(dev, tmp_path):
     m = deflow_amd.DeFlow(voxel_size=[0.4, 0.4, 6], grid_feature_size=[256, 256], num_iters=2)
     res = m.load_from_checkpoint(ck)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_resume_continues_the_run_exactly(dev, tmp_path, capsys):
+    """checkpoint / resume: two epochs in one run == one epoch, checkpoint, `resume=true` for the second epoch -- the same
+    parameters bit for bit (weights, Adam moments and step count, epoch counter and the per-epoch data order all restored)"""
+    import deflow_amd
+    from deflow_amd import train as T
+    base = ["model=deflow", "lr=2e-4", "batch_size=2", "loss_fn=deflowLoss", "model.target.num_iters=2",
+            "voxel_size=[0.2, 0.2, 6]", "point_cloud_range=[-6.4, -6.4, -3, 6.4, 6.4, 3]", "pairs_per_epoch=6", "points_per_cloud=1200"]
+    a, b1, b2 = (str(tmp_path / n) for n in ("a.ckpt", "b1.ckpt", "b2.ckpt"))
+    T.main(base + ["epochs=2", f"save_checkpoint={a}"])
+    T.main(base + ["epochs=1", f"save_checkpoint={b1}"])
+    T.main(base + ["epochs=2", f"checkpoint={b1}", "resume=true", f"save_checkpoint={b2}"])
+    capsys.readouterr()
+    sa, sb = torch.load(a, weights_only=False), torch.load(b2, weights_only=False)
+    assert sa["global_step"] == sb["global_step"] == 6 and sa["epoch"] == sb["epoch"] == 1
+    for k, v in sa["state_dict"].items():
+        assert torch.equal(v, sb["state_dict"][k]), k
+    assert torch.equal(sa["optimizer_states"][0]["exp_avg"], sb["optimizer_states"][0]["exp_avg"])
