@@ -19,6 +19,6 @@ i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc$i -o p -- python /tmp/one.py > /tmp/pmc$i.log 2>&1
-  python $R/tools/rocpd_pmc.py --raw conv_dma $(find /tmp/pmc$i -name "*.db" | head -1) >> $R/gpurun_out/pmc_conv.txt 2>&1 || tail -3 /tmp/pmc$i.log >> $R/gpurun_out/pmc_conv.txt
+  python $R/tools/rocpd_pmc.py --raw conv_halo $(find /tmp/pmc$i -name "*.db" | head -1) >> $R/gpurun_out/pmc_conv.txt 2>&1 || tail -3 /tmp/pmc$i.log >> $R/gpurun_out/pmc_conv.txt
 done
 cat $R/gpurun_out/pmc_conv.txt
