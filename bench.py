@@ -121,7 +121,7 @@ def main():
     if prof is not None and os.environ.get("DF_BENCH_DUMP"):
         with open(os.environ["DF_BENCH_DUMP"], "w") as f:
             per = len(prof.records) // args.steps
-            for name, flops, e0, e1 in prof.records[:per]:
+            for name, flops, e0, e1, *_ in prof.records[:per]:
                 ms_ = e0.elapsed_time(e1)
                 f.write(f"{name:28s} {flops / 1e9:10.2f} GF {ms_:8.3f} ms {flops / ms_ / 1e9:8.1f} TF/s\n")
     if prof is not None:

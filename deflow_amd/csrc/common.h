@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/deflow_amd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -17,6 +19,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DF_REQUIRE(cond, code) \
   do {                         \
     if (!(cond)) return (code); \
+  } while (0)
+
+// One-time raise of a kernel's dynamic-LDS limit, safe when several host threads make their first call at once (the
+// header promises "thread-safe per stream"): std::call_once instead of a racy `static bool`.
+#define DF_SET_LDS_ONCE(kernel, bytes)                                                                            \
+  do {                                                                                                            \
+    static std::once_flag once__;                                                                                 \
+    static int rc__ = 0;                                                                                          \
+    const int bytes__ = (int)(bytes);                                                                             \
+    std::call_once(once__, [bytes__] {                                                                            \
+      rc__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes__);                        \
+    });                                                                                                           \
+    if (rc__ != 0) return rc__;                                                                                   \
   } while (0)
 
 static inline bool df_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

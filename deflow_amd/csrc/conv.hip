@@ -513,20 +513,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<BM, BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  static bool attr_set_dma = false;
-  if (!attr_set_dma) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set_dma = true;
-  }
+  DF_SET_LDS_ONCE((conv_kernel<BM, BN, WM, WN>), (int)lds_bytes);
+  DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN>), (int)lds_bytes);
   if (p.x_bytes)
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
   else
@@ -661,13 +649,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
 template <int BN, int WM, int WN>
 static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (136 + BN) * LDT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((conv_halo_kernel<BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -679,13 +661,7 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -1355,7 +1331,7 @@ extern "C" int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int 
   return pick_variant(rows, rows_per_stat_group, cout, epi);
 }
 
-static int g_last_dma = 0;
+static thread_local int g_last_dma = 0;   // per host thread: the query below refers to the CALLING thread's previous df_conv2d
 extern "C" int df_conv2d_last_dma(void) { return g_last_dma; }  // 1 if the previous df_conv2d used the LDS-DMA kernel
 
 extern "C" int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout) {

@@ -312,13 +312,7 @@ __global__ __launch_bounds__(512) void conv_halo_bf16_kernel(ConvHParams p) {
 template <int BN, int WM, int WN>
 int launch_halo_bf16(const ConvHParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (136 + BN) * LDB_ * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bf16_kernel<BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((conv_halo_bf16_kernel<BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_halo_bf16_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -327,13 +321,7 @@ int launch_halo_bf16(const ConvHParams& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 int launch_bf16(const ConvHParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (BM + BN) * LDB_ * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<BM, BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((conv_bf16_kernel<BM, BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -585,13 +573,7 @@ extern "C" int df_conv2d_bf16(df_img x, const void* w, const float* bias, df_img
     rp.rows_per_wg = R;
     rp.chunks = (y.h + R - 1) / R;
     const size_t lds_bytes = ((size_t)3 * 136 * LDB_ + 8 * 32 * 36) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_roll_bf16_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    DF_SET_LDS_ONCE((conv64_roll_bf16_kernel), (int)lds_bytes);
     hipLaunchKernelGGL(conv64_roll_bf16_kernel, dim3((unsigned)(y.n * rp.segs * rp.chunks)), dim3(512), lds_bytes, s, rp);
     DF_CHECK_LAUNCH();
     return DF_OK;

@@ -292,13 +292,7 @@ extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* co
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   const size_t lds_bytes = (size_t)(2 * BSZ + 4 * 16 * LDA_F) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((gru_fwd_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(gru_fwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
@@ -316,13 +310,7 @@ extern "C" int df_linear_decoder_fwd(df_img before, df_img after, const int32_t*
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts; p.N = N;
   p.w_off = w_off; p.b_off = b_off; p.w_1 = w_1; p.b_1 = b_1; p.w_2 = w_2; p.b_2 = b_2; p.flow = flow;
   const size_t lds_bytes = (size_t)(2 * BSZ_L + 4 * 16 * LDA_L) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((linear_fwd_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();

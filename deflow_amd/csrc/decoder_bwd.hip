@@ -520,13 +520,7 @@ extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const i
   p.plane_stride = p.iter_stride * num_iters;
   p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.xout = xout; p.bias_partial = bias_partial;
   const size_t lds_bytes = (size_t)(2 * BS_B + 4 * 16 * LDA_B) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((gru_bwd_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(gru_bwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
@@ -576,13 +570,7 @@ extern "C" int df_linear_decoder_bwd(df_img before, df_img after, const int32_t*
   p.w_off = w_off; p.b_off = b_off; p.w_1 = w_1; p.b_1 = b_1; p.w_2 = w_2; p.wt_1 = wt_1;
   p.vx = vx; p.dh0 = dh0; p.dxe = dxe; p.dpre1 = dpre1; p.hid = hid;
   const size_t lds_bytes = (size_t)(2 * BS_L + 4 * 16 * LDA_B) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((linear_bwd_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(linear_bwd_kernel, dim3((N + 63) / 64, B), dim3(256), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();

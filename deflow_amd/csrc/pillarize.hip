@@ -1132,13 +1132,7 @@ extern "C" int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* c
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.accumulate = accumulate;
   p.dy1 = dy1; p.w1 = w1; p.dskip = dskip; p.w3 = w3; p.dcanvas = dcanvas;
   const size_t lds_bytes = (size_t)(9 * 64 * 32 + 64 * 32 + (PG_THREADS / 64) * 16) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pillar_input_grad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((pillar_input_grad_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(pillar_input_grad_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
@@ -1167,13 +1161,7 @@ extern "C" int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* coun
   SparseConvParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.H = y.h; p.W = y.w; p.x = x; p.y = y; p.w = w; p.bias = bias;
   const size_t lds_bytes = (size_t)(9 * 64 * 64 + (PG_THREADS / 64) * 16) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_conv3x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  DF_SET_LDS_ONCE((sparse_conv3x3_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(sparse_conv3x3_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();

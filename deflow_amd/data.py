@@ -63,7 +63,12 @@ class HDF5Dataset:
         f = self._file(scene_id)
         k = f.sweeps.index(timestamp)
         if k + 1 >= len(f.sweeps):
-            raise IndexError(f"{scene_id}/{timestamp} is the last sweep of its scene: it has no successor to pair with")
+            # upstream's index (create_reading_index) lists EVERY sweep of a scene; the last one has no successor, and
+            # upstream's HDF5Dataset steps such an entry back by one sweep instead of failing
+            if len(f.sweeps) < 2:
+                raise IndexError(f"{scene_id} holds a single sweep: nothing to pair {timestamp} with")
+            k -= 1
+            timestamp = f.sweeps[k]
         g0, g1 = f[timestamp], f[f.sweeps[k + 1]]
         t = lambda d: torch.from_numpy(d.read())
         item = {"scene_id": scene_id, "timestamp": int(timestamp),

@@ -47,7 +47,8 @@ class DeFlow(nn.Module):
         self.last_state: Optional[dict] = None  # padded device-side tensors of the last forward (fast trainer path)
 
     def load_from_checkpoint(self, ckpt_path):
-        ckpt = torch.load(ckpt_path, map_location="cpu")["state_dict"]
+        from .ckpt import load_checkpoint   # torch.load that survives omegaconf / Lightning objects in the file
+        ckpt = load_checkpoint(ckpt_path)["state_dict"]
         state_dict = {k[len("model."):]: v for k, v in ckpt.items() if k.startswith("model.")}
         print("\nLoading... model weight from: ", ckpt_path, "\n")
         return self.load_state_dict(state_dict=state_dict, strict=False)

@@ -24,10 +24,15 @@ def main(argv=None):
     if "checkpoint" not in given:
         raise SystemExit("usage: python -m deflow_amd.eval checkpoint=<path> [av2_mode=val] [val_data=<dir>|synthetic]")
     path = given["checkpoint"].split("=", 1)[1]
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    # configuration: defaults < what the checkpoint was trained with < what this command line names
+    from .ckpt import flatten, load_checkpoint, plain
+    ckpt = load_checkpoint(path)
+    # configuration: defaults < what the checkpoint was trained with < what this command line names.  The reference's
+    # Lightning checkpoints hold a NESTED (omegaconf) config -- model.target.num_iters etc. -- so it is flattened to the
+    # dotted keys used here; keys this trainer does not know are ignored.
     cfg = dict(DEFAULTS)
-    cfg.update(ckpt.get("hyper_parameters", {}).get("cfg", {}))
+    hp = plain(ckpt.get("hyper_parameters", {}))
+    saved = flatten(hp.get("cfg", hp) if isinstance(hp, dict) else {})
+    cfg.update({k: v for k, v in saved.items() if k in DEFAULTS})
     typed = parse_overrides([a for k, a in given.items() if k not in ("av2_mode", "leaderboard_version", "inference_dtype")])
     cfg.update({k: typed[k] for k in given if k in typed})
     assert torch.cuda.is_available(), "evaluation runs on the HIP engine only"

@@ -224,6 +224,27 @@ class Trainer:
                 self.dist.all_reduce(self.flat.grad, group=self.pg)
         return 1.0 / self.world
 
+    def sync_buffers(self):
+        """BatchNorm buffers (running_mean / running_var / num_batches_tracked) are rank-local during training; torch DDP
+        (Lightning's default, broadcast_buffers=True) makes every rank use rank 0's.  Called before validation and before a
+        checkpoint so that all ranks evaluate the SAME model and the file holds the statistics that were validated: the
+        float buffers go out as one flat tensor, the integer counters as another (two broadcasts, not ~60)."""
+        if not self.collective:
+            return
+        bufs = [b for b in self.model.buffers()]
+        for sel in (lambda b: b.dtype.is_floating_point, lambda b: not b.dtype.is_floating_point):
+            group = [b for b in bufs if sel(b)]
+            if not group:
+                continue
+            flat = torch.cat([b.detach().reshape(-1) for b in group])
+            self.dist.broadcast(flat, src=0, group=self.pg)
+            off = 0
+            with torch.no_grad():
+                for b in group:
+                    b.copy_(flat[off:off + b.numel()].view(b.shape))
+                    off += b.numel()
+        ops.PARAM_GEN[0] += 1   # cached eval-mode BatchNorm folds are stale
+
     @staticmethod
     def shard_seed(base_seed: int, rank: int, per_rank_batch: int) -> int:
         """frame pairs are sharded by global sample index: rank r owns samples [r*b, (r+1)*b)"""

@@ -31,6 +31,11 @@ DEFAULTS: Dict[str, Any] = {
 }
 
 
+# hydra / wandb / slurm plumbing of the reference's command lines [REF 1_train.sh:28-78]: accepted silently, unused here
+_IGNORED_PREFIXES = ("wandb", "slurm", "hydra", "model.target.", "model.val_monitor", "exp_note", "save_top_model",
+                     "val_every", "dataset_path", "av2_mode", "leaderboard_version", "gpus", "sync_bn", "optimizer")
+
+
 def parse_overrides(argv: List[str]) -> Dict[str, Any]:
     cfg = dict(DEFAULTS)
     for a in argv:
@@ -42,6 +47,9 @@ def parse_overrides(argv: List[str]) -> Dict[str, Any]:
             val = ast.literal_eval(v)
         except (ValueError, SyntaxError):
             val = v
+        if k not in DEFAULTS and not k.startswith(_IGNORED_PREFIXES):
+            print(f"[deflow_amd.train] warning: unknown override {k!r} (accepted, unused); known keys: "
+                  f"{', '.join(sorted(DEFAULTS))}", file=sys.stderr)
         cfg[k] = val
     if cfg["model"] not in ("deflow", "fastflow3d"):
         raise SystemExit(f"unknown model {cfg['model']!r}")
@@ -100,7 +108,8 @@ def main(argv=None):
     if cfg["checkpoint"] and str(cfg["resume"]).lower() in ("1", "true"):
         # "checkpoints also include parameters and status of that epoch" [REF README.md:76-77]: continue where it stopped --
         # Adam moments and step count, epoch and global step (weights were loaded above; every rank reads the same file)
-        ck = torch.load(cfg["checkpoint"], map_location="cpu", weights_only=False)
+        from deflow_amd.ckpt import load_checkpoint
+        ck = load_checkpoint(cfg["checkpoint"])
         if ck.get("optimizer_states"):
             trainer.opt.load_state_dict(ck["optimizer_states"][0])
             trainer.opt.lr = float(cfg["lr"])
@@ -144,6 +153,7 @@ def main(argv=None):
                 print(json.dumps({"epoch": epoch, "step": gstep, "trainer/loss": lv / B,
                                   "pairs_per_s": B * world * (gstep - log_step) / (now - log_t)}), flush=True)
                 log_t, log_step = now, gstep
+        trainer.sync_buffers()         # every rank validates (and rank 0 saves) rank 0's BatchNorm statistics, as DDP does
         model.eval()
         with torch.no_grad():
             if val_loader is not None:

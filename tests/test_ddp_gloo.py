@@ -68,7 +68,13 @@ def _worker(rank, world, port, q):
     # shards: the two ranks draw different frame pairs
     seed = Trainer.shard_seed(20240116, rank, 2)
     b = synth_batch(2, 64, seed=seed, grid_hw=(64, 64))
-    q.put((rank, p_sum, err, scale, alias_ok, float(b["pc0"][0, 0, 0]), float(local.abs().sum()), sink_err, all_delivered, n_works))
+    # BatchNorm buffers drift apart during training (rank-local statistics); sync_buffers() = DDP's broadcast_buffers
+    bn = model.backbone.encoder_step_1[0].batchnorm
+    with torch.no_grad():
+        bn.running_mean.fill_(1.0 + rank); bn.running_var.fill_(2.0 + rank); bn.num_batches_tracked.fill_(5 + rank)
+    tr.sync_buffers()
+    buf_ok = float(bn.running_mean[0]) == 1.0 and float(bn.running_var[3]) == 2.0 and int(bn.num_batches_tracked) == 5
+    q.put((rank, p_sum, err, scale, alias_ok, float(b["pc0"][0, 0, 0]), float(local.abs().sum()), sink_err, all_delivered, n_works, buf_ok))
     dist.destroy_process_group()
 
 
@@ -83,7 +89,8 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, e0, sc0, a0, x0, l0, se0, ad0, nw0), (r1, s1, e1, sc1, a1, x1, l1, se1, ad1, nw1) = res
+    (r0, s0, e0, sc0, a0, x0, l0, se0, ad0, nw0, bo0), (r1, s1, e1, sc1, a1, x1, l1, se1, ad1, nw1, bo1) = res
+    assert bo0 and bo1, "sync_buffers must leave rank 0's BatchNorm statistics on every rank"
     assert se0 < 1e-5 and se1 < 1e-5 and ad0 and ad1, "bucketed gradient delivery must equal one all-reduce"
     assert nw0 == nw1 and nw0 >= 6, "head, UNet decoder and the encoder stages go out as separate overlapped buckets"
     assert s0 == s1, "rank 1 must hold rank 0's parameters after the broadcast"

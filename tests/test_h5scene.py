@@ -65,9 +65,34 @@ def test_dataset_pairs_a_sweep_with_its_successor(expected):
         assert torch.equal(it["pose1"].double(), torch.from_numpy(expected[f"{scene}/{nxt}/pose"]).double())
         assert torch.equal(it["flow"], torch.from_numpy(expected[f"{scene}/{ts}/flow"]))
         assert it["gm0"].dtype == torch.bool and it["flow_category_indices"].dtype == torch.uint8
-    ds.data_index.append(["scene_a", sorted(k.split("/")[1] for k in expected.files if k.startswith("scene_a/"))[-1]])
-    with pytest.raises(IndexError):
-        ds[len(ds) - 1]
+    # upstream's index lists EVERY sweep of a scene (create_reading_index); the last one has no successor and upstream's
+    # dataset steps it back by one sweep (raising here aborts the first epoch on real preprocessed data)
+    sweeps_a = sorted((k.split("/")[1] for k in expected.files if k.startswith("scene_a/") and k.endswith("/lidar")), key=int)
+    ds.data_index.append(["scene_a", sweeps_a[-1]])
+    last = ds[len(ds) - 1]
+    assert last["timestamp"] == int(sweeps_a[-2])
+    assert torch.equal(last["pc0"], torch.from_numpy(expected[f"scene_a/{sweeps_a[-2]}/lidar"]))
+    assert torch.equal(last["pc1"], torch.from_numpy(expected[f"scene_a/{sweeps_a[-1]}/lidar"]))
+
+
+def test_index_listing_every_sweep_loads_end_to_end(tmp_path):
+    """index_total.pkl as upstream's preprocessing writes it -- all timestamps of all scenes -- through the loader"""
+    import shutil
+    from deflow_amd.h5scene import H5File as HF
+    d = tmp_path / "full"
+    d.mkdir()
+    index = []
+    for scene in ("scene_a", "scene_b"):
+        shutil.copy(os.path.join(ROOT, scene + ".h5"), d / (scene + ".h5"))
+        with HF(os.path.join(ROOT, scene + ".h5")) as f:
+            index += [[scene, ts] for ts in sorted(f.keys(), key=int)]
+    pickle.dump(index, open(d / "index_total.pkl", "wb"))
+    ds = HDF5Dataset(str(d))
+    assert len(ds) == 95          # 25 + 70 sweeps, the two scene-final ones included
+    n = 0
+    for batch in SceneLoader(ds, batch_size=8, num_workers=0, device="cpu", drop_last=False):
+        n += batch["pc0"].shape[0]
+    assert n == 95
 
 
 def test_collate_drops_ground_and_pads_with_nan():
