@@ -1,20 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- frame-pairs/s of the DeFlow training step (deflowLoss, Adam lr=2e-4, bs=16 per GPU, 512x512 BEV,
-80 000-point clouds, 4 GRU iterations, fp32) on N MI355X of one node.  One process per GPU (torchrun), RCCL.
+80 000-point clouds, 4 GRU iterations, fp32) on N MI355X of one node.  One process per GPU, RCCL over xGMI.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment) or started bare -- then this file re-launches itself under torch.distributed.run (127.0.0.1 rendezvous,
+free port) and rank 0's JSON line is the output.
 
 A "step" = one full training pass over one synthetic, HBM-resident batch: ego-motion, pillarise both clouds, UNet
 forward, GRU decoder, gt gather + deflowLoss, complete backward, gradient all-reduce (N > 1), Adam.  Nothing is
 skipped or cached between steps.  Prints ONE JSON line on rank 0 (contract in the round prompt), including
-  roofline      live HIP-event timing of the dominant kernel (fp32 MFMA implicit-GEMM conv) vs the 157.3 TFLOP/s peak
-  cpu_baseline  the CPU oracle (oracle/ref_torch.py, a PyTorch port of the reference algorithm) timed on this host.
+  roofline        live HIP-event timing of the dominant kernel (fp32 MFMA implicit-GEMM conv) vs the 157.3 TFLOP/s peak
+  roofline_hbm    the HBM-bound stages (pillarise, BatchNorm+GELU passes) and the GRU kernels: algorithmic bytes / time / 8 TB/s
+  forward_only    BASELINE configs[1] (B=1 inference), timed AFTER the training region
+  bf16_inference  BASELINE configs[4] shape (1024x1024, 160k points, 8 iterations, bf16 MFMA), after the training region
+  cpu_baseline    the CPU oracle (oracle/ref_torch.py, a PyTorch port of the reference algorithm) timed on this host:
+                  median of 5 after 2 warm-ups, training step and forward only
+  (N > 1) rccl_ranks, per-rank step times, allreduce_exposed_ms (steps with vs without the gradient collectives).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -23,53 +35,135 @@ PER_GPU_BATCH = 16
 N_POINTS = 80000
 GRID = 512
 NUM_ITERS = 4
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 
 
-def cpu_baseline():
-    """One training step of the oracle on ONE frame pair of the same workload (bounded sample), all host threads."""
-    from deflow_amd.synth import synth_batch
-    from oracle import ref_torch as O
-    torch.manual_seed(0)
-    ref = O.DeFlow(grid_feature_size=[GRID, GRID], num_iters=NUM_ITERS).train()
-    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
-    batch = synth_batch(1, N_POINTS, seed=20240116)
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    loss = O.training_loss(ref(batch), batch)
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 training step on 1 synthetic frame pair ({N_POINTS} pts/cloud, {GRID}x{GRID}, {NUM_ITERS} GRU iters), "
-                      f"oracle/ref_torch.py fp32, {dt:.1f} s; host cpu_count={os.cpu_count()}"}
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (the metric is quoted at 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--forward-only", action="store_true",
-                    help="also time BASELINE configs[1] (B=1 inference) after the training steps; off by default so that a\n"
-                         "rocprofv3 trace of the default command holds training launches only")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events of the conv kernels")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-samples", type=int, default=5, help="timed CPU-oracle repetitions per leg (after 2 warm-ups)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip forward_only / bf16_inference / allreduce_exposed (e.g. for a rocprofv3 trace that should hold "
+                         "the training launches only)")
+    ap.add_argument("--forward-only", action="store_true", help="(kept for compatibility: the forward-only leg now always runs)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective plumbing only: gloo, no GPU, no kernels (CPU test of the N > 1 start-up)")
+    return ap.parse_args()
 
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: one process per GPU under torch.distributed.run on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see the environment notes): RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(samples: int):
+    """The oracle on ONE frame pair of the same workload (bounded sample), all host threads: a full training step and a
+    forward-only pass, each the median of `samples` repetitions after 2 warm-ups."""
+    import torch
+    from deflow_amd.synth import synth_batch
+    from oracle import ref_torch as O
+    torch.manual_seed(0)
+    ref = O.DeFlow(grid_feature_size=[GRID, GRID], num_iters=NUM_ITERS).train()
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
+    batch = synth_batch(1, N_POINTS, seed=20240116)
+
+    def train_step():
+        opt.zero_grad()
+        loss = O.training_loss(ref(batch), batch)
+        loss.backward()
+        opt.step()
+
+    def forward():
+        with torch.no_grad():
+            ref(batch)
+
+    def median_time(fn):
+        for _ in range(2):
+            fn()
+        ts = []
+        for _ in range(max(1, samples)):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), min(ts), max(ts)
+
+    tr = median_time(train_step)
+    ref.eval()
+    fw = median_time(forward)
+    return {"value": 1.0 / tr[0], "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"training step on 1 synthetic frame pair ({N_POINTS} pts/cloud, {GRID}x{GRID}, {NUM_ITERS} GRU iters), "
+                      f"oracle/ref_torch.py fp32: median of {samples} after 2 warm-ups = {tr[0]:.2f} s (min {tr[1]:.2f}, max {tr[2]:.2f}); "
+                      f"host cpu_count={os.cpu_count()}",
+            "forward_only": {"value": 1.0 / fw[0], "unit": "frame-pairs/s",
+                             "sample": f"eval-mode forward of the same pair: median of {samples} after 2 warm-ups = {fw[0]:.2f} s "
+                                       f"(min {fw[1]:.2f}, max {fw[2]:.2f})"}}
+
+
+def dry_run(args, rank, world):
+    """N > 1 start-up without a GPU: process group (gloo), barrier, MAX-reduced timing, all-gathered rank ids, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = torch.ones(1024)
+        dist.all_reduce(g)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ids = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ids, t)
+    if rank == 0:
+        print(json.dumps({"metric": "frame-pairs/sec training (deflow, bs=16, 512x512 BEV)", "dry_run": True, "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": [int(x.item()) for x in ids],
+                          "allreduce_sum_ok": bool(float(g[0]) == world), "ms_per_step": float(dt.item()) / args.steps * 1e3}), flush=True)
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it bare (`python bench.py --gpus N`, it launches "
+                 f"its own ranks) or with torch.distributed.run --nproc-per-node equal to --gpus")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
     assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
 
     import deflow_amd
@@ -88,22 +182,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            loss_ = trainer.step(batch)
+        torch.cuda.synchronize()
+        local = time.perf_counter() - t0
+        barrier()
+        return time.perf_counter() - t0, local, loss_
+
     for _ in range(args.warmup):
         trainer.step(batch)
     prof = None if args.no_profile else ops.KernelProfiler()
-    barrier()
     ops.PROFILER = prof
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(batch)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, dt_local, loss = timed_steps(args.steps)       # THE timed region: exactly --steps steps between barriers
     ops.PROFILER = None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = None
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([dt_local / args.steps * 1e3, float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     dt = float(t.item())
+
+    exposed = None
+    if world > 1 and not args.no_extras:
+        # how much of the gradient all-reduce is NOT hidden behind the backward: the same steps without the collectives
+        # (replicas drift apart afterwards -- nothing is measured after this)
+        trainer.collective = trainer.sink.collective = False
+        dt_nc, _, _ = timed_steps(args.steps)
+        tn = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        exposed = (dt - float(tn.item())) / args.steps * 1e3
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -118,12 +230,18 @@ def main():
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
                    "parallelism": f"dp{world}", "loss": float(loss)},
     }
+    if per_rank is not None:
+        out["rccl_ranks"] = [int(x[1].item()) for x in per_rank]
+        out["per_rank_ms_per_step"] = {"min": min(float(x[0]) for x in per_rank), "max": max(float(x[0]) for x in per_rank)}
+    if exposed is not None:
+        out["allreduce_exposed_ms"] = exposed
     if prof is not None and os.environ.get("DF_BENCH_DUMP"):
         with open(os.environ["DF_BENCH_DUMP"], "w") as f:
             per = len(prof.records) // args.steps
-            for name, flops, e0, e1, *_ in prof.records[:per]:
+            for name, flops, e0, e1, tag, *rest in prof.records[:per]:
                 ms_ = e0.elapsed_time(e1)
-                f.write(f"{name:28s} {flops / 1e9:10.2f} GF {ms_:8.3f} ms {flops / ms_ / 1e9:8.1f} TF/s\n")
+                f.write(f"{name:28s} {flops / 1e9:10.2f} GF {(rest[0] if rest else 0) / 1e6:10.2f} MB {ms_:8.3f} ms "
+                        f"{flops / ms_ / 1e9:8.1f} TF/s  {tag}\n")
     if prof is not None:
         summ = prof.summary()
         conv = {k: v for k, v in summ.items() if k.startswith("conv_")}
@@ -136,34 +254,88 @@ def main():
                 traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"] if args.batch == PER_GPU_BATCH else None
         except Exception:
             traffic = None
+        mfma = {k: v for k, v in summ.items() if v["flops"] > 0 and not k.startswith("gru_")}
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": dom,
                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": d["ms"] / d["launches"],
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
                                                     "ms_per_step": v["ms"] / args.steps,
-                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}}
-    if world == 1 and args.forward_only:
+                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in mfma.items()}}
+        # HBM-bound stages and the GRU kernels: algorithmic bytes / measured time / 8 TB/s
+        hbm = {}
+
+        def entry(name, keys, note):
+            sel = [summ[k] for k in keys if k in summ]
+            if not sel:
+                return
+            b = sum(v["bytes"] for v in sel)
+            msx = sum(v["ms"] for v in sel)
+            fl = sum(v["flops"] for v in sel)
+            e = {"ms_per_step": msx / args.steps, "algorithmic_mb_per_step": b / args.steps / 1e6,
+                 "achieved_gbps": b / (msx * 1e-3) / 1e9, "peak_gbps": PEAK_HBM_GBPS, "frac": b / (msx * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                 "note": note}
+            if fl:
+                e["tflops"] = fl / (msx * 1e-3) / 1e12
+                e["frac_mfma_f32"] = e["tflops"] / PEAK_F32_MFMA_TFLOPS
+            hbm[name] = e
+
+        entry("pillarise_fwd", ["pillarise_fwd", "canvas_zero_fill"],
+              "both clouds: voxelise, sort, feature net (train: + batch statistics), canvas incl. its zero fill; "
+              "bytes = points in + dense 32-channel canvas out (SURVEY 8d: 69.0 MB/pair)")
+        entry("bn_gelu_apply", ["bn_gelu_apply"], "BatchNorm normalise + GELU: read y, write z (8 B/element)")
+        entry("bn_gelu_bwd", ["bn_gelu_bwd_reduce", "bn_gelu_bwd_apply"], "two passes: read dz,y | read dz,y write dy (20 B/element)")
+        entry("gru_fwd", ["gru_fwd"], "gather + T GRU steps + head, training form; bytes = fused minimum (548 B/point)")
+        entry("gru_bwd", ["gru_bwd"], "data gradients; bytes = (T+2) state planes + dflow/offsets per point")
+        entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = one read of the three gate-gradient planes + h|x rows per step")
+        out["roofline_hbm"] = hbm
+
+    if world == 1 and not args.no_extras:
         # forward-only pairs/s of BASELINE configs[1] (one 80k-point pair, eval mode) beside the headline
+        def time_forward(m, b, reps):
+            with torch.no_grad():
+                for _ in range(3):
+                    m.forward_padded(b)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    m.forward_padded(b)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps * 1e3
+
         model.eval()
         b1 = synth_batch(1, N_POINTS, seed=20240116, device=dev)
-        with torch.no_grad():
-            for _ in range(3):
-                model.forward_padded(b1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                model.forward_padded(b1)
-            torch.cuda.synchronize()
-            fwd_ms = (time.perf_counter() - t1) / 20 * 1e3
-        model.train()
-        out["forward_only"] = {"workload": "BASELINE configs[1]: deflow inference, 1 pair (B=1), 80000 pts/cloud, 512x512, 4 GRU iters",
+        fwd_ms = time_forward(model, b1, 20)
+        out["forward_only"] = {"workload": "BASELINE configs[1]: deflow inference, 1 pair (B=1), 80000 pts/cloud, 512x512, 4 GRU iters, fp32",
                                "ms_per_pair": fwd_ms, "pairs_per_s": 1e3 / fwd_ms,
-                               "algorithmic_tflops": 391.6e9 / (fwd_ms * 1e-3) / 1e12}
+                               "algorithmic_tflops": 391.6e9 / (fwd_ms * 1e-3) / 1e12,
+                               "frac_mfma_f32": 391.6e9 / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        fwd16 = time_forward(model, batch, 10)
+        out["forward_only"]["b16_ms_per_pair"] = fwd16 / args.batch
+        model.inference_dtype = "bf16"
+        f16 = time_forward(model, b1, 20)
+        out["forward_only"]["bf16_ms_per_pair"] = f16
+        model.train()
+        model.inference_dtype = "fp32"
+        del b1
+        # BASELINE configs[4] shape: 1024x1024 grid (voxel 0.1 m), 160k points per cloud, 8 GRU iterations, bf16 MFMA; one pair
+        torch.manual_seed(0)
+        big = deflow_amd.DeFlow(voxel_size=[0.1, 0.1, 6], grid_feature_size=[1024, 1024], num_iters=8).to(dev).eval()
+        bb = synth_batch(1, 160000, seed=20240116, device=dev)
+        f32_ms = time_forward(big, bb, 5)
+        big.inference_dtype = "bf16"
+        bf_ms = time_forward(big, bb, 10)
+        # roofs from SURVEY 8(d): 1564 GFLOP and 3.85 GB per pair at this shape
+        out["bf16_inference"] = {"workload": "BASELINE configs[4] shape: deflow inference, 1 pair, 160000 pts/cloud, 1024x1024, 8 GRU iters",
+                                 "dtype": "bf16 MFMA (fp32 accumulate, fp32 pillars / gates)", "ms_per_pair": bf_ms, "pairs_per_s": 1e3 / bf_ms,
+                                 "fp32_ms_per_pair": f32_ms, "algorithmic_tflops": 1564e9 / (bf_ms * 1e-3) / 1e12,
+                                 "frac_mfma_bf16": 1564e9 / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                 "frac_hbm": 3.85e9 / (bf_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+        del big, bb
     if use_dist:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
     print(json.dumps(out), flush=True)
 
 

@@ -70,7 +70,7 @@ class DeFlowFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, pc0s, pc1s, *params):
-        flow, state = model._run(pc0s, pc1s, train=True, save=True)
+        flow, state = model._run(pc0s, pc1s, train=model.training, save=True)   # eval mode: frozen-BatchNorm tape
         ctx.model, ctx.state, ctx.params = model, state, list(params)
         model._state_tmp = state
         return flow

@@ -14,6 +14,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import ops
 from ._lib import DfImg, call, img, ptr, stream
 from .autograd import DeFlowFn
 from .decoder import ConvGRUDecoder, LinearDecoder, PointSet
@@ -59,7 +60,8 @@ class DeFlow(nn.Module):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device
-        bstar = torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)  # streaming zero-fill; pillars overwrite
+        with ops.timed("canvas_zero_fill"):   # part of the pillarise stage's time; its bytes are counted in pillarise_fwd
+            bstar = torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)  # streaming zero-fill; pillars overwrite
         self.timer[1].start("Voxelization")
         if not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0":
             # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
@@ -115,7 +117,9 @@ class DeFlow(nn.Module):
 
         train = self.training
         params = [p for p in self.parameters()]
-        if torch.is_grad_enabled() and train and any(p.requires_grad for p in params):
+        # differentiable whenever autograd is recording, in training AND in eval mode (frozen BatchNorm), as the reference
+        # nn.Module is; inference callers wrap the call in torch.no_grad() (eval.py, bench.py do) and get the tape-less path
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             flow = DeFlowFn.apply(self, pc0s, pc1s, *params)
             state = self._state_tmp
             self._state_tmp = None

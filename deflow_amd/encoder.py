@@ -93,6 +93,12 @@ class DynamicEmbedder(nn.Module):
     # -- engine ------------------------------------------------------------------------------
     def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
         """pts [B,N,3] f32 contiguous on the GPU; writes the occupied cells of the ZERO-FILLED [B,H,W,32] canvas `out`."""
+        B, N, _ = pts.shape
+        # algorithmic traffic of the stage (SURVEY 8(d)): the points once in, the dense 32-channel canvas once out
+        with ops.timed("pillarise_fwd", bytes=B * (N * 12.0 + 32.0 * self.H * self.W * 4.0), tag=f"B={B} N={N}"):
+            return self._pillarize(pts, out, train)
+
+    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
         assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
         B, N, _ = pts.shape
         dev, g, s = pts.device, self.geom, stream()
@@ -186,7 +192,7 @@ class DynamicEmbedder(nn.Module):
         partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_stats", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, self.mode, gout, ptr(partial), nbs, s)
-        if ops.SYNC is not None:   # statistics of sample b are shared with sample b of the other ranks (one module call each)
+        if ops.SYNC is not None and st.bn_stride != 0:   # statistics of sample b are shared with sample b of the other ranks
             loc = partial.double().sum(1)                                         # [B, 32, (sum g, sum g * xhat)], this rank
             tb, tg = loc[:, :, 0].sum(0).float(), loc[:, :, 1].sum(0).float()
             dbeta.copy_(dbeta + tb if acc else tb)
@@ -197,6 +203,8 @@ class DynamicEmbedder(nn.Module):
         else:
             coef = torch.empty(B, 2, 32, dtype=torch.float32, device=dev)
             call("df_pfn_bwd_finalize", ptr(partial), B, nbs, ptr(st.counts), ptr(dgamma), ptr(dbeta), int(acc), ptr(coef), s)
+            if st.bn_stride == 0:      # eval mode: running statistics are constants, no batch-statistic terms
+                coef.zero_()
         dwp = torch.empty(B * nbs, 288, dtype=torch.float32, device=dev)
         call("df_pfn_bwd_weights", ptr(st.pts_sorted), ptr(st.cell_rng), ptr(st.key_sorted), ptr(st.counts), B, g, ptr(w), ptr(st.bn_ss),
              st.bn_stride, self.mode, ptr(coef), gout, ptr(dwp), nbs, s)

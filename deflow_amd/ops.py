@@ -25,23 +25,46 @@ def ohwi(w: torch.Tensor) -> torch.Tensor:
 
 
 class KernelProfiler:
-    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline figure).  Events are
+    """Optional per-launch HIP-event timing of the hot kernels (bench.py's live roofline figures).  Events are
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (kernel name, algorithmic flops, start event, end event, layer tag)
+        self.records = []  # (kernel / stage name, algorithmic flops, start event, end event, layer tag[, algorithmic bytes])
 
     def summary(self):
         out = {}
-        for name, flops, e0, e1, _ in self.records:
-            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for name, flops, e0, e1, _tag, *rest in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += rest[0] if rest else 0.0
             d["ms"] += e0.elapsed_time(e1)
         return out
 
 
 PROFILER: Optional[KernelProfiler] = None
+
+
+class timed:
+    """with ops.timed("stage", bytes=..., flops=...): HIP events around a launch (or a short chain of launches) on the current
+    stream when a KernelProfiler is installed; free otherwise.  `bytes` / `flops` are the ALGORITHMIC figures of DESIGN.md
+    section 4 (what the stage has to move / compute), not what the implementation happens to do."""
+
+    def __init__(self, name: str, bytes: float = 0.0, flops: float = 0.0, tag: str = ""):
+        self.name, self.bytes, self.flops, self.tag = name, float(bytes), float(flops), tag
+        self.prof = PROFILER
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof is not None and exc[0] is None:
+            self.e1.record()
+            self.prof.records.append((self.name, self.flops, self.e0, self.e1, self.tag, self.bytes))
+        return False
 
 
 class SideStream:
@@ -176,7 +199,8 @@ def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, mo
 
 
 def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):
-    call("df_bn_gelu_apply", ptr(y), ptr(bn_ss), imgs_per_group, z, stream())
+    with timed("bn_gelu_apply", bytes=8.0 * y.numel()):          # read y, write z
+        call("df_bn_gelu_apply", ptr(y), ptr(bn_ss), imgs_per_group, z, stream())
 
 
 def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
@@ -187,17 +211,20 @@ def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
     return n
 
 
-def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True
-                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """-> dy [n,h,w,C], dgamma [C], dbeta [C], dbias [C]"""
+def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True,
+                frozen: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> dy [n,h,w,C], dgamma [C], dbeta [C], dbias [C].
+    frozen: eval-mode BatchNorm (running statistics are constants): the batch-statistic terms of the data gradient
+    vanish (coef = 0), dgamma / dbeta keep their form, and the conv bias gradient is no longer cancelled."""
     dev = y.device
     C = dz.c
     rows_per_group = imgs_per_group * dz.h * dz.w
     nbg = _pow2_blocks(rows_per_group)
     nblk = nbg * groups
     partial = _f32(nblk, C, 2, device=dev)
-    call("df_bn_gelu_bwd_reduce", dz, ptr(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
-    if SYNC is not None:
+    with timed("bn_gelu_bwd_reduce", bytes=8.0 * y.numel()):     # read dz, y
+        call("df_bn_gelu_bwd_reduce", dz, ptr(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
+    if SYNC is not None and not frozen:
         red = partial.view(groups, nbg, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
         dbeta, dgamma = red[:, :, 0].sum(0).float(), red[:, :, 1].sum(0).float()
         glob = SYNC.sum(red.clone()) / (float(rows_per_group) * SYNC.world)
@@ -206,9 +233,12 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
         dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
         coef = _f32(groups, 2, C, device=dev)
         call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
+        if frozen:
+            coef.zero_()
     dy = torch.empty_like(y)
     dbp = _f32(nblk, C, device=dev)
-    call("df_bn_gelu_bwd_apply", dz, ptr(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), ptr(dbp), nblk, stream())
+    with timed("bn_gelu_bwd_apply", bytes=12.0 * y.numel()):     # read dz, y; write dy
+        call("df_bn_gelu_bwd_apply", dz, ptr(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), ptr(dbp), nblk, stream())
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
     return dy, dgamma, dbeta, dbias

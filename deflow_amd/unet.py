@@ -34,11 +34,17 @@ class ConvWithNorms(nn.Module):
         xh = x.permute(0, 2, 3, 1).contiguous()
         n, h, w, _ = xh.shape
         ho, wo = (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
-        if ho == 1 and wo == 1:
-            raise NotImplementedError("1x1 output maps (BatchNorm skipped, [REF decoder.py:214-217]) are not on the DeFlow path")
         z = torch.empty(n, ho, wo, self.conv.out_channels, dtype=torch.float32, device=x.device)
         with torch.no_grad():
-            _cwn_forward(self, img(xh), img(z), n, 1, self.training, None)
+            if ho == 1 and wo == 1:
+                # [REF decoder.py:214-217]: BatchNorm is skipped on 1x1 maps (in training AND eval; no statistics update) ->
+                # gelu(conv(x) + bias): the folded epilogue with scale 1, shift 0
+                C = self.conv.out_channels
+                one = torch.ones(C, dtype=torch.float32, device=x.device)
+                ops.conv2d(img(xh), ops.ohwi(self.conv.weight), self.conv.bias.detach(), img(z), self.conv.kernel_size[0],
+                           self.stride, epi=ops.EPI_BN_GELU, scale=one, shift=torch.zeros_like(one))
+            else:
+                _cwn_forward(self, img(xh), img(z), n, 1, self.training, None)
         return z.permute(0, 3, 1, 2)
 
 
@@ -56,9 +62,19 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     dev = m.conv.weight.device
     w, b, bn = ops.ohwi(m.conv.weight), m.conv.bias.detach(), m.batchnorm
     C = m.conv.out_channels
-    if not train:
+    if not train and tape is None:
         scale, shift, _, _ = ops.folded_bn(bn)
         ops.conv2d(x, w, b, z, 3, m.stride, epi=ops.EPI_BN_GELU, scale=scale, shift=shift)
+        return
+    if not train:
+        # eval mode WITH a tape (fine-tuning with frozen BatchNorm, saliency, gradient checks: the reference module is
+        # differentiable in eval mode): keep the conv output y and normalise with the running statistics through the same
+        # two kernels as training, so the shared backward applies with the batch-statistic terms switched off
+        y = torch.empty(n_imgs, z.h, z.w, C, dtype=torch.float32, device=dev)
+        ops.conv2d(x, w, b, img(y), 3, m.stride, epi=ops.EPI_BIAS)
+        bn_ss = torch.stack(list(ops.folded_bn(bn))).view(1, 4, C).contiguous()   # scale, shift, running mean, invstd
+        ops.bn_gelu_apply(y, bn_ss, n_imgs, z)
+        tape.append(("cwn", m, x, y, bn_ss, n_imgs, 1, True))
         return
     ipg = n_imgs // groups
     rows_pg = ipg * z.h * z.w
@@ -77,7 +93,7 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     bn.num_batches_tracked.add_(groups)
     ops.bn_gelu_apply(y, bn_ss, ipg, z)
     if tape is not None:
-        tape.append(("cwn", m, x, y, bn_ss, ipg, groups))
+        tape.append(("cwn", m, x, y, bn_ss, ipg, groups, False))
 
 
 class FastFlow3DUNet(nn.Module):
@@ -383,8 +399,8 @@ class FastFlow3DUNet(nn.Module):
         for sidx, stage in ((3, self.encoder_step_3), (2, self.encoder_step_2), (1, self.encoder_step_1)):
             for i in reversed(range(len(stage))):
                 pop("keep")
-                _, m, x, y, bn_ss, ipg, groups = pop("cwn")
-                dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups)
+                _, m, x, y, bn_ss, ipg, groups, frozen = pop("cwn")
+                dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups, frozen=frozen)
                 hold(dy)
                 grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
                 if i > 0:

@@ -375,6 +375,12 @@ class DeFlow(nn.Module):
             pc0s.append(t_pc0)
         pc0s = torch.stack(pc0s, dim=0)
         pc1s = batch["pc1"]
+        # fp64 checker mode (``ref.double()``, tests only): the ego-motion step and the voxel coordinates stay fp32 -- they
+        # decide WHICH cell a point falls in and must equal the fp32 path bit for bit -- everything downstream (offsets,
+        # feature net, UNet, decoder) runs in double, which gives the tests a yardstick for both fp32 implementations
+        pdt = next(self.parameters()).dtype
+        if pdt != pc0s.dtype:
+            pc0s, pc1s = pc0s.to(pdt), pc1s.to(pdt)
         img0, infos0 = self.embedder(pc0s)
         img1, infos1 = self.embedder(pc1s)
         grid = self.backbone(img0, img1)

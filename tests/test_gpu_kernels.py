@@ -114,6 +114,54 @@ def test_conv_dgrad_wgrad(dev, cin, cout, k, s, n, h, w):
     check("bias grad (colsum)", db, gy.sum((0, 2, 3)))
 
 
+# the tiles the BASELINE shapes actually run on: 128-pixel haloed tiles (W % 128 == 0), the 8-wave 128x128 DMA tile, the
+# 12-wave ring weight gradient, the 1x1 weight-gradient tiles -- reached directly here, not only through the model tests,
+# so that the DF_CONV_HALO / DF_CONV_W8 / DF_WGRAD_RING legs of test_alternate_kernel_paths switch something
+BIG_CONV_CASES = [  # cin, cout, k, stride, n, h, w, forward kernel, dgrad kernel, wgrad kernel (default switches)
+    (128, 128, 3, 1, 2, 64, 128, "conv_halo_kernel<128,2,4>", "conv_halo_kernel<128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
+    (64, 64, 3, 1, 2, 32, 256, "conv_halo_kernel<64,4,2>", "conv_halo_kernel<64,4,2>", "wgrad3_ring_kernel<32,2,1>"),
+    (128, 64, 3, 1, 2, 64, 128, "conv_halo_kernel<64,4,2>", "conv_halo_kernel<128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
+    (256, 128, 3, 1, 3, 64, 64, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
+    (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1x1_kernel<128>"),
+    (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad_kernel<3,2,32>"),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,n,h,w,k_fwd,k_dgrad,k_wgrad", BIG_CONV_CASES)
+def test_conv_big_tiles(dev, cin, cout, k, s, n, h, w, k_fwd, k_dgrad, k_wgrad):
+    import os
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin * 5 + cout + k + s + w)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv2d(x, wt, b, stride=s, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, gyd = nhwc(x.detach()).to(dev), nhwc(gy).to(dev)
+    wd = ops.ohwi(wt.detach().to(dev).contiguous(memory_format=torch.channels_last))
+    prof = ops.KernelProfiler()
+    ops.PROFILER = prof
+    try:
+        yd = torch.empty(n, y.shape[2], y.shape[3], cout, device=dev)
+        ops.conv2d(img(xd), wd, b.to(dev), img(yd), k, s)
+        dx = torch.empty_like(xd)
+        ops.conv2d(img(gyd), ops.weight_transpose(wd), None, img(dx), k, s, mode=ops.CONV_DGRAD)
+        dw = torch.empty_like(wd)
+        db = ops.conv2d_wgrad(img(xd), img(gyd), k, s, dw, want_bias=True)
+    finally:
+        ops.PROFILER = None
+    names = [r[0] for r in prof.records]
+    print(f"[kernels] {cin}->{cout} k{k} s{s} @{h}x{w}x{n}: {names}")
+    if not any(e.startswith(("DF_CONV", "DF_WGRAD")) for e in os.environ):   # default dispatch: the forms named above
+        assert names == [k_fwd, k_dgrad, k_wgrad], names
+    check(f"big conv fwd {cin}->{cout} k{k} s{s}", nchw(yd), y.detach())
+    check(f"big conv dgrad {cin}->{cout} k{k} s{s}", nchw(dx), x.grad)
+    check(f"big conv wgrad {cin}->{cout} k{k} s{s}", dw.permute(0, 3, 1, 2), wt.grad)
+    check("big conv bias grad", db, gy.sum((0, 2, 3)))
+
+
 # ---------------------------------------------------------------------------- BN + GELU -----------
 @pytest.mark.parametrize("groups", [1, 2])
 def test_convwithnorms_train_fwd_bwd(dev, groups):
@@ -157,7 +205,7 @@ def test_convwithnorms_train_fwd_bwd(dev, groups):
     assert float(dbias.abs().max()) <= 1e-3 * float(gz.abs().sum())  # mathematically zero under BatchNorm
 
 
-@pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1"])
+@pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1", "skip1x1"])
 def test_convwithnorms_golden(dev, golden_dir, tag):
     """REAL reference vectors ([REF decoder.py:202-220] executed by oracle/gen_golden.py)"""
     import os

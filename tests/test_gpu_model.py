@@ -76,79 +76,61 @@ def test_forward_eval_vs_oracle(dev, opt):
         check(f"pose_flow b{b}", got["pose_flow"][b].cpu()[m], want["pose_flow"][b][m], 1e-5)
 
 
-def test_train_step_vs_oracle(dev):
-    """forward in training mode (batch statistics), deflowLoss, backward: every parameter gradient vs the oracle's
-    autograd; BatchNorm running statistics after the step."""
+def test_train_step_vs_oracle(dev, monkeypatch):
+    """forward in training mode (batch statistics), deflowLoss, backward: flow, loss and EVERY parameter gradient against
+    the oracle in fp32 and in fp64 (tests/parity.py: err(HIP, fp64) <= max(1e-4, 4 x err(oracle fp32, fp64))); the 17
+    BatchNorm-shadowed conv biases must vanish against sum|dy|; BatchNorm running statistics after the step."""
     from oracle import ref_torch as O
+    import parity
     ref, mine = build_pair(dev, 2, decoder_option="gru", num_iters=4)
     ref.train(); mine.train()
+    ref, ref64 = parity.oracle_pair(ref)
     batch = make_batch(2, 1500, 200)
-    res_r = ref(batch)
-    loss_r = O.training_loss(res_r, batch)
-    loss_r.backward()
+    o32, o64 = parity.oracle_step(ref, batch), parity.oracle_step(ref64, batch)
     bd = to_dev(batch, dev)
+    sums = parity.DyAbsSums(monkeypatch)
     res_m = mine(bd)
-    for b in range(2):
-        check(f"train flow b{b}", res_m["flow"][b], res_r["flow"][b], 2e-4)
     loss_m = O.training_loss(res_m, bd)  # the trainer's own torch loss on the drop-in result dict
-    check("loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
     loss_m.backward()
-    worst = 0.0
-    pr = dict(ref.named_parameters())
-    for k, p in mine.named_parameters():
-        assert p.grad is not None, k
-        e = rel_err(p.grad, pr[k].grad)
-        worst = max(worst, e)
-        is_bn_shadowed_bias = k.endswith("conv.bias") and "encoder_step" in k  # exactly cancelled by BatchNorm: noise/noise
-        print(f"[parity] grad {k}: rel_err={e:.3e}")
-        if not is_bn_shadowed_bias:
-            assert e <= 2e-3, (k, e)
+    parity.check_step("train_step", mine, res_m, loss_m.detach(), o32, o64, dy_sums=sums)
     br = dict(ref.named_buffers())
     for k, v in mine.named_buffers():
         if v.dtype.is_floating_point:
             check(f"buffer {k}", v, br[k], 1e-4)
         else:
             assert int(v) == int(br[k]), k
-    print(f"[parity] worst parameter-gradient rel err: {worst:.3e}")
 
 
 def test_train_step_scatter_max_vs_oracle(dev):
     """DynamicScatter reduce 'max' (the embedder's mode="max"): forward canvas and the whole training step against the
-    oracle, whose backward follows mmcv's rule (the first maximal point of a pillar takes the channel's gradient)."""
+    oracle (fp32 and fp64), whose backward follows mmcv's rule (the first maximal point of a pillar takes the channel's
+    gradient)."""
     from oracle import ref_torch as O
+    import parity
     ref, mine = build_pair(dev, 5, decoder_option="gru", num_iters=2)
     ref.embedder.feature_net.mode = "max"
     mine.embedder.mode = 1
     ref.train(); mine.train()
+    ref, ref64 = parity.oracle_pair(ref)
     batch = make_batch(2, 3000, 700)       # ~0.7 points per cell on average: many multi-point pillars
-    res_r = ref(batch)
-    loss_r = O.training_loss(res_r, batch)
-    loss_r.backward()
+    o32, o64 = parity.oracle_step(ref, batch), parity.oracle_step(ref64, batch)
     bd = to_dev(batch, dev)
     res_m = mine(bd)
-    for b in range(2):
-        check(f"max-mode flow b{b}", res_m["flow"][b], res_r["flow"][b], 2e-4)
     loss_m = O.training_loss(res_m, bd)
-    check("max-mode loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
     loss_m.backward()
-    pr = dict(ref.named_parameters())
-    for k, p in mine.named_parameters():
-        e = rel_err(p.grad, pr[k].grad)
-        if k.startswith("embedder"):
-            print(f"[parity] max-mode grad {k}: rel_err={e:.3e}")
-        if not (k.endswith("conv.bias") and "encoder_step" in k):
-            assert e <= 2e-3, (k, e)
+    parity.check_step("scatter_max", mine, res_m, loss_m.detach(), o32, o64)
     ref.eval(); mine.eval()
     with torch.no_grad():
         want, got = ref.embedder(batch["pc0"])[0], mine.embedder(bd["pc0"])[0]
     check("max-mode eval canvas", got, want, 1e-5)
 
 
-def test_full_size_train_step_vs_oracle(dev):
+def test_full_size_train_step_vs_oracle(dev, monkeypatch):
     """the BASELINE shape itself (512 x 512 grid, 80 000 points per cloud, 4 GRU iterations; one pair): loss, flow and
-    every parameter gradient of a training step against the oracle's autograd (about 15 s of CPU time).  This is the
-    shape at which the 8/12-wave tiles, the two-stage reductions and the sparse edge kernels are actually exercised."""
+    every parameter gradient of a training step against the oracle in fp32 and fp64 (about 15 s + 1 min of CPU time).  This
+    is the shape at which the 8/12-wave tiles, the two-stage reductions and the sparse edge kernels are actually exercised."""
     import deflow_amd
+    import parity
     from oracle import ref_torch as O
     from deflow_amd.synth import synth_batch
     torch.manual_seed(11)
@@ -157,45 +139,125 @@ def test_full_size_train_step_vs_oracle(dev):
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(dev)
     ref.train(); mine.train()
+    ref, ref64 = parity.oracle_pair(ref)
     batch = synth_batch(1, 80000)
-    res_r = ref(batch)
-    loss_r = O.training_loss(res_r, batch)
-    loss_r.backward()
+    o32, o64 = parity.oracle_step(ref, batch), parity.oracle_step(ref64, batch)
     bd = to_dev(batch, dev)
+    sums = parity.DyAbsSums(monkeypatch)
     res_m = mine(bd)
-    check("full-size flow", res_m["flow"][0], res_r["flow"][0], 2e-4)
     loss_m = O.training_loss(res_m, bd)
-    check("full-size loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
     loss_m.backward()
-    pr = dict(ref.named_parameters())
-    worst = 0.0
-    for k, p in mine.named_parameters():
-        if k.endswith("conv.bias") and "encoder_step" in k:   # cancelled exactly by BatchNorm: noise / noise
-            continue
-        e = rel_err(p.grad, pr[k].grad)
-        worst = max(worst, e)
-        assert e <= 2e-3, (k, e)
-    print(f"[parity] full-size worst parameter-gradient rel err: {worst:.3e}")
+    parity.check_step("full_size", mine, res_m, loss_m.detach(), o32, o64, dy_sums=sums)
+
+
+def _bs16_case(dev, monkeypatch, grid, n_pts, tag, with_fp64):
+    import deflow_amd
+    import parity
+    from oracle import ref_torch as O
+    from deflow_amd.synth import synth_batch
+    half = 0.1 * grid
+    cfg = dict(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid])
+    torch.manual_seed(16)
+    ref = O.DeFlow(**cfg)
+    mine = deflow_amd.DeFlow(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    ref.train(); mine.train()
+    ref, ref64 = parity.oracle_pair(ref)
+    batch = synth_batch(16, n_pts, seed=4242, grid_hw=(grid, grid))
+    o32 = parity.oracle_step(ref, batch)
+    o64 = parity.oracle_step(ref64, batch) if with_fp64 else None
+    bd = to_dev(batch, dev)
+    sums = parity.DyAbsSums(monkeypatch)
+    # the bench's own path: Trainer.step's forward_padded + fused loss kernel + hand-sequenced backward into the arena
+    from deflow_amd.optim import Trainer
+    tr = Trainer(mine, lr=0.0)
+    tr.flat.zero_grad(); tr.sink.begin()
+    mine.forward_padded(bd)
+    loss_m = tr.loss_on_last_forward(bd)
+    loss_m.backward()
+    torch.cuda.synchronize()
+    st = mine.last_state
+    m0 = st["counts0"].tolist()
+    res_m = {"flow": [st["flow"][b, :m0[b]] for b in range(16)]}
+    if with_fp64:
+        parity.check_step(tag, mine, res_m, loss_m.detach(), o32, o64, dy_sums=sums)
+    else:   # fp32 oracle only (the fp64 twin of 16 full-size pairs costs ~10 min of CPU): north-star tolerance doubled for the
+        res32, loss32, g32 = o32      # oracle's own fp32 rounding, shadowed biases against sum|dy| as everywhere
+        for b in range(16):
+            check(f"{tag} flow[{b}]", res_m["flow"][b], res32["flow"][b], 2e-4)
+        check(f"{tag} loss", loss_m.reshape(1), loss32.reshape(1), 1e-4)
+        shadow = sums.by_module(mine.backbone)
+        mods = dict(mine.backbone.named_modules())
+        worst = 0.0
+        for k, p in mine.named_parameters():
+            if parity.is_bn_shadowed_bias(k):
+                sc = shadow[mods[k[len("backbone."):-len(".conv.bias")]]]
+                assert float(p.grad.abs().max()) <= 1e-6 * sc, k
+                continue
+            e = rel_err(p.grad, g32[k])
+            parity.record(tag, "grad " + k, err_hip_vs_oracle32=e, bound=2e-4, ok=e <= 2e-4)
+            worst = max(worst, e)
+            assert e <= 2e-4, (k, e)
+        print(f"[parity] {tag}: worst parameter-gradient error vs fp32 oracle: {worst:.3e}")
+
+
+def test_bs16_train_step_vs_oracle(dev, monkeypatch):
+    """BASELINE configs[2] is quoted at bs = 16: the batch size changes the split-K partitions of the weight gradients, the
+    two-stage BatchNorm reductions (thousands of tile partials per group), the max(1, 256 // B) block counts and work lists
+    of the sparse edge kernels.  16 pairs on a 256 x 256 grid / 20 000 points (every bs-dependent branch, seconds of CPU)
+    through the bench's own path (Trainer: fused loss kernel, gradient arena) against the oracle in fp32 and fp64."""
+    _bs16_case(dev, monkeypatch, 256, 20000, "bs16_256", with_fp64=True)
+
+
+@pytest.mark.skipif(os.environ.get("DF_TEST_FULL_BS16", "1") == "0", reason="DF_TEST_FULL_BS16=0")
+def test_bs16_full_size_train_step_vs_oracle(dev, monkeypatch):
+    """configs[2] exactly: 16 pairs x 80 000 points on the 512 x 512 grid, one training step against the fp32 oracle
+    (minutes of CPU time; DF_TEST_FULL_BS16=0 skips it)."""
+    _bs16_case(dev, monkeypatch, 512, 80000, "bs16_512", with_fp64=False)
 
 
 def test_fastflow3d_train_step_vs_oracle(dev):
-    """decoder_option=linear (the fastflow3d head): training step gradients vs the oracle"""
+    """decoder_option=linear (the fastflow3d head): training step gradients vs the oracle (fp32 and fp64)"""
     from oracle import ref_torch as O
+    import parity
     ref, mine = build_pair(dev, 4, decoder_option="linear")
     ref.train(); mine.train()
+    ref, ref64 = parity.oracle_pair(ref)
     batch = make_batch(2, 1200, 400)
-    loss_r = O.training_loss(ref(batch), batch)
-    loss_r.backward()
+    o32, o64 = parity.oracle_step(ref, batch), parity.oracle_step(ref64, batch)
     bd = to_dev(batch, dev)
-    loss_m = O.training_loss(mine(bd), bd)
-    check("linear-head loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    res_m = mine(bd)
+    loss_m = O.training_loss(res_m, bd)
     loss_m.backward()
-    pr = dict(ref.named_parameters())
-    for k, p in mine.named_parameters():
-        if k.endswith("conv.bias") and "encoder_step" in k:
-            continue
-        e = rel_err(p.grad, pr[k].grad)
-        assert e <= 2e-3, (k, e)
+    parity.check_step("fastflow3d", mine, res_m, loss_m.detach(), o32, o64)
+
+
+def test_eval_mode_backward_vs_oracle(dev):
+    """model.eval() with autograd recording (fine-tuning with frozen BatchNorm, saliency, gradient checks): the reference
+    nn.Module is differentiable in eval mode, so is this one -- running statistics in the forward, no batch-statistic terms
+    in the backward, conv biases no longer shadowed (every one of them is checked), running statistics untouched."""
+    from oracle import ref_torch as O
+    import parity
+    ref, mine = build_pair(dev, 6, decoder_option="gru", num_iters=3)
+    ref.eval(); mine.eval()
+    ref, ref64 = parity.oracle_pair(ref)
+    buf0 = {k: v.clone() for k, v in mine.named_buffers()}
+    batch = make_batch(2, 1500, 900)
+    o32, o64 = parity.oracle_step(ref, batch), parity.oracle_step(ref64, batch)
+    bd = to_dev(batch, dev)
+    res_m = mine(bd)
+    assert res_m["flow"][0].grad_fn is not None, "eval-mode forward under autograd must be differentiable"
+    loss_m = O.training_loss(res_m, bd)
+    loss_m.backward()
+    parity.check_step("eval_backward", mine, res_m, loss_m.detach(), o32, o64)
+    for k, v in mine.named_buffers():
+        assert torch.equal(v, buf0[k]), f"eval mode must not touch {k}"
+    # and without autograd the same call takes the tape-less inference path with identical values
+    with torch.no_grad():
+        res_n = mine(bd)
+    for b in range(2):
+        check(f"eval no_grad flow[{b}]", res_n["flow"][b], res_m["flow"][b], 1e-5)
 
 
 def test_fused_loss_path_matches_list_path(dev):
@@ -377,6 +439,82 @@ def test_bf16_inference_path_vs_oracle(dev):
     check("loss with bf16 inference switch set", lm_.reshape(1), lr_.reshape(1), 1e-4)
 
 
+def _bf16_flow_err(got, want):
+    g, w = got.detach().float().cpu(), want.detach().float()
+    return float((g - w).abs().max() / w.abs().max()), float(((g - w) ** 2).mean().sqrt() / (w ** 2).mean().sqrt())
+
+
+def test_bf16_configs4_shape_vs_oracle(dev):
+    """BASELINE configs[4] at its own shape: 1024 x 1024 grid (voxel 0.1 m), 160 000 points per cloud, 8 GRU iterations,
+    bf16 MFMA -- one pair, eval-mode forward (fp32 HIP path AND bf16 path) against the fp32 CPU oracle.  At this size the
+    rolling-row 64->64 kernel (>= 8192 row tiles), the haloed bf16 tiles and the zero-padded first conv (reads 32 channels
+    past each cloud's half of the canvas) are all on the path.  fp32: 1e-4; bf16: 2e-2 of the largest flow component (8
+    mantissa bits through ~30 layers + 8 GRU iterations), rms error reported."""
+    import deflow_amd
+    from oracle import ref_torch as O
+    from deflow_amd.synth import synth_pair
+    cfg = dict(voxel_size=[0.1, 0.1, 6], grid_feature_size=[1024, 1024], num_iters=8)
+    torch.manual_seed(44)
+    ref = O.DeFlow(**cfg)
+    with torch.no_grad():   # non-trivial BatchNorm state, as a trained checkpoint would have
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.6, 1.4); m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.5)
+    mine = deflow_amd.DeFlow(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).eval()
+    ref.eval()
+    p = synth_pair(77, 160000)
+    batch = {"pc0": p[0][None], "pc1": p[1][None], "pose0": torch.eye(4)[None], "pose1": torch.linalg.inv(p[2])[None]}
+    with torch.no_grad():
+        want = ref(batch)
+        got32 = mine(to_dev(batch, dev))
+        mine.inference_dtype = "bf16"
+        got16 = mine(to_dev(batch, dev))
+    assert torch.equal(got16["pc0_valid_point_idxes"][0].cpu(), want["pc0_valid_point_idxes"][0])
+    check("configs[4] shape fp32 flow", got32["flow"][0], want["flow"][0], 1e-4)
+    emax, erms = _bf16_flow_err(got16["flow"][0], want["flow"][0])
+    import parity
+    parity.record("bf16_cfg4", "flow", max_err_over_max_flow=emax, rms_err_over_rms_flow=erms, bound=2e-2, ok=emax <= 2e-2)
+    print(f"[parity] bf16 @1024x1024/160k/8 iters: max err / max|flow| = {emax:.2e}, rms err / rms flow = {erms:.2e} (tol 2e-2)")
+    assert emax <= 2e-2
+
+
+def test_bf16_bs16_vs_fp32_and_oracle(dev):
+    """bf16 inference at B = 16 on the 512 x 512 grid (the encoder's 64->64 layers then reach the rolling-row kernel: 32
+    images x 4 segments x 256 rows): every sample against the fp32 HIP forward of the same batch, samples 0 and 15 also
+    against the CPU oracle (eval mode has no cross-sample coupling, so the oracle runs them alone)."""
+    import deflow_amd
+    from oracle import ref_torch as O
+    from deflow_amd.synth import synth_batch
+    torch.manual_seed(45)
+    ref = O.DeFlow()
+    mine = deflow_amd.DeFlow()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).eval()
+    ref.eval()
+    batch = synth_batch(16, 80000, seed=777)
+    bd = to_dev(batch, dev)
+    with torch.no_grad():
+        got32 = mine(bd)
+        mine.inference_dtype = "bf16"
+        got16 = mine(bd)
+        worst = 0.0
+        for b in range(16):
+            emax, _ = _bf16_flow_err(got16["flow"][b], got32["flow"][b].cpu())
+            worst = max(worst, emax)
+        print(f"[parity] bf16 vs fp32 HIP forward, B=16 @512x512: worst max err / max|flow| = {worst:.2e} (tol 2e-2)")
+        assert worst <= 2e-2
+        for b in (0, 15):
+            one = {k: v[b:b + 1] for k, v in batch.items()}
+            want = ref(one)
+            check(f"B=16 fp32 flow[{b}] vs oracle", got32["flow"][b], want["flow"][0], 1e-4)
+            emax, erms = _bf16_flow_err(got16["flow"][b], want["flow"][0])
+            print(f"[parity] bf16 B=16 flow[{b}] vs oracle: max {emax:.2e} rms {erms:.2e}")
+            assert emax <= 2e-2
+
+
 def test_train_mode_forward_without_grad_is_repeatable():
     """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
     (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
@@ -478,7 +616,7 @@ def test_alternate_kernel_paths(env):
     import sys
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_gpu_kernels.py", "tests/test_gpu_model.py",
-                        "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
+                        "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size and not bs16", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
