@@ -285,8 +285,15 @@ def main():
               "bytes = points in + dense 32-channel canvas out (SURVEY 8d: 69.0 MB/pair)")
         entry("bn_gelu_apply", ["bn_gelu_apply"], "BatchNorm normalise + GELU: read y, write z (8 B/element)")
         entry("bn_gelu_bwd", ["bn_gelu_bwd_reduce", "bn_gelu_bwd_apply"], "two passes: read dz,y | read dz,y write dy (20 B/element)")
+        # the decoder kernels were priced per padded row; only the valid rows (not NaN padding / out of range) do work
+        vf = float(model.last_state["counts0"].sum().item()) / float(args.batch * N_POINTS)
+        for k in ("gru_fwd", "gru_bwd", "gru_wgrad"):
+            if k in summ:
+                summ[k]["flops"] *= vf
+                summ[k]["bytes"] *= vf
         entry("gru_fwd", ["gru_fwd"], "gather + T GRU steps + head, training form; bytes = fused minimum (548 B/point)")
-        entry("gru_bwd", ["gru_bwd"], "data gradients; bytes = (T+2) state planes + dflow/offsets per point")
+        entry("gru_bwd", ["gru_bwd"], "data gradients (flops = 2 x the un-hoisted forward count, SURVEY 8d -- the hoisted kernels execute "
+                                      "about 25 % fewer, so this can exceed what the pipe did); bytes = (T+2) state planes + dflow/offsets per point")
         entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = one read of the three gate-gradient planes + h|x rows per step")
         out["roofline_hbm"] = hbm
 

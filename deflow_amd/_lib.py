@@ -46,6 +46,12 @@ _SIGS = {
     "df_pillar_sort": [P, P, P, L, I, P, L, P],
     "df_pillar_gather_sorted": [P, P, P, L, L, P, P],
     "df_pillar_cells": [P, L, L, P, P],
+    "df_pillar2_rows_per_band": [I, I],
+    "df_pillar2_tile": [],
+    "df_pillar2_hist": [P, I, I, DfGeom, I, P, P],
+    "df_pillar2_scan": [P, I, I, I, P, P, P, P],
+    "df_pillar2_scatter": [P, I, I, DfGeom, I, P, P, P, P, P, P, P, P, P, P, P],
+    "df_pillar2_band": [P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P],
     "df_pfn_stats": [P, P, P, P, I, DfGeom, P, P, I, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
     "df_pfn_canvas": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
@@ -57,6 +63,8 @@ _SIGS = {
     "df_sparse_wgrad3x3": [P, P, I, DfImg, DfImg, P, P, I, P],
     "df_pillar_input_grad": [P, P, I, I, I, I, P, P, DfImg, P, DfImg, I, I, P],
     "df_conv2d": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
+    "df_conv2d_mp": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, I, P],
+    "df_conv2d_wgrad_mp": [DfImg, DfImg, I, I, I, P, I, P, I, P, I, P],
     "df_conv2d_tile_m": [L, I],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
@@ -94,7 +102,7 @@ _SIGS = {
     "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
 }
 _RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
-_RAW = {"df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

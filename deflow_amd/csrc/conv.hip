@@ -24,6 +24,27 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDT = BK;  // LDS row pitch (floats); slots swizzled instead of padded
 
+// ---- bf16-operand mode (mixed-precision training, BASELINE configs[4] "bf16 MFMA"): tensors stay fp32 in HBM and LDS;
+// the MFMA operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as the fragments are read, products are
+// exact in the fp32 accumulator (v_mfma_f32_32x32x16_bf16: 16 k per instruction instead of 2).  What torch.autocast(bf16)
+// computes for a conv -- operands in bf16, fp32 accumulation -- with the output kept in fp32.  Templates carry `BF`.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
+  bf16x8_t r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[k] = (__bf16)lo[k];
+    r[4 + k] = (__bf16)hi[k];
+  }
+  return r;
+}
+__device__ __forceinline__ bf16x8_t pack_bf16(const float (&v)[8]) {
+  bf16x8_t r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = (__bf16)v[k];
+  return r;
+}
+
 struct ConvParams {
   df_img x, y;
   const float* w;
@@ -39,6 +60,7 @@ struct ConvParams {
   unsigned x_bytes, w_bytes, dshift;  // DMA path: buffer extents (bytes) and the base shift that keeps offsets >= 0
   unsigned y_bytes;                   // extent of y in bytes if it fits 32-bit buffer offsets (branch-free epilogue), else 0
   int dbg;  // ablation switch (env DF_CONV_DBG): 1 = no global loads after the prologue, 2 = also no LDS stores
+  int bf16; // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
 };
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 // offset of a stage is wave-uniform and rides in soffset (SGPR), so per stage a thread only recomputes validity.
 constexpr unsigned DMA_BAD = 0xFFFFFFFFu - (8u << 20);  // + soffset (< 8 MB) never wraps, always out of range
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -481,6 +503,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
     if (st + 1 < nst) load_stage(buf ^ 1);   // buf^1 was last read in stage st-1; every wave has passed that barrier
     const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
     const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
+    if constexpr (BF) {
+      // bf16 operands: k groups (2 q, 2 q + 1) of a lane = 8 k values = one operand of v_mfma_f32_32x32x16_bf16
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+        bf16x8_t a8[TM], b8[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a8[i] = pack_bf16(ld4(a + i * 32 * LDT + rslot[2 * q]), ld4(a + i * 32 * LDT + rslot[2 * q + 1]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b8[j] = pack_bf16(ld4(b + j * 32 * LDT + rslot[2 * q]), ld4(b + j * 32 * LDT + rslot[2 * q + 1]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
     // fragments double-buffered in registers: the ds_read_b128s of k-group g+1 are issued before the MFMAs of group g
     f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -515,7 +557,10 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
   DF_SET_LDS_ONCE((conv_kernel<BM, BN, WM, WN>), (int)lds_bytes);
   DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN>), (int)lds_bytes);
-  if (p.x_bytes)
+  if (p.x_bytes && p.bf16) {   // (the register-staged fallback for > 4 GB tensors stays fp32)
+    DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
+  } else if (p.x_bytes)
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
   else
     hipLaunchKernelGGL((conv_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds_bytes, s, p);
@@ -530,7 +575,7 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
 // DMA instructions than the per-tap im2col tiles of conv_dma_kernel (the in-loop DMA costs ~9 % there).  The XOR slot
 // swizzle is keyed on the PHYSICAL tile row, and the b128 fragment reads stay conflict-free for any row shift (every
 // 16-lane service group still touches 16 rows that are distinct mod 16).  8 waves, 2 workgroups per CU (66 KB LDS).
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool BF = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, HR = 136;                 // halo tile rows: 130 used, padded to whole 8-row DMA instructions
@@ -617,6 +662,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
       const float* a = As + (g & 1) * HR * LDT + (wm * TM * 32 + li + tx) * LDT;
       const float* b = Bs + (st & 1) * BN * LDT + (wn * TN * 32 + li) * LDT;
       const int sa = ((li + tx) >> 1) & 7, sb = (li >> 1) & 7;
+      if constexpr (BF) {
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) {
+          bf16x8_t a8[TM], b8[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a8[i] = pack_bf16(ld4(a + i * 32 * LDT + (((4 * q + kh) ^ sa) * 4)), ld4(a + i * 32 * LDT + (((4 * q + 2 + kh) ^ sa) * 4)));
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            b8[j] = pack_bf16(ld4(b + j * 32 * LDT + (((4 * q + kh) ^ sb) * 4)), ld4(b + j * 32 * LDT + (((4 * q + 2 + kh) ^ sb) * 4)));
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        continue;
+      }
       f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[0][i] = ld4(a + i * 32 * LDT + ((kh ^ sa) * 4));
@@ -649,6 +713,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
 template <int BN, int WM, int WN>
 static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (136 + BN) * LDT * sizeof(float);
+  if (p.bf16) {
+    DF_SET_LDS_ONCE((conv_halo_kernel<BN, WM, WN, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN, true>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   DF_SET_LDS_ONCE((conv_halo_kernel<BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_halo_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
@@ -661,6 +731,12 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
   const size_t lds_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+  if (p.bf16) {
+    DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
@@ -676,6 +752,7 @@ struct WgradParams {
   int stride, pad, K, N, chunks_per_row, total_chunks, chunks_per_split;
   unsigned x_bytes, dy_bytes;  // DMA path: buffer extents (0 = use the register-staged kernels)
   float* bias_ws;              // optional [splits][N]: per-split column sums of dy (bias gradient), written by ci-tile 0
+  int bf16;                    // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
 };
 
 // chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
@@ -698,7 +775,7 @@ __device__ __forceinline__ bool wg_row_ok(const WgradParams& p, int pix) {
 
 // Generic k x k weight gradient: 64 co x 64 ci x all taps per workgroup.  Loads are unconditional (clamped address +
 // select) and the NEXT chunk is fetched into registers while the current one is multiplied (T14).
-template <int KS, int STRIDE, int P /* output pixels per chunk (one row segment) */>
+template <int KS, int STRIDE, int P /* output pixels per chunk (one row segment) */, bool BF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   constexpr int XW = (P - 1) * STRIDE + KS;     // input pixels needed per row
   constexpr int TAPS = KS * KS;
@@ -774,7 +851,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   __syncthreads();
   for (int ch = c_begin; ch < c_end; ++ch) {
     if (ch + 1 < c_end) fetch(ch + 1);
-    if (wave_active) {
+    if (wave_active && BF) {   // bf16 operands: lane (column, kh) holds pixels 16 s + 8 kh .. + 7 of k step s
+#pragma unroll
+      for (int ks = 0; ks < P / 16; ++ks) {
+        float av[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) av[k] = dYs[(16 * ks + 8 * kh + k) * LC + wco * 32 + li];
+        const bf16x8_t a8 = pack_bf16(av);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = Xs[(ky * XW + (16 * ks + 8 * kh + k) * STRIDE + kx) * LC + wci * 32 + li];
+            acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, pack_bf16(bv), acc[ky * KS + kx], 0, 0, 0);
+          }
+      }
+    } else if (wave_active) {
 #pragma unroll 4
       for (int ks = 0; ks < P / 2; ++ks) {
         const int px = 2 * ks + kh;
@@ -817,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 // 1x1 weight gradient (= row GEMM dW[co, ci] = sum_p dy[p, co] x[p, ci]) with a 128 co x CIT ci tile per workgroup:
 // every operand row is read once per tile instead of once per 64x64 tile -- the decoder's weight-gradient GEMMs
 // stream 2.6 GB planes and were HBM-bound on re-reads with the generic kernel.
-template <int CIT>
+template <int CIT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
   constexpr int P = 32, COT = 128;
   constexpr int TCI = CIT / 64;               // 32-wide ci tiles per wave
@@ -886,7 +980,30 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(WgradParams p) {
   const bool wave_active = ciw < p.K;
   for (int ch = c_begin; ch < c_end; ++ch) {
     if (ch + 1 < c_end) fetch(ch + 1);
-    if (wave_active) {
+    if (wave_active && BF) {
+#pragma unroll
+      for (int ks = 0; ks < P / 16; ++ks) {
+        bf16x8_t a8[2], b8[TCI];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = dYs[(16 * ks + 8 * kh + k) * COT + wco * 64 + i * 32 + li];
+          a8[i] = pack_bf16(v);
+        }
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = Xs[(16 * ks + 8 * kh + k) * CIT + wci * (CIT / 2) + j * 32 + li];
+          b8[j] = pack_bf16(v);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+    } else if (wave_active) {
 #pragma unroll 4
       for (int ks = 0; ks < P / 2; ++ks) {
         const int px = 2 * ks + kh;
@@ -1045,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams p) {
 // waves per SIMD at most).  The three ky groups share every dY / X tile.  D = 2 (default): double-buffered, two
 // workgroups per CU = six waves per SIMD -- measured +1.5..5 % over the 4-wave kernel (132 vs 126 TFLOP/s on the
 // largest layers); D = 3: one workgroup per CU with a 3-deep ring -- measured 5 % SLOWER (one barrier domain per CU).
-template <int P, int D, int STRIDE = 1>
+template <int P, int D, int STRIDE = 1, bool BF = false>
 __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int XW = (P - 1) * STRIDE + 3, LC = 64;
@@ -1120,7 +1237,37 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
     if (i + D - 1 < nst) issue(c_begin + i + D - 1, (i + D - 1) % D);
     const float* dyb = lds + (i % D) * STG;
     const float* xbuf = dyb + YSZ;
-    if (wave_active) {
+    if (wave_active && BF) {
+      // bf16 operands.  The three horizontal taps of a lane read overlapping pixel runs: ten consecutive pixels are read
+      // once (stride 1) and packed three times with a shift, instead of 3 x 8 LDS reads
+#pragma unroll
+      for (int ks = 0; ks < P / 16; ++ks) {
+        float av[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) av[k] = dyb[(16 * ks + 8 * kh + k) * LC + wco * 32 + li];
+        const bf16x8_t a8 = pack_bf16(av);
+        if constexpr (STRIDE == 1) {
+          float xv[10];
+#pragma unroll
+          for (int k = 0; k < 10; ++k) xv[k] = xbuf[(ky * XW + 16 * ks + 8 * kh + k) * LC + wci * 32 + li];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = xv[k + kx];
+            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, pack_bf16(bv), acc[kx], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = xbuf[(ky * XW + (16 * ks + 8 * kh + k) * STRIDE + kx) * LC + wci * 32 + li];
+            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, pack_bf16(bv), acc[kx], 0, 0, 0);
+          }
+        }
+      }
+    } else if (wave_active) {
 #pragma unroll 4
       for (int ks = 0; ks < P / 2; ++ks) {
         const int px = 2 * ks + kh;
@@ -1341,6 +1488,12 @@ extern "C" int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout) {
 extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                          int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                          int accumulate, void* stream) {
+  return df_conv2d_mp(x, w, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, stream);
+}
+
+extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
+                            int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                            int accumulate, int mfma_bf16, void* stream) {
   DF_REQUIRE(img_ok(x) && img_ok(y) && w && df_aligned16(w), DF_E_ALIGN);
   DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
   DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
@@ -1357,6 +1510,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   ConvParams p;
   p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
+  p.bf16 = mfma_bf16 != 0;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -1458,6 +1612,12 @@ extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride
 
 extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
                                const int32_t* row_counts, int rows_per_seg, float* bias_ws, void* stream) {
+  return df_conv2d_wgrad_mp(x, dy, ksize, stride, pad, ws, splits, row_counts, rows_per_seg, bias_ws, 0, stream);
+}
+
+extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
+                                  const int32_t* row_counts, int rows_per_seg, float* bias_ws, int mfma_bf16,
+                                  void* stream) {
   DF_REQUIRE(!row_counts || (ksize == 1 && x.h == 1 && rows_per_seg > 0), DF_E_ARG);
   DF_REQUIRE(img_ok(x) && img_ok(dy) && ws && df_aligned16(ws), DF_E_ALIGN);
   DF_REQUIRE(x.n == dy.n && x.c % 32 == 0 && dy.c % 64 == 0, DF_E_SHAPE);
@@ -1466,6 +1626,7 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
   WgradParams p;
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = row_counts; p.rows_per_seg = rows_per_seg > 0 ? rows_per_seg : 1;
   p.bias_ws = bias_ws;
+  p.bf16 = mfma_bf16 != 0;
   p.stride = stride; p.pad = pad; p.K = x.c; p.N = dy.c;
   p.x_bytes = p.dy_bytes = 0;
   {
@@ -1506,19 +1667,30 @@ extern "C" int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int p
     const size_t ring_stage = (size_t)(32 * 64 + ((3 * 34 + 3) / 4) * 4 * 64) * 4;
     if (stride == 1 && wgrad_ring_depth(ksize, stride) == 3)
       return launch_wgrad_dma(wgrad3_ring_kernel<32, 3>, grid, 3 * ring_stage, s, p, 768);
-    if (stride == 1 && wgrad_ring_depth(ksize, stride) == 2)
+    if (stride == 1 && wgrad_ring_depth(ksize, stride) == 2) {
+      if (p.bf16) return launch_wgrad_dma(wgrad3_ring_kernel<32, 2, 1, true>, grid, 2 * ring_stage, s, p, 768);
       return launch_wgrad_dma(wgrad3_ring_kernel<32, 2>, grid, 2 * ring_stage, s, p, 768);
+    }
     if (stride == 1) return launch_wgrad_dma(wgrad_dma_kernel<3, 1, 32>, grid, bytes(3, 1), s, p);
     return launch_wgrad_dma(wgrad_dma_kernel<3, 2, 32>, grid, bytes(3, 2), s, p);
   }
   if (wgrad_use_1x1(ksize, dy.c)) {
     const int cit = wgrad_cit(x.c);
     dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);
-    if (cit == 128) hipLaunchKernelGGL((wgrad1x1_kernel<128>), g1, dim3(256), 0, s, p);
+    if (cit == 128 && p.bf16) hipLaunchKernelGGL((wgrad1x1_kernel<128, true>), g1, dim3(256), 0, s, p);
+    else if (cit == 128) hipLaunchKernelGGL((wgrad1x1_kernel<128>), g1, dim3(256), 0, s, p);
+    else if (p.bf16) hipLaunchKernelGGL((wgrad1x1_kernel<64, true>), g1, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad1x1_kernel<64>), g1, dim3(256), 0, s, p);
-  } else if (ksize == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1, 32>), grid, dim3(256), 0, s, p);
-  else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1, 32>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((wgrad_kernel<3, 2, 32>), grid, dim3(256), 0, s, p);
+  } else if (ksize == 1) {
+    if (p.bf16) hipLaunchKernelGGL((wgrad_kernel<1, 1, 32, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1, 32>), grid, dim3(256), 0, s, p);
+  } else if (stride == 1) {
+    if (p.bf16) hipLaunchKernelGGL((wgrad_kernel<3, 1, 32, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<3, 1, 32>), grid, dim3(256), 0, s, p);
+  } else {
+    if (p.bf16) hipLaunchKernelGGL((wgrad_kernel<3, 2, 32, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<3, 2, 32>), grid, dim3(256), 0, s, p);
+  }
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -1,0 +1,499 @@
+// Pillarisation, second generation: band-bucketed stable counting sort + fused feature net + canvas, 4 launches per
+// cloud set in inference (6 in training), every canvas byte written exactly once, no library sort, no float atomics,
+// no spin-waits.  Replaces keys/scan/compact/rocPRIM-sort/gather/cells/stats/canvas + a separate zero-fill (~15
+// launches) of csrc/pillarize.hip on the DeFlow path ([REF deflow.py:27-30,82-83]; algorithm: oracle/ref_torch.py).
+//
+// The BEV grid of every sample is cut into BANDS of R rows (R * W <= 2048 cells).  Sorting points by cell =
+//   pass 1 (global, stable): bucket by (sample, band)        -- df_pillar2_hist / _scan / _scatter
+//   pass 2 (LDS, stable):    counting sort by cell in band    -- df_pillar2_band, one workgroup per (band, sample)
+// and because band = row / R is monotone in the cell key, the concatenation of the sorted buckets IS the array sorted by
+// (sample, cell) with input order kept inside a cell -- the order the first generation got from a stable radix sort, so
+// every consumer (feature-net backward, sparse edge kernels, gather backward) reads the same layout as before.
+//
+//   hist     per 1024-point tile: points per band (LDS integer counters) and valid points            [S][NB+1][nblk]
+//   scan     one wavefront per (sample, column): exclusive scan over the tiles (DPP-free shuffles)     offsets + totals
+//   scatter  per tile: stable ranks from wave ballots (lanes with equal band = AND of per-bit ballots), writes the
+//            order-preserving compaction the result dict needs (points, voxel coords, indices, centre offsets) and
+//            the bucketed (key, index, xyz) arrays
+//   band     the workgroup owning a band: LDS histogram of its <= 2048 cells -> scan -> one wavefront assigns stable
+//            positions chunk by chunk (segmented rank = popcount of the equal-cell lane mask below the lane) while the
+//            other three stream zeros into the band's EMPTY canvas cells -> permuted copy into the sorted arrays and an
+//            LDS image of the sorted points -> 8 lanes per occupied pillar walk its run in LDS: 9-d feature,
+//            Linear(9->32) + BN1d + ReLU, mean / max, one 128-B store per pillar.
+// Training needs the BatchNorm1d batch statistics before it can normalise: band<sort, stats> leaves per-band partial
+// sums (fp32, finalised in fp64 by df_pfn_bn_finalize), band<canvas> then re-derives the cell table from the sorted keys.
+#include "common.h"
+#include "pillar_common.h"
+
+namespace {
+
+constexpr int TILE = 1024;        // points per workgroup in hist / scatter (4 rounds x 256 threads)
+constexpr int MAX_BANDS = 512;    // LDS tables in hist / scatter
+constexpr int BAND_CELLS = 2048;  // max cells per band (LDS cell tables of the band kernel)
+constexpr int CHUNK = 2048;       // bucket elements ranked / staged per round of the band kernel
+
+struct P2Geom {
+  df_pillar_geom g;
+  int R, NB;  // rows per band, bands per sample
+};
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  total = __shfl(x, 63);
+  return x - v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+// lanes of the wave holding the same `c` (among `valid` lanes): AND of per-bit ballots
+template <int NBITS>
+__device__ __forceinline__ unsigned long long match_lanes(int c, bool valid) {
+  unsigned long long mask = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < NBITS; ++b) {
+    const bool bit = (c >> b) & 1;
+    const unsigned long long bal = __ballot(bit);
+    mask &= bit ? bal : ~bal;
+  }
+  return mask;
+}
+
+// ------------------------------------------------------------------------------------------------ hist ----
+__global__ __launch_bounds__(256) void p2_hist_kernel(const float* __restrict__ pts, int N, P2Geom q, int nblk,
+                                                      int32_t* __restrict__ hist) {
+  __shared__ int h[MAX_BANDS + 1];
+  const int s = blockIdx.y, blk = blockIdx.x, ncol = q.NB + 1;
+  for (int i = threadIdx.x; i < ncol; i += 256) h[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    const int n = blk * TILE + r * 256 + threadIdx.x;
+    bool ok = false;
+    int cx = 0, cy = 0;
+    if (n < N) {
+      const float* p = pts + ((int64_t)s * N + n) * 3;
+      ok = voxelize(q.g, p[0], p[1], p[2], cx, cy);
+    }
+    if (ok) atomicAdd(&h[cy / q.R], 1);  // integer LDS counters: totals do not depend on the order of arrival
+    const unsigned long long vb = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&h[q.NB], __popcll(vb));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncol; i += 256) hist[((int64_t)s * ncol + i) * nblk + blk] = h[i];
+}
+
+// ------------------------------------------------------------------------------------------------ scan ----
+// one wavefront per (sample, column): exclusive scan of its nblk tile counters
+__global__ __launch_bounds__(256) void p2_scan_kernel(const int32_t* __restrict__ hist, int ncols_total, int ncol, int nblk,
+                                                      int32_t* __restrict__ off, int32_t* __restrict__ tot,
+                                                      int32_t* __restrict__ counts) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= ncols_total) return;
+  const int32_t* h = hist + (int64_t)col * nblk;
+  int32_t* o = off + (int64_t)col * nblk;
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int i = b0 + lane;
+    const int v = i < nblk ? h[i] : 0;
+    int t;
+    const int e = wave_excl_scan(v, lane, t);
+    if (i < nblk) o[i] = carry + e;
+    carry += t;
+  }
+  if (lane == 0) {
+    tot[col] = carry;
+    if (col % ncol == ncol - 1) counts[col / ncol] = carry;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- scatter ----
+struct P2Scatter {
+  const float* pts;
+  const int32_t *off, *tot;
+  float* points_c;
+  int32_t* coords_c;
+  int64_t* idx_c;
+  float* offs_c;
+  int32_t* cpos;
+  uint32_t *bkey, *bidx;
+  float* bpts;
+  int S, N, nblk;
+};
+
+template <int NBITS>
+__global__ __launch_bounds__(256) void p2_scatter_kernel(P2Scatter a, P2Geom q) {
+  extern __shared__ int sm[];
+  const int NB = q.NB, ncol = NB + 1;
+  int* bstart = sm;                 // [NB] bucket start inside the sample's sorted segment
+  int* blkoff = sm + NB;            // [NB] this tile's offset inside each bucket
+  int* unit = sm + 2 * NB;          // [16][NB] per (round, wave) counts -> exclusive prefix over the 16 units
+  int* vcnt = sm + 18 * NB;         // [16] valid points per unit -> exclusive prefix
+  int* misc = vcnt + 16;            // [0] = first sorted position of this sample
+  const int s = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const df_pillar_geom& g = q.g;
+  if (wave == 0) {  // sorted segment of sample s starts after the valid points of samples 0 .. s-1
+    int v = 0;
+    for (int k = lane; k < s; k += 64) v += a.tot[(int64_t)k * ncol + NB];
+    v = wave_sum(v);
+    if (lane == 0) misc[0] = v;
+    int carry = 0;   // bucket starts: exclusive scan of this sample's band totals
+    for (int b0 = 0; b0 < NB; b0 += 64) {
+      const int i = b0 + lane;
+      const int t = i < NB ? a.tot[(int64_t)s * ncol + i] : 0;
+      int tt;
+      const int e = wave_excl_scan(t, lane, tt);
+      if (i < NB) bstart[i] = carry + e;
+      carry += tt;
+    }
+  }
+  for (int i = threadIdx.x; i < NB; i += 256) blkoff[i] = a.off[((int64_t)s * ncol + i) * a.nblk + blk];
+  for (int i = threadIdx.x; i < 16 * NB; i += 256) unit[i] = 0;
+  __syncthreads();
+  float px[4], py[4], pz[4];
+  int band[4], cxy[4], rk[4], vrk[4];
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = blk * TILE + r * 256 + threadIdx.x;
+    ok[r] = false;
+    band[r] = 0; cxy[r] = 0;
+    px[r] = py[r] = pz[r] = 0.f;
+    if (n < a.N) {
+      const float* p = a.pts + ((int64_t)s * a.N + n) * 3;
+      px[r] = p[0]; py[r] = p[1]; pz[r] = p[2];
+      int cx = 0, cy = 0;
+      ok[r] = voxelize(g, px[r], py[r], pz[r], cx, cy);
+      if (ok[r]) { band[r] = cy / q.R; cxy[r] = cy * g.gx + cx; }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long vb = __ballot(ok[r]);
+    vrk[r] = __popcll(vb & lt);
+    if (lane == 0) vcnt[r * 4 + wave] = __popcll(vb);
+    const unsigned long long m = match_lanes<NBITS>(band[r], ok[r]);
+    rk[r] = __popcll(m & lt);
+    if (ok[r] && rk[r] == 0) unit[(r * 4 + wave) * NB + band[r]] = __popcll(m);   // one writer per (unit, band)
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < NB; b += 256) {  // exclusive prefix over the 16 units, per band
+    int run = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = unit[u * NB + b];
+      unit[u * NB + b] = run;
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int u = 0; u < 16; ++u) { const int c = vcnt[u]; vcnt[u] = run; run += c; }
+  }
+  __syncthreads();
+  const int voff = a.off[((int64_t)s * ncol + NB) * a.nblk + blk];
+  const int seg0 = misc[0];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = blk * TILE + r * 256 + threadIdx.x;
+    if (n >= a.N) continue;
+    const int64_t flat = (int64_t)s * a.N + n;
+    if (!ok[r]) { a.cpos[flat] = -1; continue; }
+    const int u = r * 4 + wave;
+    // order-preserving compaction (the result dict's per-sample lists are row slices of these)
+    const int pos = voff + vcnt[u] + vrk[r];
+    const int cy = cxy[r] / g.gx, cx = cxy[r] - cy * g.gx;
+    const int64_t o = (int64_t)s * a.N + pos;
+    a.points_c[o * 3 + 0] = px[r]; a.points_c[o * 3 + 1] = py[r]; a.points_c[o * 3 + 2] = pz[r];
+    a.coords_c[o * 3 + 0] = 0; a.coords_c[o * 3 + 1] = cy; a.coords_c[o * 3 + 2] = cx;
+    a.idx_c[o] = n;
+    // centre = c * vs + min + vs / 2, three roundings, no contraction (DynamicVoxelizer._get_point_offsets)
+    const float ctx = __fadd_rn(__fadd_rn(__fmul_rn((float)cx, g.vx), g.minx), g.vx * 0.5f);
+    const float cty = __fadd_rn(__fadd_rn(__fmul_rn((float)cy, g.vy), g.miny), g.vy * 0.5f);
+    const float ctz = __fadd_rn(__fadd_rn(0.f, g.minz), g.vz * 0.5f);
+    a.offs_c[o * 3 + 0] = __fsub_rn(px[r], ctx);
+    a.offs_c[o * 3 + 1] = __fsub_rn(py[r], cty);
+    a.offs_c[o * 3 + 2] = __fsub_rn(pz[r], ctz);
+    a.cpos[flat] = pos;
+    // stable bucket position: sample segment + bucket start + tiles before + units before + lanes before
+    const int64_t d = (int64_t)seg0 + bstart[band[r]] + blkoff[band[r]] + unit[u * NB + band[r]] + rk[r];
+    a.bkey[d] = (uint32_t)(s * g.gy * g.gx + cxy[r]);
+    a.bidx[d] = (uint32_t)flat;
+    a.bpts[d * 3 + 0] = px[r]; a.bpts[d * 3 + 1] = py[r]; a.bpts[d * 3 + 2] = pz[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ band ----
+struct P2Band {
+  const uint32_t *in_key, *in_idx;   // bucketed (SORT) or already sorted (!SORT) arrays
+  const float* in_pts;
+  const int32_t* tot;
+  uint32_t *key_sorted, *idx_sorted;
+  float* pts_sorted;
+  int32_t* cell_rng;                 // optional [S*H*W][2]
+  const float *w_pfn, *bn_ss;
+  float* partial;                    // STATS: [S][NB][32][2]
+  df_img out;
+  int bn_stride, mode, S;
+};
+
+template <bool SORT, bool STATS, bool CANVAS>
+__global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
+  __shared__ int cnt[BAND_CELLS];     // points per cell of the band
+  __shared__ int pos0[BAND_CELLS];    // running / final END position of each cell's run, relative to the bucket
+  __shared__ int stage[CHUNK];        // cell of a bucket element -> its position after ranking
+  __shared__ float spts[CHUNK * 3];   // sorted points with bucket position < CHUNK (the rest is read back from L2)
+  __shared__ int misc[8];
+  __shared__ float red[STATS ? 256 * 8 : 1];
+  const df_pillar_geom& g = q.g;
+  const int band = blockIdx.x, s = blockIdx.y, NB = q.NB, ncol = NB + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = band * q.R, rows = min(q.R, g.gy - row0), ncb = rows * g.gx;
+  if (wave == 0) {
+    int v = 0;
+    for (int k = lane; k < s; k += 64) v += a.tot[(int64_t)k * ncol + NB];
+    for (int k = lane; k < band; k += 64) v += a.tot[(int64_t)s * ncol + k];
+    v = wave_sum(v);
+    if (lane == 0) { misc[0] = v; misc[1] = a.tot[(int64_t)s * ncol + band]; }
+  }
+  for (int i = threadIdx.x; i < ncb; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int64_t g0 = misc[0];
+  const int n = misc[1];
+  const uint32_t base_key = (uint32_t)((s * g.gy + row0) * g.gx);
+  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&cnt[a.in_key[g0 + i] - base_key], 1);
+  __syncthreads();
+  {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread)
+    const int c0 = threadIdx.x * (BAND_CELLS / 256);
+    int loc[BAND_CELLS / 256], sum = 0;
+#pragma unroll
+    for (int k = 0; k < BAND_CELLS / 256; ++k) { loc[k] = (c0 + k < ncb) ? cnt[c0 + k] : 0; sum += loc[k]; }
+    int wt;
+    int ex = wave_excl_scan(sum, lane, wt);
+    if (lane == 63) misc[2 + wave] = wt;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) ex += misc[2 + w];
+#pragma unroll
+    for (int k = 0; k < BAND_CELLS / 256; ++k) {
+      if (c0 + k < ncb) pos0[c0 + k] = SORT ? ex : ex + loc[k];   // !SORT: the run END right away
+      ex += loc[k];
+    }
+  }
+  __syncthreads();
+  float* __restrict__ op = CANVAS ? reinterpret_cast<float*>(a.out.ptr) + df_img_base(a.out, s) + (int64_t)row0 * g.gx * a.out.ld : nullptr;
+  const bool prefilled = SORT && CANVAS && n > 0;
+  if (SORT) {
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+      const int m = min(CHUNK, n - c0);
+      for (int i = threadIdx.x; i < m; i += 256) stage[i] = (int)(a.in_key[g0 + c0 + i] - base_key);
+      __syncthreads();
+      if (wave == 0) {
+        // stable ranks, 64 bucket elements at a time: position = run end of the cell so far + equal-cell lanes below
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int j0 = 0; j0 < m; j0 += 64) {
+          const int i = j0 + lane;
+          const bool v = i < m;
+          const int c = v ? stage[i] : 0;
+          const unsigned long long mk = match_lanes<11>(c, v);
+          const int basep = v ? pos0[c] : 0;
+          const int below = __popcll(mk & lt);
+          if (v) {
+            stage[i] = basep + below;
+            if ((mk >> lane) == 1ull) pos0[c] = basep + __popcll(mk);   // highest lane of the group advances the cell
+          }
+        }
+      } else if (CANVAS && c0 == 0) {
+        // meanwhile: zeros into the band's empty cells (128 B each, 8 lanes x 16 B), every byte of the canvas once
+        const int grp = (threadIdx.x - 64) >> 3, sub = threadIdx.x & 7;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = grp; c < ncb; c += 24)
+          if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * sub, z);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < m; i += 256) {
+        const int64_t src = g0 + c0 + i;
+        const int d = stage[i];
+        const float x = a.in_pts[src * 3 + 0], y = a.in_pts[src * 3 + 1], zc = a.in_pts[src * 3 + 2];
+        a.key_sorted[g0 + d] = a.in_key[src];
+        a.idx_sorted[g0 + d] = a.in_idx[src];
+        float* o = a.pts_sorted + (g0 + d) * 3;
+        o[0] = x; o[1] = y; o[2] = zc;
+        if (d < CHUNK) { spts[d * 3 + 0] = x; spts[d * 3 + 1] = y; spts[d * 3 + 2] = zc; }
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = threadIdx.x; i < min(n, CHUNK); i += 256) {
+      const float* p = a.in_pts + (g0 + i) * 3;
+      spts[i * 3 + 0] = p[0]; spts[i * 3 + 1] = p[1]; spts[i * 3 + 2] = p[2];
+    }
+    __syncthreads();
+  }
+  // ---- feature net over the band's cells: 8 lanes per cell, lane `sub` owns output channels 4*sub .. 4*sub+3
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const float* __restrict__ gpts = SORT ? a.pts_sorted : a.in_pts;
+  PfnCtx c;
+  pfn_load_w(c, a.w_pfn, sub);
+  if (CANVAS) pfn_load_bn(c, a.bn_ss + (int64_t)s * a.bn_stride, sub);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int cell = grp; cell < ncb; cell += 32) {
+    const int k = cnt[cell];
+    const int e = pos0[cell], b = e - k;
+    if (a.cell_rng && sub == 0) {
+      int32_t* cr = a.cell_rng + 2 * ((int64_t)base_key + cell);
+      cr[0] = k ? (int32_t)(g0 + b) : 0;
+      cr[1] = k ? (int32_t)(g0 + e) : 0;
+    }
+    if (k == 0) {
+      if (CANVAS && !prefilled) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
+      }
+      continue;
+    }
+    auto ld = [&](int i, float (&p)[3]) {
+      if (i < CHUNK) { p[0] = spts[i * 3]; p[1] = spts[i * 3 + 1]; p[2] = spts[i * 3 + 2]; }
+      else { const float* gq = gpts + (g0 + i) * 3; p[0] = gq[0]; p[1] = gq[1]; p[2] = gq[2]; }
+    };
+    float mx, my, mz, ctx, cty, ctz;
+    {  // pillar mean: plain left-to-right sums in input order, as pfn_mean (csrc/pillar_common.h) does
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (int i = b; i < e; ++i) { float p[3]; ld(i, p); sx += p[0]; sy += p[1]; sz += p[2]; }
+      const float inv = (float)k;
+      mx = sx / inv; my = sy / inv; mz = sz / inv;
+    }
+    pfn_centre(g, row0 * g.gx + cell, ctx, cty, ctz);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    for (int i = b; i < e; ++i) {
+      float p[3], f[9], u[4];
+      ld(i, p);
+      pfn_feat(p, mx, my, mz, ctx, cty, ctz, f);
+      pfn_linear(c, f, u);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (STATS) { acc[kk] += u[kk]; acc[4 + kk] += u[kk] * u[kk]; }
+        if (CANVAS) {
+          const float v = fmaxf(fmaf(u[kk], c.sc[kk], c.sh[kk]), 0.f);
+          if (a.mode == 0) r[kk] += v;
+          else r[kk] = (i == b) ? v : fmaxf(r[kk], v);
+        }
+      }
+    }
+    if (CANVAS) {
+      if (a.mode == 0) {
+        const float cntf = (float)k;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) r[kk] = r[kk] / cntf;
+      }
+      st4(op + (int64_t)cell * a.out.ld + 4 * sub, r);
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) red[kk * 256 + threadIdx.x] = acc[kk];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      for (int gi = 1; gi < 32; ++gi)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc[kk] += red[kk * 256 + gi * 8 + sub];
+      float* o = a.partial + (((int64_t)s * NB + band) * 32 + 4 * sub) * 2;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { o[kk * 2 + 0] = acc[kk]; o[kk * 2 + 1] = acc[4 + kk]; }
+    }
+  }
+}
+
+bool p2_geom(const df_pillar_geom& g, int rows_per_band, P2Geom& q) {
+  if (!(g.gx > 0 && g.gy > 0 && g.gz == 1 && g.vx > 0.f && g.vy > 0.f && g.vz > 0.f)) return false;
+  if (rows_per_band < 1 || (int64_t)rows_per_band * g.gx > BAND_CELLS) return false;
+  q.g = g; q.R = rows_per_band; q.NB = (g.gy + rows_per_band - 1) / rows_per_band;
+  return q.NB <= MAX_BANDS;
+}
+
+}  // namespace
+
+extern "C" int df_pillar2_rows_per_band(int H, int W) {
+  if (W <= 0 || H <= 0 || W > BAND_CELLS) return 0;
+  int r = BAND_CELLS / W;
+  while (r > 1 && (H + r - 1) / r < 8) r >>= 1;          // tiny grids: still a handful of bands
+  while ((H + r - 1) / r > MAX_BANDS) ++r;
+  return ((int64_t)r * W <= BAND_CELLS) ? r : 0;
+}
+
+extern "C" int df_pillar2_tile(void) { return TILE; }
+
+extern "C" int df_pillar2_hist(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, int32_t* hist,
+                               void* stream) {
+  P2Geom q;
+  DF_REQUIRE(pts && hist && S > 0 && N > 0, DF_E_ARG);
+  DF_REQUIRE(p2_geom(g, rows_per_band, q), DF_E_SHAPE);
+  const int nblk = (N + TILE - 1) / TILE;
+  hipLaunchKernelGGL(p2_hist_kernel, dim3(nblk, S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts, N, q, nblk, hist);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pillar2_scan(const int32_t* hist, int S, int ncol, int nblk, int32_t* off, int32_t* tot, int32_t* counts,
+                               void* stream) {
+  DF_REQUIRE(hist && off && tot && counts && S > 0 && ncol > 1 && nblk > 0, DF_E_ARG);
+  const int total = S * ncol;
+  hipLaunchKernelGGL(p2_scan_kernel, dim3((total + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), hist, total,
+                     ncol, nblk, off, tot, counts);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, const int32_t* off,
+                                  const int32_t* tot, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
+                                  int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, void* stream) {
+  P2Geom q;
+  DF_REQUIRE(pts && off && tot && points_c && coords_c && idx_c && offs_c && cpos && bkey && bidx && bpts && S > 0 && N > 0,
+             DF_E_ARG);
+  DF_REQUIRE(p2_geom(g, rows_per_band, q) && (int64_t)S * g.gx * g.gy < 0x7fffffffll && (int64_t)S * N < 0x7fffffffll, DF_E_SHAPE);
+  P2Scatter a;
+  a.pts = pts; a.off = off; a.tot = tot; a.points_c = points_c; a.coords_c = coords_c; a.idx_c = idx_c; a.offs_c = offs_c;
+  a.cpos = cpos; a.bkey = bkey; a.bidx = bidx; a.bpts = bpts; a.S = S; a.N = N; a.nblk = (N + TILE - 1) / TILE;
+  const size_t lds = (size_t)(18 * q.NB + 16 + 8) * sizeof(int);
+  const dim3 grid(a.nblk, S);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int bits = 1;
+  while ((1 << bits) < q.NB) ++bits;
+  if (bits <= 4) hipLaunchKernelGGL(p2_scatter_kernel<4>, grid, dim3(256), lds, st, a, q);
+  else if (bits <= 7) hipLaunchKernelGGL(p2_scatter_kernel<7>, grid, dim3(256), lds, st, a, q);
+  else hipLaunchKernelGGL(p2_scatter_kernel<9>, grid, dim3(256), lds, st, a, q);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
+                               int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
+                               const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
+                               uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial,
+                               void* stream) {
+  P2Geom q;
+  const bool sort = flags & 1, stats = flags & 2, canvas = flags & 4;
+  DF_REQUIRE(in_key && in_pts && tot && w_pfn && S > 0 && (mode == 0 || mode == 1), DF_E_ARG);
+  DF_REQUIRE(p2_geom(g, rows_per_band, q), DF_E_SHAPE);
+  DF_REQUIRE((sort && !canvas && stats) || (sort && canvas && !stats) || (!sort && canvas && !stats), DF_E_ARG);
+  if (sort) DF_REQUIRE(in_idx && key_sorted && idx_sorted && pts_sorted, DF_E_ARG);
+  if (stats) DF_REQUIRE(stats_partial, DF_E_ARG);
+  if (canvas) {
+    DF_REQUIRE(bn_ss && out.ptr, DF_E_ARG);
+    DF_REQUIRE(out.n == S && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr), DF_E_SHAPE);
+  }
+  P2Band a;
+  a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
+  a.pts_sorted = pts_sorted; a.cell_rng = cell_rng; a.w_pfn = w_pfn; a.bn_ss = bn_ss; a.partial = stats_partial; a.out = out;
+  a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S;
+  const dim3 grid(q.NB, S);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sort && canvas) hipLaunchKernelGGL((p2_band_kernel<true, false, true>), grid, dim3(256), 0, st, a, q);
+  else if (sort) hipLaunchKernelGGL((p2_band_kernel<true, true, false>), grid, dim3(256), 0, st, a, q);
+  else hipLaunchKernelGGL((p2_band_kernel<false, false, true>), grid, dim3(256), 0, st, a, q);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}

@@ -18,7 +18,7 @@ from . import ops
 from ._lib import DfImg, call, img, ptr, stream
 from .autograd import DeFlowFn
 from .decoder import ConvGRUDecoder, LinearDecoder, PointSet
-from .encoder import DynamicEmbedder
+from .encoder import DynamicEmbedder, canvas_alloc
 from .timer import Timing
 from .unet import FastFlow3DUNet
 
@@ -60,19 +60,19 @@ class DeFlow(nn.Module):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device
-        with ops.timed("canvas_zero_fill"):   # part of the pillarise stage's time; its bytes are counted in pillarise_fwd
-            bstar = torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev)  # streaming zero-fill; pillars overwrite
+        with ops.timed("canvas_zero_fill"):   # (first-generation pillariser only: the band pipeline writes its own zeros)
+            bstar = canvas_alloc(B, emb.H, emb.W, 64, device=dev)
         self.timer[1].start("Voxelization")
         if not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0":
             # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
             # samples writing the two channel halves of bstar -- half the launches of the ~15-kernel pipeline, which is
             # what a B = 1 forward spends there.  Same arithmetic sample by sample (BatchNorm statistics are per sample).
             both = emb.pillarize(torch.cat([pc0s, pc1s], 0), DfImg(bstar.data_ptr(), 2 * B, emb.H, emb.W, 32, 64, B,
-                                                                  bstar.stride(0), 32), train)
+                                                                  bstar.stride(0), 32), train, need_cells=False)
             p0, p1 = both.split(B)
         else:
-            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train)
-            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train)
+            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save)
+            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save)
         self.timer[1].stop()
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None

@@ -6,6 +6,7 @@ keys follow the upstream module tree (``feature_net.pfn_layers.0.{0,1}.*``).  Al
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -14,6 +15,14 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import DfGeom, DfImg, call, img, ptr, stream
+
+
+def canvas_alloc(*shape, device) -> torch.Tensor:
+    """canvas buffer for pillarize(): the band pipeline writes every byte itself; the first generation (DF_PILLAR_V1=1) writes
+    occupied cells only and needs the zero fill"""
+    if os.environ.get("DF_PILLAR_V1") == "1":
+        return torch.zeros(*shape, dtype=torch.float32, device=device)
+    return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
 def make_geom(voxel_size, point_cloud_range) -> DfGeom:
@@ -48,13 +57,14 @@ class PillarState:
         starts at a device-side offset) stay whole in the first half and are dropped from the second -- only the
         tape-less forward uses merged sets, and it reads them for the first cloud alone."""
         N = self.pts.shape[1]
-        nc = self.cell_rng.shape[0] // 2
+        nc = 0 if self.cell_rng is None else self.cell_rng.shape[0] // 2
         per = self.bn_stride != 0
+        cr = self.cell_rng
         a = PillarState(self.pts[:B], self.counts[:B], self.points_c[:B], self.coords_c[:B], self.idx_c[:B], self.offs_c[:B],
-                        self.cpos[:B * N], self.idx_sorted, self.cell_rng[:nc], self.key_sorted, self.pts_sorted,
+                        self.cpos[:B * N], self.idx_sorted, None if cr is None else cr[:nc], self.key_sorted, self.pts_sorted,
                         self.bn_ss[:B] if per else self.bn_ss, self.bn_stride)
         b = PillarState(self.pts[B:], self.counts[B:], self.points_c[B:], self.coords_c[B:], self.idx_c[B:], self.offs_c[B:],
-                        self.cpos[B * N:], None, self.cell_rng[nc:], None, None,
+                        self.cpos[B * N:], None, None if cr is None else cr[nc:], None, None,
                         self.bn_ss[B:] if per else self.bn_ss, self.bn_stride)
         return a, b
 
@@ -91,18 +101,90 @@ class DynamicEmbedder(nn.Module):
         return self.feature_net.pfn_layers[0][1]
 
     # -- engine ------------------------------------------------------------------------------
-    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
-        """pts [B,N,3] f32 contiguous on the GPU; writes the occupied cells of the ZERO-FILLED [B,H,W,32] canvas `out`."""
+    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool = True) -> PillarState:
+        """pts [B,N,3] f32 contiguous on the GPU; writes the WHOLE [B,H,W,32] canvas `out` (zeros included: the canvas needs no
+        prior fill).  need_cells: also leave the dense per-cell [start, end) table the backward kernels read."""
         B, N, _ = pts.shape
         # algorithmic traffic of the stage (SURVEY 8(d)): the points once in, the dense 32-channel canvas once out
         with ops.timed("pillarise_fwd", bytes=B * (N * 12.0 + 32.0 * self.H * self.W * 4.0), tag=f"B={B} N={N}"):
-            return self._pillarize(pts, out, train)
+            if os.environ.get("DF_PILLAR_V1") == "1":
+                return self._pillarize_v1(pts, out, train)
+            return self._pillarize(pts, out, train, need_cells)
 
-    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
+    def _bn_state(self, train: bool, partial, counts, B: int, nbs: int, dev):
+        """-> (bn_ss, bn_stride): per-sample batch statistics (training; running statistics updated) or the folded running ones"""
+        bn, s = self._bn, stream()
+        if train:
+            if ops.SYNC is not None:
+                bn_ss = self._sync_bn_stats(partial, counts)
+            else:
+                bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
+                call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                     bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
+            bn.num_batches_tracked.add_(B)
+            ops.PARAM_GEN[0] += 1
+            return bn_ss, 128
+        c = getattr(bn, "_df_fold_ss", None)
+        fold = ops.folded_bn(bn)
+        if c is None or c[0] is not fold[0]:   # re-stack only when the fold was recomputed
+            c = (fold[0], torch.stack(list(fold)).contiguous())
+            bn._df_fold_ss = c
+        return c[1], 0
+
+    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool) -> PillarState:
+        """Band-bucketed pipeline (csrc/pillar_bands.hip): hist -> scan -> scatter -> band (4 launches; training 6)."""
+        assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
+        S, N, _ = pts.shape
+        dev, g, s = pts.device, self.geom, stream()
+        H, W = self.H, self.W
+        R = call("df_pillar2_rows_per_band", H, W)
+        if R <= 0:
+            raise RuntimeError(f"pillarise: a {H}x{W} grid is not supported (rows wider than 2048 cells)")
+        NB = (H + R - 1) // R
+        ncol = NB + 1
+        nblk = (N + call("df_pillar2_tile") - 1) // call("df_pillar2_tile")
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        hist = torch.empty(S, ncol, nblk, **i32)
+        off = torch.empty(S, ncol, nblk, **i32)
+        tot = torch.empty(S, ncol, **i32)
+        counts = torch.empty(S, **i32)
+        call("df_pillar2_hist", ptr(pts), S, N, g, R, ptr(hist), s)
+        call("df_pillar2_scan", ptr(hist), S, ncol, nblk, ptr(off), ptr(tot), ptr(counts), s)
+        points_c = torch.empty(S, N, 3, **f32)
+        coords_c = torch.empty(S, N, 3, **i32)
+        idx_c = torch.empty(S, N, dtype=torch.int64, device=dev)
+        offs_c = torch.empty(S, N, 3, **f32)
+        cpos = torch.empty(S * N, **i32)
+        bkey, bidx, bpts = torch.empty(S * N, **i32), torch.empty(S * N, **i32), torch.empty(S * N, 3, **f32)
+        call("df_pillar2_scatter", ptr(pts), S, N, g, R, ptr(off), ptr(tot), ptr(points_c), ptr(coords_c), ptr(idx_c), ptr(offs_c),
+             ptr(cpos), ptr(bkey), ptr(bidx), ptr(bpts), s)
+        key_sorted, idx_sorted, pts_sorted = torch.empty(S * N, **i32), torch.empty(S * N, **i32), torch.empty(S * N, 3, **f32)
+        cell_rng = torch.empty(S * H * W, 2, **i32) if need_cells else None
+        w = self._lin.weight.detach()
+        SORT, STATS, CANVAS = 1, 2, 4
+        if train:
+            partial = torch.empty(S, NB, 32, 2, **f32)
+            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), S, g, R, SORT | STATS, ptr(w), None, 0, self.mode, out,
+                 ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), None, ptr(partial), s)
+            bn_ss, bn_stride = self._bn_state(True, partial, counts, S, NB, dev)
+            call("df_pillar2_band", ptr(key_sorted), None, ptr(pts_sorted), ptr(tot), S, g, R, CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+                 self.mode, out, None, None, None, ptr(cell_rng), None, s)
+        else:
+            bn_ss, bn_stride = self._bn_state(False, None, counts, S, NB, dev)
+            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), S, g, R, SORT | CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+                 self.mode, out, ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), ptr(cell_rng), None, s)
+        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss,
+                           bn_stride)
+
+    def _pillarize_v1(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
+        """First generation (csrc/pillarize.hip; DF_PILLAR_V1=1, tested alternate): keys -> scan -> compact -> library radix sort
+        -> gather -> cell table -> (statistics) -> canvas over occupied pillars of a canvas zeroed here."""
         assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
         B, N, _ = pts.shape
         dev, g, s = pts.device, self.geom, stream()
         H, W = self.H, self.W
+        # this generation writes occupied cells only: the caller allocates the canvas with canvas_alloc() (zero-filled)
         nblk = (N + 255) // 256
         i32 = dict(dtype=torch.int32, device=dev)
         key = torch.empty(B * N, **i32)
@@ -130,28 +212,12 @@ class DynamicEmbedder(nn.Module):
         cell_rng = torch.zeros(ncells, 2, **i32)
         call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), s)
         w = self._lin.weight.detach()
-        bn = self._bn
+        partial = None
+        nbs = max(1, min(256, (N + 31) // 32))
         if train:
-            nbs = max(1, min(256, (N + 31) // 32))
             partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
             call("df_pfn_stats", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
-            if ops.SYNC is not None:
-                bn_ss = self._sync_bn_stats(partial, counts)
-            else:
-                bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
-                call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
-                     bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
-            bn.num_batches_tracked.add_(B)
-            ops.PARAM_GEN[0] += 1
-            bn_stride = 128
-        else:
-            c = getattr(bn, "_df_fold_ss", None)
-            fold = ops.folded_bn(bn)
-            if c is None or c[0] is not fold[0]:   # re-stack only when the fold was recomputed
-                c = (fold[0], torch.stack(list(fold)).contiguous())
-                bn._df_fold_ss = c
-            bn_ss = c[1]
-            bn_stride = 0
+        bn_ss, bn_stride = self._bn_state(train, partial, counts, B, nbs, dev)
         nbc = max(1, min(2048, (N + 31) // 32))
         call("df_pfn_canvas", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
              out, nbc, s)
@@ -220,8 +286,8 @@ class DynamicEmbedder(nn.Module):
     def forward(self, points: torch.Tensor):
         pts = points.contiguous().float()
         B = pts.shape[0]
-        canvas = torch.zeros(B, self.H, self.W, 32, dtype=torch.float32, device=pts.device)
+        canvas = canvas_alloc(B, self.H, self.W, 32, device=pts.device)
         with torch.no_grad():
-            st = self.pillarize(pts, img(canvas), self.training)
+            st = self.pillarize(pts, img(canvas), self.training, need_cells=False)
         infos = self.infos_from_state(st, st.counts.tolist())
         return canvas.permute(0, 3, 1, 2), infos

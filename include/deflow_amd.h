@@ -49,7 +49,37 @@ typedef struct df_pillar_geom {
   int32_t gx, gy, gz;        /* grid = round((max-min)/v); gz must be 1 (pillars)          */
 } df_pillar_geom;
 
-/* step 1: per point voxel coords / validity / sort key; per-256-point-block valid counts.
+/* ---- second generation (csrc/pillar_bands.hip): the path DynamicEmbedder takes.  The grid is cut into bands of R rows
+ * (R * gx <= 2048 cells, df_pillar2_rows_per_band); points are bucketed by (sample, band) with a stable counting sort over
+ * 1024-point tiles (hist -> scan -> scatter) and each band's workgroup finishes the sort by cell in LDS, runs the feature
+ * net and writes its slice of the canvas -- zeros included, every byte once; no separate zero-fill, no library sort.
+ * S = number of cloud samples in this call (B, or 2B when both clouds are pillarised together), NB = ceil(gy / R),
+ * nblk = ceil(N / df_pillar2_tile()).  Sorted layout = first generation: sample s owns sorted positions
+ * [sum counts[0..s), + counts[s]), ascending cell key, input order inside a cell; positions past the last valid point are
+ * not written. */
+int df_pillar2_rows_per_band(int H, int W);   /* 0 if the grid is not supported (W > 2048) */
+int df_pillar2_tile(void);
+/* hist [S, NB+1, nblk] i32: points of each tile per band; column NB = valid points of the tile */
+int df_pillar2_hist(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, int32_t* hist, void* stream);
+/* off (shape of hist): exclusive scan over the tiles of every (sample, column); tot [S, NB+1]; counts [S] = valid points */
+int df_pillar2_scan(const int32_t* hist, int S, int ncol, int nblk, int32_t* off, int32_t* tot, int32_t* counts,
+                    void* stream);
+/* order-preserving compaction (shapes as df_pillar_compact) + bucketed key [S*N] u32 / flat index [S*N] u32 / xyz [S*N,3] */
+int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, const int32_t* off,
+                       const int32_t* tot, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
+                       int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, void* stream);
+/* flags: 1 = sort (inputs are the bucketed arrays; writes key_sorted / idx_sorted / pts_sorted), 2 = BatchNorm1d batch
+ * statistics partials [S, NB, 32, 2] (finalise with df_pfn_bn_finalize, nblk_stat = NB), 4 = canvas (writes ALL of
+ * out [S, gy, gx, 32]).  Valid: 1|4 (inference), 1|2 then 4 (training; the second call takes the SORTED arrays as inputs).
+ * cell_rng: optional dense [S*gy*gx, 2] table of sorted [start, end) per cell (written completely). */
+int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot, int S,
+                    df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn, const float* bn_ss,
+                    int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted, uint32_t* idx_sorted,
+                    float* pts_sorted, int32_t* cell_rng, float* stats_partial, void* stream);
+
+/* ---- first generation (csrc/pillarize.hip): kept for the stand-alone decoder-head API (arbitrary voxel_coords) and as
+ * the tested alternate DF_PILLAR_V1=1.
+ * step 1: per point voxel coords / validity / sort key; per-256-point-block valid counts.
  * pts [B,N,3] f32 (NaN rows = padding).  key [B*N] u32 = b*gy*gx + y*gx + x, or B*gy*gx if dropped.
  * blk_cnt [B, ceil(N/256)] i32. */
 int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt, void* stream);
@@ -149,6 +179,12 @@ int df_sparse_in_wgrad(const uint32_t* key_sorted, const int32_t* counts, int B,
 int df_conv2d(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
               int mode, int epi, const float* scale, const float* shift, float* stats_partial,
               int accumulate, void* stream);
+/* Mixed-precision form (training with BASELINE configs[4]'s "bf16 MFMA"): mfma_bf16 != 0 rounds both MFMA operands to bf16
+ * as they leave LDS (v_cvt_pk_bf16_f32, round to nearest even) and multiplies on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation; every tensor stays fp32 in memory, epilogues unchanged.  mfma_bf16 == 0 is df_conv2d. */
+int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
+                 int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                 int accumulate, int mfma_bf16, void* stream);
 int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick for DF_EPI_STATS */
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);
@@ -188,6 +224,8 @@ int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride);
  * the kernel stages anyway (sum its rows with df_colsum_finalize). */
 int df_conv2d_wgrad(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
                     const int32_t* row_counts, int rows_per_seg, float* bias_ws, void* stream);
+int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits,
+                       const int32_t* row_counts, int rows_per_seg, float* bias_ws, int mfma_bf16, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
 /* bf16 inference convolution (BASELINE configs[4], "bf16 MFMA"): x, w bf16 (NHWC / [Cout,kh,kw,Cin]), fp32 accumulation on

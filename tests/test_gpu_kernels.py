@@ -191,7 +191,7 @@ def test_convwithnorms_train_fwd_bwd(dev, groups):
     check(f"cwn train fwd g{groups}", nchw(z), want)
     check("running_mean", mine.batchnorm.running_mean, ref.batchnorm.running_mean)
     check("running_var", mine.batchnorm.running_var, ref.batchnorm.running_var)
-    _, m, xi, y, bn_ss, ipg_, groups_ = tape[0]
+    _, m, xi, y, bn_ss, ipg_, groups_, _frozen = tape[0]
     dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(nhwc(gz).to(dev)), y, bn_ss, ipg_, groups_)
     wd = ops.ohwi(mine.conv.weight)
     dx = torch.empty_like(xd)
@@ -281,6 +281,100 @@ def test_pillarize_vs_oracle(dev, train):
     if train:
         check("bn1d running_mean", mine._bn.running_mean, bn.running_mean)
         check("bn1d running_var", mine._bn.running_var, bn.running_var)
+
+
+def _pillar_case(dev, monkeypatch, pts, grid, ext, train, mode="avg", merged_img=False):
+    """run both pillariser generations on the same cloud set; -> (state, canvas) of each"""
+    from deflow_amd.encoder import DynamicEmbedder
+    from deflow_amd._lib import DfImg, img
+    vs, rng, dims = [2 * ext / grid, 2 * ext / grid, 6], [-ext, -ext, -3, ext, ext, 3], [grid, grid]
+    out = []
+    for v1 in (False, True):
+        if v1:
+            monkeypatch.setenv("DF_PILLAR_V1", "1")
+        else:
+            monkeypatch.delenv("DF_PILLAR_V1", raising=False)
+        torch.manual_seed(5)
+        emb = DynamicEmbedder(vs, dims, rng, 32, mode=mode)
+        with torch.no_grad():
+            emb._bn.weight.uniform_(0.5, 1.5); emb._bn.bias.uniform_(-0.2, 0.2)
+            emb._bn.running_mean.uniform_(-1, 1); emb._bn.running_var.uniform_(0.5, 2)
+        emb = emb.to(dev).train(train)
+        S = pts.shape[0]
+        if merged_img:   # S = 2B samples writing the two 32-channel halves of one [B,H,W,64] buffer (the tape-less forward)
+            B = S // 2
+            buf = torch.full((B, grid, grid, 64), float("nan"), device=dev) if not v1 else torch.zeros(B, grid, grid, 64, device=dev)
+            d = DfImg(buf.data_ptr(), S, grid, grid, 32, 64, B, buf.stride(0), 32)
+            canvas = buf
+        else:            # NaN-poisoned: the band pipeline must write every byte itself
+            canvas = torch.full((S, grid, grid, 32), float("nan"), device=dev) if not v1 else torch.zeros(S, grid, grid, 32, device=dev)
+            d = img(canvas)
+        with torch.no_grad():
+            st = emb.pillarize(pts.to(dev), d, train)
+        torch.cuda.synchronize()
+        out.append((st, canvas, emb))
+    monkeypatch.delenv("DF_PILLAR_V1", raising=False)
+    return out
+
+
+PILLAR_CASES = [  # S, N, grid, extent
+    (3, 700, 64, 6.4), (2, 20000, 256, 25.6), (2, 80000, 512, 51.2), (1, 160000, 1024, 51.2), (5, 1023, 64, 6.4), (1, 1025, 128, 12.8),
+]
+
+
+@pytest.mark.parametrize("S,N,grid,ext", PILLAR_CASES)
+@pytest.mark.parametrize("train", [False, True])
+def test_pillar_bands_equal_first_generation(dev, monkeypatch, S, N, grid, ext, train):
+    """the band-bucketed pipeline (hist / scan / scatter / band: in-tree stable counting sort, LDS cell sort, fused canvas incl.
+    its zeros) against the first generation (library radix sort + separate kernels): identical integer outputs (compaction,
+    sorted keys / indices / cell table), identical sorted points, and the same canvas -- bit for bit in eval mode (same
+    arithmetic in the same order), to fp32 rounding of the batch statistics in training mode; no canvas byte left unwritten."""
+    pts = _cloud(S, N, 1000 + N, ext)
+    (s2, c2, e2), (s1, c1, e1) = _pillar_case(dev, monkeypatch, pts, grid, ext, train)
+    assert torch.equal(s2.counts, s1.counts)
+    tot = int(s1.counts.sum())
+    for name in ("points_c", "coords_c", "idx_c", "offs_c"):
+        a, b = getattr(s2, name), getattr(s1, name)
+        for k in range(S):
+            m = int(s1.counts[k])
+            assert torch.equal(a[k, :m], b[k, :m]), (name, k)
+    assert torch.equal(s2.cpos, s1.cpos)
+    assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
+    assert torch.equal(s2.pts_sorted[:tot], s1.pts_sorted[:tot])
+    assert torch.equal(s2.cell_rng, s1.cell_rng)
+    assert torch.isfinite(c2).all(), "every canvas byte must be written (zeros included)"
+    if train:
+        check("band canvas (train)", c2, c1, 1e-5)
+        check("band running_mean", e2._bn.running_mean, e1._bn.running_mean, 1e-6)
+        check("band running_var", e2._bn.running_var, e1._bn.running_var, 1e-6)
+    else:
+        assert torch.equal(c2, c1)
+
+
+def test_pillar_bands_degenerate_clouds(dev, monkeypatch):
+    """buckets far beyond the LDS chunk (5000 points in ONE cell, 3000 in one row), an all-NaN sample, a sample with a
+    single point, max mode, and the merged two-cloud image layout"""
+    g = torch.Generator().manual_seed(3)
+    S, N = 4, 6000
+    pts = torch.full((S, N, 3), float("nan"))
+    pts[0, :5000] = torch.tensor([1.01, -2.03, 0.5]) + torch.rand(5000, 3, generator=g) * torch.tensor([0.09, 0.09, 1.0])   # one cell
+    pts[0, 5000:5600] = torch.rand(600, 3, generator=g) * torch.tensor([12.0, 12.0, 5.0]) - torch.tensor([6.0, 6.0, 2.5])
+    pts[1, :3000, 0] = torch.rand(3000, generator=g) * 12.6 - 6.3       # one row of cells
+    pts[1, :3000, 1] = 0.05
+    pts[1, :3000, 2] = 0.0
+    pts[3, 17] = torch.tensor([0.1, 0.1, 0.1])                          # sample 2 stays all NaN, sample 3 has one point
+    for mode in ("avg", "max"):
+        for train in (False, True):
+            (s2, c2, _), (s1, c1, _) = _pillar_case(dev, monkeypatch, pts, 64, 6.4, train, mode=mode, merged_img=True)
+            tot = int(s1.counts.sum())
+            assert s1.counts.tolist() == s2.counts.tolist() and s1.counts.tolist()[2] == 0 and s1.counts.tolist()[3] == 1
+            assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
+            assert torch.equal(s2.cell_rng, s1.cell_rng)
+            assert torch.isfinite(c2).all()
+            if train:
+                check(f"degenerate canvas {mode} train", c2, c1, 1e-5)
+            else:
+                assert torch.equal(c2, c1), mode
 
 
 def test_pillarize_backward(dev):

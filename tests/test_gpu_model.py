@@ -466,7 +466,10 @@ def test_bf16_configs4_shape_vs_oracle(dev):
     mine = mine.to(dev).eval()
     ref.eval()
     p = synth_pair(77, 160000)
-    batch = {"pc0": p[0][None], "pc1": p[1][None], "pose0": torch.eye(4)[None], "pose1": torch.linalg.inv(p[2])[None]}
+    # ego_motion given directly: inverting pose1 on the host vs on the device differs in the last bit, and with 160 000
+    # points on 0.1 m cells that is enough to move a point across a cell edge
+    batch = {"pc0": p[0][None], "pc1": p[1][None], "pose0": torch.eye(4)[None], "pose1": torch.linalg.inv(p[2])[None],
+             "ego_motion": p[2][None]}
     with torch.no_grad():
         want = ref(batch)
         got32 = mine(to_dev(batch, dev))
