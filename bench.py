@@ -297,6 +297,21 @@ def main():
         entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = one read of the three gate-gradient planes + h|x rows per step")
         out["roofline_hbm"] = hbm
 
+    if not args.no_extras:
+        # BASELINE configs[4] names "bf16 MFMA": the same training step with the UNet convolutions (forward, data gradient,
+        # weight gradient) on bf16 MFMA operands, fp32 accumulation, fp32 tensors / master weights (Trainer(dtype="bf16")).
+        # Timed AFTER and reported BESIDE the fp32 headline, never instead of it.  (With N > 1 the gradient collectives are off
+        # at this point -- see allreduce_exposed_ms -- so the block is only emitted on one GPU.)
+        if world == 1:
+            trainer.mfma_bf16 = True
+            for _ in range(2):
+                trainer.step(batch)
+            dtb, _, lossb = timed_steps(args.steps)
+            trainer.mfma_bf16 = False
+            out["bf16_training"] = {"workload": "the headline step with dtype=bf16 (bf16 MFMA operands in every UNet conv fwd/dgrad/wgrad, "
+                                                "fp32 accumulate, fp32 tensors + master weights + decoder)",
+                                    "ms_per_step": dtb / args.steps * 1e3, "pairs_per_s": args.batch * args.steps / dtb,
+                                    "speedup_vs_fp32": dt / dtb, "loss": float(lossb)}
     if world == 1 and not args.no_extras:
         # forward-only pairs/s of BASELINE configs[1] (one 80k-point pair, eval mode) beside the headline
         def time_forward(m, b, reps):
@@ -319,6 +334,18 @@ def main():
                                "frac_mfma_f32": 391.6e9 / (fwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         fwd16 = time_forward(model, batch, 10)
         out["forward_only"]["b16_ms_per_pair"] = fwd16 / args.batch
+        # the pillarise stage of that B = 16 inference forward (both clouds as one 32-sample set) against the HBM roof
+        ops.PROFILER = pp = ops.KernelProfiler()
+        time_forward(model, batch, 5)
+        ops.PROFILER = None
+        ps_ = pp.summary().get("pillarise_fwd")
+        if ps_ and "roofline_hbm" in out:
+            ms_pair = ps_["ms"] / ps_["launches"] / args.batch
+            out["roofline_hbm"]["pillarise_fwd_inference_b16"] = {
+                "us_per_pair": ms_pair * 1e3, "algorithmic_mb_per_pair": ps_["bytes"] / ps_["launches"] / args.batch / 1e6,
+                "achieved_gbps": ps_["bytes"] / (ps_["ms"] * 1e-3) / 1e9, "peak_gbps": PEAK_HBM_GBPS,
+                "frac": ps_["bytes"] / (ps_["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                "note": "eval forward, B=16: hist + scan + scatter + band (4 launches for both clouds), canvas zeros included"}
         model.inference_dtype = "bf16"
         f16 = time_forward(model, b1, 20)
         out["forward_only"]["bf16_ms_per_pair"] = f16

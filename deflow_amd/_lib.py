@@ -50,8 +50,8 @@ _SIGS = {
     "df_pillar2_tile": [],
     "df_pillar2_hist": [P, I, I, DfGeom, I, P, P],
     "df_pillar2_scan": [P, I, I, I, P, P, P, P],
-    "df_pillar2_scatter": [P, I, I, DfGeom, I, P, P, P, P, P, P, P, P, P, P, P],
-    "df_pillar2_band": [P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P],
+    "df_pillar2_scatter": [P, I, I, DfGeom, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "df_pillar2_band": [P, P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P],
     "df_pfn_stats": [P, P, P, P, I, DfGeom, P, P, I, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
     "df_pfn_canvas": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],

@@ -30,7 +30,7 @@ namespace {
 constexpr int TILE = 1024;        // points per workgroup in hist / scatter (4 rounds x 256 threads)
 constexpr int MAX_BANDS = 512;    // LDS tables in hist / scatter
 constexpr int BAND_CELLS = 2048;  // max cells per band (LDS cell tables of the band kernel)
-constexpr int CHUNK = 2048;       // bucket elements ranked / staged per round of the band kernel
+constexpr int CHUNK = 1024;       // bucket elements ranked / staged per round of the band kernel (4 per thread)
 
 struct P2Geom {
   df_pillar_geom g;
@@ -124,6 +124,7 @@ struct P2Scatter {
   int32_t* cpos;
   uint32_t *bkey, *bidx;
   float* bpts;
+  int32_t* bucket0;   // [S][NB] absolute sorted position of every bucket's first element (written by tile 0 of each sample)
   int S, N, nblk;
 };
 
@@ -197,6 +198,8 @@ __global__ __launch_bounds__(256) void p2_scatter_kernel(P2Scatter a, P2Geom q) 
   __syncthreads();
   const int voff = a.off[((int64_t)s * ncol + NB) * a.nblk + blk];
   const int seg0 = misc[0];
+  if (blk == 0)
+    for (int i = threadIdx.x; i < NB; i += 256) a.bucket0[(int64_t)s * NB + i] = seg0 + bstart[i];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = blk * TILE + r * 256 + threadIdx.x;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void p2_scatter_kernel(P2Scatter a, P2Geom q) 
 struct P2Band {
   const uint32_t *in_key, *in_idx;   // bucketed (SORT) or already sorted (!SORT) arrays
   const float* in_pts;
-  const int32_t* tot;
+  const int32_t *tot, *bucket0;
   uint32_t *key_sorted, *idx_sorted;
   float* pts_sorted;
   int32_t* cell_rng;                 // optional [S*H*W][2]
@@ -247,36 +250,57 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   __shared__ int pos0[BAND_CELLS];    // running / final END position of each cell's run, relative to the bucket
   __shared__ int stage[CHUNK];        // cell of a bucket element -> its position after ranking
   __shared__ float spts[CHUNK * 3];   // sorted points with bucket position < CHUNK (the rest is read back from L2)
-  __shared__ int misc[8];
-  __shared__ float red[STATS ? 256 * 8 : 1];
+  __shared__ int misc[12];
+  static_assert(CHUNK * 3 >= 256 * 8, "the statistics reduction reuses the point image");
+  float* red = spts;
   const df_pillar_geom& g = q.g;
   const int band = blockIdx.x, s = blockIdx.y, NB = q.NB, ncol = NB + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = band * q.R, rows = min(q.R, g.gy - row0), ncb = rows * g.gx;
-  if (wave == 0) {
-    int v = 0;
-    for (int k = lane; k < s; k += 64) v += a.tot[(int64_t)k * ncol + NB];
-    for (int k = lane; k < band; k += 64) v += a.tot[(int64_t)s * ncol + k];
-    v = wave_sum(v);
-    if (lane == 0) { misc[0] = v; misc[1] = a.tot[(int64_t)s * ncol + band]; }
-  }
   for (int i = threadIdx.x; i < ncb; i += 256) cnt[i] = 0;
   __syncthreads();
-  const int64_t g0 = misc[0];
-  const int n = misc[1];
+  const int64_t g0 = a.bucket0[(int64_t)s * NB + band];   // wave-uniform scalar loads
+  const int n = a.tot[(int64_t)s * ncol + band];
   const uint32_t base_key = (uint32_t)((s * g.gy + row0) * g.gx);
-  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&cnt[a.in_key[g0 + i] - base_key], 1);
-  __syncthreads();
-  {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread)
-    const int c0 = threadIdx.x * (BAND_CELLS / 256);
-    int loc[BAND_CELLS / 256], sum = 0;
+  // this thread's share of the first CHUNK bucket elements stays in registers from here to the permuted copy: one global
+  // round trip feeds the histogram, the ranking and the copy (buckets beyond CHUNK elements take the slower loop below)
+  constexpr int EPT = CHUNK / 256;
+  int kreg[EPT];
+  uint32_t ireg[EPT];
+  float xreg[EPT][3];
+  const int m0 = min(n, CHUNK);
 #pragma unroll
-    for (int k = 0; k < BAND_CELLS / 256; ++k) { loc[k] = (c0 + k < ncb) ? cnt[c0 + k] : 0; sum += loc[k]; }
-    int wt;
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    kreg[e] = -1;
+    if (i < m0) {
+      kreg[e] = (int)(a.in_key[g0 + i] - base_key);
+      const float* pp = a.in_pts + (g0 + i) * 3;
+      xreg[e][0] = pp[0]; xreg[e][1] = pp[1]; xreg[e][2] = pp[2];
+      if (SORT) ireg[e] = a.in_idx[g0 + i];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e)
+    if (kreg[e] >= 0) atomicAdd(&cnt[kreg[e]], 1);
+  for (int i = CHUNK + threadIdx.x; i < n; i += 256) atomicAdd(&cnt[a.in_key[g0 + i] - base_key], 1);
+  __syncthreads();
+  int occ_ex, occ_mask = 0;   // this thread's 8 cells: number of occupied cells before them / which of them are occupied
+  {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread), and of the occupancy flags -> occupied-cell list
+    const int c0 = threadIdx.x * (BAND_CELLS / 256);
+    int loc[BAND_CELLS / 256], sum = 0, nocc = 0;
+#pragma unroll
+    for (int k = 0; k < BAND_CELLS / 256; ++k) {
+      loc[k] = (c0 + k < ncb) ? cnt[c0 + k] : 0;
+      sum += loc[k];
+      if (loc[k] > 0) { ++nocc; occ_mask |= 1 << k; }
+    }
+    int wt, wo;
     int ex = wave_excl_scan(sum, lane, wt);
-    if (lane == 63) misc[2 + wave] = wt;
+    occ_ex = wave_excl_scan(nocc, lane, wo);
+    if (lane == 63) { misc[2 + wave] = wt; misc[8 + wave] = wo; }
     __syncthreads();
-    for (int w = 0; w < wave; ++w) ex += misc[2 + w];
+    for (int w = 0; w < wave; ++w) { ex += misc[2 + w]; occ_ex += misc[8 + w]; }
 #pragma unroll
     for (int k = 0; k < BAND_CELLS / 256; ++k) {
       if (c0 + k < ncb) pos0[c0 + k] = SORT ? ex : ex + loc[k];   // !SORT: the run END right away
@@ -284,12 +308,28 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     }
   }
   __syncthreads();
+  const int n_occ = misc[8] + misc[9] + misc[10] + misc[11];
   float* __restrict__ op = CANVAS ? reinterpret_cast<float*>(a.out.ptr) + df_img_base(a.out, s) + (int64_t)row0 * g.gx * a.out.ld : nullptr;
   const bool prefilled = SORT && CANVAS && n > 0;
   if (SORT) {
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
       const int m = min(CHUNK, n - c0);
-      for (int i = threadIdx.x; i < m; i += 256) stage[i] = (int)(a.in_key[g0 + c0 + i] - base_key);
+      if (c0 > 0) {   // rare: a bucket beyond CHUNK elements -- refill the registers
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int i = threadIdx.x + 256 * e;
+          kreg[e] = -1;
+          if (i < m) {
+            kreg[e] = (int)(a.in_key[g0 + c0 + i] - base_key);
+            const float* pp = a.in_pts + (g0 + c0 + i) * 3;
+            xreg[e][0] = pp[0]; xreg[e][1] = pp[1]; xreg[e][2] = pp[2];
+            ireg[e] = a.in_idx[g0 + c0 + i];
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e)
+        if (kreg[e] >= 0) stage[threadIdx.x + 256 * e] = kreg[e];
       __syncthreads();
       if (wave == 0) {
         // stable ranks, 64 bucket elements at a time: position = run end of the cell so far + equal-cell lanes below
@@ -314,22 +354,23 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
           if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * sub, z);
       }
       __syncthreads();
-      for (int i = threadIdx.x; i < m; i += 256) {
-        const int64_t src = g0 + c0 + i;
-        const int d = stage[i];
-        const float x = a.in_pts[src * 3 + 0], y = a.in_pts[src * 3 + 1], zc = a.in_pts[src * 3 + 2];
-        a.key_sorted[g0 + d] = a.in_key[src];
-        a.idx_sorted[g0 + d] = a.in_idx[src];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        if (kreg[e] < 0) continue;
+        const int d = stage[threadIdx.x + 256 * e];
+        a.key_sorted[g0 + d] = (uint32_t)kreg[e] + base_key;
+        a.idx_sorted[g0 + d] = ireg[e];
         float* o = a.pts_sorted + (g0 + d) * 3;
-        o[0] = x; o[1] = y; o[2] = zc;
-        if (d < CHUNK) { spts[d * 3 + 0] = x; spts[d * 3 + 1] = y; spts[d * 3 + 2] = zc; }
+        o[0] = xreg[e][0]; o[1] = xreg[e][1]; o[2] = xreg[e][2];
+        if (d < CHUNK) { spts[d * 3 + 0] = xreg[e][0]; spts[d * 3 + 1] = xreg[e][1]; spts[d * 3 + 2] = xreg[e][2]; }
       }
       __syncthreads();
     }
   } else {
-    for (int i = threadIdx.x; i < min(n, CHUNK); i += 256) {
-      const float* p = a.in_pts + (g0 + i) * 3;
-      spts[i * 3 + 0] = p[0]; spts[i * 3 + 1] = p[1]; spts[i * 3 + 2] = p[2];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int i = threadIdx.x + 256 * e;
+      if (kreg[e] >= 0) { spts[i * 3 + 0] = xreg[e][0]; spts[i * 3 + 1] = xreg[e][1]; spts[i * 3 + 2] = xreg[e][2]; }
     }
     __syncthreads();
   }
@@ -340,21 +381,32 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   pfn_load_w(c, a.w_pfn, sub);
   if (CANVAS) pfn_load_bn(c, a.bn_ss + (int64_t)s * a.bn_stride, sub);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int cell = grp; cell < ncb; cell += 32) {
+  // list of the band's occupied cells (the ranking scratch is free now): the pillar loop below then keeps all 32 lane
+  // groups busy instead of having most of them skip empty cells while one walks a pillar
+  {
+    int o = occ_ex;
+#pragma unroll
+    for (int k = 0; k < BAND_CELLS / 256; ++k)
+      if ((occ_mask >> k) & 1) stage[o++] = threadIdx.x * (BAND_CELLS / 256) + k;
+  }
+  if (a.cell_rng)   // dense [start, end) table, 8 B per cell
+    for (int cell = threadIdx.x; cell < ncb; cell += 256) {
+      const int k = cnt[cell], e = pos0[cell];
+      int2 v;
+      v.x = k ? (int32_t)(g0 + e - k) : 0;
+      v.y = k ? (int32_t)(g0 + e) : 0;
+      *reinterpret_cast<int2*>(a.cell_rng + 2 * ((int64_t)base_key + cell)) = v;
+    }
+  if (CANVAS && !prefilled) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int cell = grp; cell < ncb; cell += 32)
+      if (cnt[cell] == 0) st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
+  }
+  __syncthreads();
+  for (int oi = grp; oi < n_occ; oi += 32) {
+    const int cell = stage[oi];
     const int k = cnt[cell];
     const int e = pos0[cell], b = e - k;
-    if (a.cell_rng && sub == 0) {
-      int32_t* cr = a.cell_rng + 2 * ((int64_t)base_key + cell);
-      cr[0] = k ? (int32_t)(g0 + b) : 0;
-      cr[1] = k ? (int32_t)(g0 + e) : 0;
-    }
-    if (k == 0) {
-      if (CANVAS && !prefilled) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
-      }
-      continue;
-    }
     auto ld = [&](int i, float (&p)[3]) {
       if (i < CHUNK) { p[0] = spts[i * 3]; p[1] = spts[i * 3 + 1]; p[2] = spts[i * 3 + 2]; }
       else { const float* gq = gpts + (g0 + i) * 3; p[0] = gq[0]; p[1] = gq[1]; p[2] = gq[2]; }
@@ -393,6 +445,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     }
   }
   if (STATS) {
+    __syncthreads();   // `red` aliases the point image the pillar loop above was still reading
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) red[kk * 256 + threadIdx.x] = acc[kk];
     __syncthreads();
@@ -449,14 +502,15 @@ extern "C" int df_pillar2_scan(const int32_t* hist, int S, int ncol, int nblk, i
 
 extern "C" int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, const int32_t* off,
                                   const int32_t* tot, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
-                                  int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, void* stream) {
+                                  int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, int32_t* bucket0,
+                                  void* stream) {
   P2Geom q;
-  DF_REQUIRE(pts && off && tot && points_c && coords_c && idx_c && offs_c && cpos && bkey && bidx && bpts && S > 0 && N > 0,
+  DF_REQUIRE(pts && off && tot && points_c && coords_c && idx_c && offs_c && cpos && bkey && bidx && bpts && bucket0 && S > 0 && N > 0,
              DF_E_ARG);
   DF_REQUIRE(p2_geom(g, rows_per_band, q) && (int64_t)S * g.gx * g.gy < 0x7fffffffll && (int64_t)S * N < 0x7fffffffll, DF_E_SHAPE);
   P2Scatter a;
   a.pts = pts; a.off = off; a.tot = tot; a.points_c = points_c; a.coords_c = coords_c; a.idx_c = idx_c; a.offs_c = offs_c;
-  a.cpos = cpos; a.bkey = bkey; a.bidx = bidx; a.bpts = bpts; a.S = S; a.N = N; a.nblk = (N + TILE - 1) / TILE;
+  a.cpos = cpos; a.bkey = bkey; a.bidx = bidx; a.bpts = bpts; a.bucket0 = bucket0; a.S = S; a.N = N; a.nblk = (N + TILE - 1) / TILE;
   const size_t lds = (size_t)(18 * q.NB + 16 + 8) * sizeof(int);
   const dim3 grid(a.nblk, S);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -470,13 +524,13 @@ extern "C" int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom
 }
 
 extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
-                               int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
+                               const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                                const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                                uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial,
                                void* stream) {
   P2Geom q;
   const bool sort = flags & 1, stats = flags & 2, canvas = flags & 4;
-  DF_REQUIRE(in_key && in_pts && tot && w_pfn && S > 0 && (mode == 0 || mode == 1), DF_E_ARG);
+  DF_REQUIRE(in_key && in_pts && tot && bucket0 && w_pfn && S > 0 && (mode == 0 || mode == 1), DF_E_ARG);
   DF_REQUIRE(p2_geom(g, rows_per_band, q), DF_E_SHAPE);
   DF_REQUIRE((sort && !canvas && stats) || (sort && canvas && !stats) || (!sort && canvas && !stats), DF_E_ARG);
   if (sort) DF_REQUIRE(in_idx && key_sorted && idx_sorted && pts_sorted, DF_E_ARG);
@@ -486,7 +540,7 @@ extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, c
     DF_REQUIRE(out.n == S && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr), DF_E_SHAPE);
   }
   P2Band a;
-  a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
+  a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.bucket0 = bucket0; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
   a.pts_sorted = pts_sorted; a.cell_rng = cell_rng; a.w_pfn = w_pfn; a.bn_ss = bn_ss; a.partial = stats_partial; a.out = out;
   a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S;
   const dim3 grid(q.NB, S);

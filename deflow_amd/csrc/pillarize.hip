@@ -206,50 +206,63 @@ __global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict_
   }
 }
 
-__global__ void pfn_bn_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
-                                       const int32_t* __restrict__ counts, const float* gamma, const float* beta,
-                                       float eps, float momentum, float* running_mean, float* running_var,
-                                       float* __restrict__ bn_ss) {
+// one workgroup per sample (the feature net is called once per sample: BatchNorm1d statistics are per sample): fp64 sums
+// of the per-band / per-block partials -> bn_ss[b] = (scale, shift, mean, invstd); (mean, unbiased var) of the sample is
+// left in the first partial slot for the running-statistics pass below, which must run in sample order
+__global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(float* __restrict__ partial, int nblk,
+                                                               const int32_t* __restrict__ counts, const float* gamma,
+                                                               const float* beta, float eps, float* __restrict__ bn_ss) {
   __shared__ double red[2][32][32];
   const int c = threadIdx.x & 31, tl = threadIdx.x >> 5;  // 32 channels x 32 partial lanes
-  for (int b = 0; b < B; ++b) {
-    float* o = bn_ss + (int64_t)b * 128;
-    const int cnt = counts[b];
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = tl; k < nblk; k += 32) {
-      const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
-      s1 += (double)q[0];
-      s2 += (double)q[1];
-    }
-    red[0][tl][c] = s1;
-    red[1][tl][c] = s2;
-    __syncthreads();
-    if (tl == 0)
-      for (int k = 1; k < 32; ++k) {
-        s1 += red[0][k][c];
-        s2 += red[1][k][c];
-      }
-    __syncthreads();
-    if (tl != 0) continue;
-    if (cnt <= 0) {
-      o[c] = 0.f; o[32 + c] = 0.f; o[64 + c] = 0.f; o[96 + c] = 0.f;
-      continue;
-    }
-    const double mean = s1 / cnt;
-    double var = s2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
-    o[c] = (float)(ga * invstd);
-    o[32 + c] = (float)(be - mean * ga * invstd);
-    o[64 + c] = (float)mean;
-    o[96 + c] = (float)invstd;
-    if (running_mean && cnt > 1) {
-      const double unb = var * cnt / (cnt - 1.0);
-      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
-    }
+  const int b = blockIdx.x;
+  float* o = bn_ss + (int64_t)b * 128;
+  const int cnt = counts[b];
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = tl; k < nblk; k += 32) {
+    const float* q = partial + (((int64_t)b * nblk + k) * 32 + c) * 2;
+    s1 += (double)q[0];
+    s2 += (double)q[1];
   }
+  red[0][tl][c] = s1;
+  red[1][tl][c] = s2;
+  __syncthreads();
+  if (tl != 0) return;
+  for (int k = 1; k < 32; ++k) {
+    s1 += red[0][k][c];
+    s2 += red[1][k][c];
+  }
+  float* mv = partial + (((int64_t)b * nblk) * 32 + c) * 2;
+  if (cnt <= 0) {
+    o[c] = 0.f; o[32 + c] = 0.f; o[64 + c] = 0.f; o[96 + c] = 0.f;
+    mv[0] = 0.f; mv[1] = 0.f;
+    return;
+  }
+  const double mean = s1 / cnt;
+  double var = s2 / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  o[c] = (float)(ga * invstd);
+  o[32 + c] = (float)(be - mean * ga * invstd);
+  o[64 + c] = (float)mean;
+  o[96 + c] = (float)invstd;
+  mv[0] = (float)mean;
+  mv[1] = (float)(cnt > 1 ? var * cnt / (cnt - 1.0) : var);
+}
+
+// running statistics: B successive momentum updates (one module call per sample), skipped for calls with < 2 points
+__global__ void pfn_bn_running_kernel(const float* __restrict__ partial, int B, int nblk, const int32_t* __restrict__ counts,
+                                      float momentum, float* running_mean, float* running_var) {
+  const int c = threadIdx.x;
+  double rm = (double)running_mean[c], rv = (double)running_var[c];
+  for (int b = 0; b < B; ++b) {
+    if (counts[b] <= 1) continue;
+    const float* mv = partial + (((int64_t)b * nblk) * 32 + c) * 2;
+    rm = (float)((1.0 - momentum) * rm + momentum * (double)mv[0]);
+    rv = (float)((1.0 - momentum) * rv + momentum * (double)mv[1]);
+  }
+  running_mean[c] = (float)rm;
+  running_var[c] = (float)rv;
 }
 
 __global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict__ pts,
@@ -967,13 +980,18 @@ extern "C" int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, co
   return DF_OK;
 }
 
-extern "C" int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts,
+extern "C" int df_pfn_bn_finalize(float* partial, int B, int nblk_stat, const int32_t* counts,
                                   const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var, float* bn_ss, void* stream) {
   DF_REQUIRE(partial && counts && bn_ss && B > 0 && nblk_stat > 0, DF_E_ARG);
-  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), partial, B,
-                     nblk_stat, counts, gamma, beta, eps, momentum, running_mean, running_var, bn_ss);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(B), dim3(1024), 0, s, partial, nblk_stat, counts, gamma, beta, eps, bn_ss);
   DF_CHECK_LAUNCH();
+  if (running_mean && running_var) {
+    hipLaunchKernelGGL(pfn_bn_running_kernel, dim3(1), dim3(32), 0, s, partial, B, nblk_stat, counts, momentum, running_mean,
+                       running_var);
+    DF_CHECK_LAUNCH();
+  }
   return DF_OK;
 }
 

@@ -157,22 +157,23 @@ class DynamicEmbedder(nn.Module):
         offs_c = torch.empty(S, N, 3, **f32)
         cpos = torch.empty(S * N, **i32)
         bkey, bidx, bpts = torch.empty(S * N, **i32), torch.empty(S * N, **i32), torch.empty(S * N, 3, **f32)
+        bucket0 = torch.empty(S, NB, **i32)
         call("df_pillar2_scatter", ptr(pts), S, N, g, R, ptr(off), ptr(tot), ptr(points_c), ptr(coords_c), ptr(idx_c), ptr(offs_c),
-             ptr(cpos), ptr(bkey), ptr(bidx), ptr(bpts), s)
+             ptr(cpos), ptr(bkey), ptr(bidx), ptr(bpts), ptr(bucket0), s)
         key_sorted, idx_sorted, pts_sorted = torch.empty(S * N, **i32), torch.empty(S * N, **i32), torch.empty(S * N, 3, **f32)
         cell_rng = torch.empty(S * H * W, 2, **i32) if need_cells else None
         w = self._lin.weight.detach()
         SORT, STATS, CANVAS = 1, 2, 4
         if train:
             partial = torch.empty(S, NB, 32, 2, **f32)
-            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), S, g, R, SORT | STATS, ptr(w), None, 0, self.mode, out,
+            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), ptr(bucket0), S, g, R, SORT | STATS, ptr(w), None, 0, self.mode, out,
                  ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), None, ptr(partial), s)
             bn_ss, bn_stride = self._bn_state(True, partial, counts, S, NB, dev)
-            call("df_pillar2_band", ptr(key_sorted), None, ptr(pts_sorted), ptr(tot), S, g, R, CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+            call("df_pillar2_band", ptr(key_sorted), None, ptr(pts_sorted), ptr(tot), ptr(bucket0), S, g, R, CANVAS, ptr(w), ptr(bn_ss), bn_stride,
                  self.mode, out, None, None, None, ptr(cell_rng), None, s)
         else:
             bn_ss, bn_stride = self._bn_state(False, None, counts, S, NB, dev)
-            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), S, g, R, SORT | CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), ptr(bucket0), S, g, R, SORT | CANVAS, ptr(w), ptr(bn_ss), bn_stride,
                  self.mode, out, ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), ptr(cell_rng), None, s)
         return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss,
                            bn_stride)

@@ -44,6 +44,28 @@ class KernelProfiler:
 
 PROFILER: Optional[KernelProfiler] = None
 
+# Mixed-precision switch of the convolution kernels (forward, data gradient, weight gradient): True = MFMA operands rounded
+# to bf16 as they leave LDS, fp32 accumulation, all tensors still fp32 (df_conv2d_mp / df_conv2d_wgrad_mp).  Set by
+# optim.Trainer(dtype="bf16") around its forward + backward (BASELINE configs[4]: "bf16 MFMA" training); False everywhere else.
+MFMA_BF16 = False
+
+
+class mfma_bf16:
+    """with ops.mfma_bf16(True): ...  -- scoped form of the switch above"""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global MFMA_BF16
+        self.prev, MFMA_BF16 = MFMA_BF16, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global MFMA_BF16
+        MFMA_BF16 = self.prev
+        return False
+
 
 class timed:
     """with ops.timed("stage", bytes=..., flops=...): HIP events around a launch (or a short chain of launches) on the current
@@ -122,14 +144,14 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("df_conv2d", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
-         int(accumulate), stream())
+    call("df_conv2d_mp", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+         int(accumulate), int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
-        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi), flops, e0, e1, tag))
+        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi) + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:
@@ -283,15 +305,15 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
-    call("df_conv2d_wgrad", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
-         stream())
+    call("df_conv2d_wgrad_mp", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
+         int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
         name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"
-        prof.records.append((name, 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
+        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
     if want_bias:

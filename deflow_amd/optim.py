@@ -167,9 +167,16 @@ class Trainer:
     all-reduce of the gradient arena (RCCL over xGMI via torch.distributed, or gloo in CPU tests) -> Adam (HIP)."""
 
     def __init__(self, model: nn.Module, lr: float = 2e-4, process_group=None, loss_fn: str = "deflowLoss",
-                 gradient_clip_val: float = 0.0, sync_bn: bool = False):
+                 gradient_clip_val: float = 0.0, sync_bn: bool = False, dtype: str = "fp32"):
         if loss_fn not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
             raise ValueError(f"unknown loss_fn {loss_fn!r}")
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(f"unknown dtype {dtype!r} (fp32, bf16)")
+        # dtype="bf16" (BASELINE configs[4] "bf16 MFMA"; Lightning's precision="bf16-mixed"): every convolution of the UNet --
+        # forward, data gradient, weight gradient -- multiplies bf16-rounded operands on v_mfma_f32_32x32x16_bf16 with fp32
+        # accumulation; master weights, Adam state, activations, BatchNorm statistics, the point decoder and the loss stay
+        # fp32 (no loss scaling needed: bf16 has fp32's exponent range)
+        self.mfma_bf16 = dtype == "bf16"
         self.loss_fn = loss_fn
         # Lightning's gradient_clip_val (norm clipping of the synchronised gradient, torch.nn.utils.clip_grad_norm_); 0 = off
         self.gradient_clip_val = float(gradient_clip_val)
@@ -253,9 +260,10 @@ class Trainer:
     def step(self, batch) -> torch.Tensor:
         self.flat.zero_grad()
         self.sink.begin()
-        self.model.forward_padded(batch)
-        loss = self.loss_on_last_forward(batch)
-        loss.backward()
+        with ops.mfma_bf16(self.mfma_bf16):
+            self.model.forward_padded(batch)
+            loss = self.loss_on_last_forward(batch)
+            loss.backward()
         scale = self.reduce_gradients()
         if self.gradient_clip_val > 0:       # two launches on the 27.6 MB arena, no host sync
             total_norm = torch.linalg.vector_norm(self.flat.grad) * scale

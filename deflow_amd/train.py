@@ -25,7 +25,7 @@ import torch
 DEFAULTS: Dict[str, Any] = {
     "model": "deflow", "lr": 2e-4, "epochs": 1, "batch_size": 16, "loss_fn": "deflowLoss", "num_workers": 0,
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
-    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dist_backend": "nccl", "resume": False,
+    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dtype": "fp32", "dist_backend": "nccl", "resume": False,
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
     "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 50,   # Lightning's log_every_n_steps default; each log line syncs
 }
@@ -103,7 +103,7 @@ def main(argv=None):
         model.load_from_checkpoint(cfg["checkpoint"])
     model.train()
     trainer = Trainer(model, lr=float(cfg["lr"]), loss_fn=str(cfg["loss_fn"]), gradient_clip_val=float(cfg["gradient_clip_val"]),
-                      sync_bn=str(cfg["sync_bn"]).lower() in ("1", "true"))
+                      sync_bn=str(cfg["sync_bn"]).lower() in ("1", "true"), dtype=str(cfg["dtype"]))
     start_epoch, gstep0 = 0, 0
     if cfg["checkpoint"] and str(cfg["resume"]).lower() in ("1", "true"):
         # "checkpoints also include parameters and status of that epoch" [REF README.md:76-77]: continue where it stopped --

@@ -67,12 +67,14 @@ int df_pillar2_scan(const int32_t* hist, int S, int ncol, int nblk, int32_t* off
 /* order-preserving compaction (shapes as df_pillar_compact) + bucketed key [S*N] u32 / flat index [S*N] u32 / xyz [S*N,3] */
 int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, const int32_t* off,
                        const int32_t* tot, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
-                       int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, void* stream);
+                       int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, int32_t* bucket0 /* [S, NB] out */,
+                       void* stream);
 /* flags: 1 = sort (inputs are the bucketed arrays; writes key_sorted / idx_sorted / pts_sorted), 2 = BatchNorm1d batch
  * statistics partials [S, NB, 32, 2] (finalise with df_pfn_bn_finalize, nblk_stat = NB), 4 = canvas (writes ALL of
  * out [S, gy, gx, 32]).  Valid: 1|4 (inference), 1|2 then 4 (training; the second call takes the SORTED arrays as inputs).
  * cell_rng: optional dense [S*gy*gx, 2] table of sorted [start, end) per cell (written completely). */
-int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot, int S,
+int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
+                    const int32_t* bucket0 /* from df_pillar2_scatter */, int S,
                     df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn, const float* bn_ss,
                     int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted, uint32_t* idx_sorted,
                     float* pts_sorted, int32_t* cell_rng, float* stats_partial, void* stream);
@@ -107,7 +109,7 @@ int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_
 /* finalize: per-sample scale/shift/mean/invstd from the partials, sequential running-stat update (one
  * update per sample, as the reference calls feature_net once per sample).
  * counts [B] i32 valid points; bn_ss [B,4,32] f32 = scale, shift, mean, invstd. */
-int df_pfn_bn_finalize(const float* partial, int B, int nblk_stat, const int32_t* counts, const float* gamma,
+int df_pfn_bn_finalize(float* partial /* clobbered: slot 0 of every sample is reused as scratch */, int B, int nblk_stat, const int32_t* counts, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                        float* bn_ss, void* stream);
 /* step 7: canvas.  `out` (n=B images, c=32) must be ZERO-FILLED by the caller (a streaming memset); this writes the

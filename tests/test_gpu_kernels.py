@@ -162,6 +162,49 @@ def test_conv_big_tiles(dev, cin, cout, k, s, n, h, w, k_fwd, k_dgrad, k_wgrad):
     check("big conv bias grad", db, gy.sum((0, 2, 3)))
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,n,h,w", [(64, 64, 3, 1, 2, 16, 16), (32, 64, 3, 2, 2, 16, 16), (256, 128, 1, 1, 2, 8, 16),
+                                               (128, 128, 3, 1, 2, 64, 128), (64, 64, 3, 1, 2, 32, 256), (256, 128, 3, 1, 3, 64, 64),
+                                               (512, 256, 1, 1, 2, 64, 128), (64, 128, 3, 2, 2, 128, 256)])
+def test_conv_bf16_operand_mode(dev, cin, cout, k, s, n, h, w):
+    """mixed-precision mode of the conv kernels (ops.mfma_bf16; Trainer(dtype="bf16")): operands rounded to bf16 on the way
+    into v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 tensors.  bf16 x bf16 products are exact in fp32, so the result
+    must equal F.conv2d on bf16-ROUNDED inputs to fp32 summation error -- a tight check that the rounding is
+    round-to-nearest-even on BOTH operands and that every k index meets its partner (forward, data and weight gradient)."""
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin * 3 + cout + k + s + w)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    xr, wr = _bf16_round(x).requires_grad_(True), _bf16_round(wt).requires_grad_(True)
+    y = F.conv2d(xr, wr, b, stride=s, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g)
+    xd, gyd = nhwc(x).to(dev), nhwc(gy).to(dev)
+    wd = ops.ohwi(wt.to(dev).contiguous(memory_format=torch.channels_last))
+    with ops.mfma_bf16(True):
+        yd = torch.empty(n, y.shape[2], y.shape[3], cout, device=dev)
+        ops.conv2d(img(xd), wd, b.to(dev), img(yd), k, s)
+        dx = torch.empty_like(xd)
+        ops.conv2d(img(gyd), ops.weight_transpose(wd), None, img(dx), k, s, mode=ops.CONV_DGRAD)
+        dw = torch.empty_like(wd)
+        ops.conv2d_wgrad(img(xd), img(gyd), k, s, dw)
+    check(f"bf16-mode fwd {cin}->{cout} k{k} s{s}", nchw(yd), y.detach(), 2e-5)
+    # data gradient: operands are dy and w (both rounded by the kernel); weight gradient: x and dy
+    want_dx = torch.autograd.grad(F.conv2d(xr, wr, None, stride=s, padding=k // 2), xr, _bf16_round(gy))[0]
+    check(f"bf16-mode dgrad {cin}->{cout} k{k} s{s}", nchw(dx), want_dx, 2e-5)
+    want_dw = torch.autograd.grad(F.conv2d(xr, wr, None, stride=s, padding=k // 2), wr, _bf16_round(gy))[0]
+    check(f"bf16-mode wgrad {cin}->{cout} k{k} s{s}", dw.permute(0, 3, 1, 2), want_dw, 2e-5)
+    # and against the unrounded fp32 convolution: bf16 operand rounding, ~2^-9 per product, averaged over the k sum
+    y32 = F.conv2d(x, wt, b, stride=s, padding=k // 2)
+    e = rel_err(nchw(yd), y32)
+    print(f"[parity] bf16-mode vs fp32 conv {cin}->{cout} k{k}: {e:.2e}")
+    assert e < 2e-2
+
+
 # ---------------------------------------------------------------------------- BN + GELU -----------
 @pytest.mark.parametrize("groups", [1, 2])
 def test_convwithnorms_train_fwd_bwd(dev, groups):

@@ -518,6 +518,38 @@ def test_bf16_bs16_vs_fp32_and_oracle(dev):
             assert emax <= 2e-2
 
 
+def test_bf16_training_trajectory(dev):
+    """Trainer(dtype="bf16") -- BASELINE configs[4]'s "bf16 MFMA" as a TRAINING mode: UNet convolutions (forward, data and
+    weight gradients) on bf16 MFMA operands with fp32 accumulation, fp32 master weights / Adam / BatchNorm statistics /
+    decoder.  Six optimizer steps against the fp32 CPU oracle stepping torch.optim.Adam on the same batches: the loss
+    trajectory must follow within 2e-2 relative (bf16 keeps 8 mantissa bits; measured ~1e-3) and must go down."""
+    from oracle import ref_torch as O
+    from deflow_amd.optim import Trainer
+    ref, mine = build_pair(dev, 31, decoder_option="gru", num_iters=4)
+    ref.train(); mine.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)   # the README's learning rate (at 2e-3 the fp32 oracle itself diverges
+    tr = Trainer(mine, lr=2e-4, dtype="bf16")            # within six steps and any rounding difference is amplified)
+    batches = [make_batch(2, 1500, 5000 + 10 * i) for i in range(2)]
+    want, got = [], []
+    for i in range(6):
+        b = batches[i % 2]
+        opt.zero_grad()
+        l = O.training_loss(ref(b), b)
+        l.backward()
+        opt.step()
+        want.append(float(l.detach()))
+        got.append(float(tr.step(to_dev(b, dev))))
+    print("[parity] bf16 training loss trajectory:", [f"{g:.4f}/{w:.4f}" for g, w in zip(got, want)])
+    import parity
+    for i, (g, w) in enumerate(zip(got, want)):
+        e = abs(g - w) / abs(w)
+        parity.record("bf16_train", f"loss step {i}", err_vs_fp32_oracle=e, bound=2e-2, ok=e <= 2e-2)
+        assert e <= 2e-2, (i, g, w)
+    assert got[4] < got[0] and got[5] < got[1], "the loss on each of the two batches must go down"
+    from deflow_amd import ops
+    assert ops.MFMA_BF16 is False, "the switch must not leak out of Trainer.step"
+
+
 def test_train_mode_forward_without_grad_is_repeatable():
     """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
     (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
