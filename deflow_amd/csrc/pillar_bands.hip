@@ -22,6 +22,8 @@
 //            Linear(9->32) + BN1d + ReLU, mean / max, one 128-B store per pillar.
 // Training needs the BatchNorm1d batch statistics before it can normalise: band<sort, stats> leaves per-band partial
 // sums (fp32, finalised in fp64 by df_pfn_bn_finalize), band<canvas> then re-derives the cell table from the sorted keys.
+#include <cstdlib>
+
 #include "common.h"
 #include "pillar_common.h"
 
@@ -242,6 +244,7 @@ struct P2Band {
   float* partial;                    // STATS: [S][NB][32][2]
   df_img out;
   int bn_stride, mode, S;
+  int dbg;   // timing ablations (env DF_P2_DBG): bit 0 = no pillar loop, bit 1 = no zero stores, bit 2 = no sort / copy
 };
 
 template <bool SORT, bool STATS, bool CANVAS>
@@ -259,8 +262,16 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   const int row0 = band * q.R, rows = min(q.R, g.gy - row0), ncb = rows * g.gx;
   for (int i = threadIdx.x; i < ncb; i += 256) cnt[i] = 0;
   __syncthreads();
+  // Barriers below order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also drain every
+  // outstanding global store -- the canvas zeros issued early would then be waited for at the next barrier instead of
+  // streaming out underneath the sort.  Only a bucket beyond CHUNK elements reads its own global writes back and needs
+  // the full fence.
   const int64_t g0 = a.bucket0[(int64_t)s * NB + band];   // wave-uniform scalar loads
   const int n = a.tot[(int64_t)s * ncol + band];
+  auto bar = [&]() {
+    if (n > CHUNK) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
   const uint32_t base_key = (uint32_t)((s * g.gy + row0) * g.gx);
   // this thread's share of the first CHUNK bucket elements stays in registers from here to the permuted copy: one global
   // round trip feeds the histogram, the ranking and the copy (buckets beyond CHUNK elements take the slower loop below)
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   for (int e = 0; e < EPT; ++e)
     if (kreg[e] >= 0) atomicAdd(&cnt[kreg[e]], 1);
   for (int i = CHUNK + threadIdx.x; i < n; i += 256) atomicAdd(&cnt[a.in_key[g0 + i] - base_key], 1);
-  __syncthreads();
+  bar();
   int occ_ex, occ_mask = 0;   // this thread's 8 cells: number of occupied cells before them / which of them are occupied
   {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread), and of the occupancy flags -> occupied-cell list
     const int c0 = threadIdx.x * (BAND_CELLS / 256);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     int ex = wave_excl_scan(sum, lane, wt);
     occ_ex = wave_excl_scan(nocc, lane, wo);
     if (lane == 63) { misc[2 + wave] = wt; misc[8 + wave] = wo; }
-    __syncthreads();
+    bar();
     for (int w = 0; w < wave; ++w) { ex += misc[2 + w]; occ_ex += misc[8 + w]; }
 #pragma unroll
     for (int k = 0; k < BAND_CELLS / 256; ++k) {
@@ -307,11 +318,22 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       ex += loc[k];
     }
   }
-  __syncthreads();
+  bar();
   const int n_occ = misc[8] + misc[9] + misc[10] + misc[11];
   float* __restrict__ op = CANVAS ? reinterpret_cast<float*>(a.out.ptr) + df_img_base(a.out, s) + (int64_t)row0 * g.gx * a.out.ld : nullptr;
-  const bool prefilled = SORT && CANVAS && n > 0;
-  if (SORT) {
+  const bool prefilled = CANVAS;
+  // zeros into the band's empty cells (128 B each, 8 lanes x 16 B) as soon as the histogram is known; every canvas byte is
+  // written exactly once.  Measured at B = 16 (tools/bench_pillar.py, DF_P2_DBG ablations): this stream runs at 7.5 TB/s
+  // (7.8 us per pair), the pillar loop costs 4 us (VALU-bound), the sort 1.5 us, hist + scan + scatter 6.1 us -- and the
+  // parts add up rather than overlap; filling after the pillar loop in every other workgroup (so that half of a CU's waves
+  // would compute while the other half stream) measured the same within noise and is not kept.
+  if (CANVAS && !(a.dbg & 2)) {
+    const int zg = threadIdx.x >> 3, zs = threadIdx.x & 7;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int c = zg; c < ncb; c += 32)
+      if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * zs, z);
+  }
+  if (SORT && !(a.dbg & 4)) {
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
       const int m = min(CHUNK, n - c0);
       if (c0 > 0) {   // rare: a bucket beyond CHUNK elements -- refill the registers
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e)
         if (kreg[e] >= 0) stage[threadIdx.x + 256 * e] = kreg[e];
-      __syncthreads();
+      bar();
       if (wave == 0) {
         // stable ranks, 64 bucket elements at a time: position = run end of the cell so far + equal-cell lanes below
         const unsigned long long lt = (1ull << lane) - 1ull;
@@ -346,14 +368,8 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
             if ((mk >> lane) == 1ull) pos0[c] = basep + __popcll(mk);   // highest lane of the group advances the cell
           }
         }
-      } else if (CANVAS && c0 == 0) {
-        // meanwhile: zeros into the band's empty cells (128 B each, 8 lanes x 16 B), every byte of the canvas once
-        const int grp = (threadIdx.x - 64) >> 3, sub = threadIdx.x & 7;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int c = grp; c < ncb; c += 24)
-          if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * sub, z);
       }
-      __syncthreads();
+      bar();
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         if (kreg[e] < 0) continue;
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
         o[0] = xreg[e][0]; o[1] = xreg[e][1]; o[2] = xreg[e][2];
         if (d < CHUNK) { spts[d * 3 + 0] = xreg[e][0]; spts[d * 3 + 1] = xreg[e][1]; spts[d * 3 + 2] = xreg[e][2]; }
       }
-      __syncthreads();
+      bar();
     }
   } else {
 #pragma unroll
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       const int i = threadIdx.x + 256 * e;
       if (kreg[e] >= 0) { spts[i * 3 + 0] = xreg[e][0]; spts[i * 3 + 1] = xreg[e][1]; spts[i * 3 + 2] = xreg[e][2]; }
     }
-    __syncthreads();
+    bar();
   }
   // ---- feature net over the band's cells: 8 lanes per cell, lane `sub` owns output channels 4*sub .. 4*sub+3
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
@@ -402,8 +418,8 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     for (int cell = grp; cell < ncb; cell += 32)
       if (cnt[cell] == 0) st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
   }
-  __syncthreads();
-  for (int oi = grp; oi < n_occ; oi += 32) {
+  bar();
+  for (int oi = grp; oi < ((a.dbg & 1) ? 0 : n_occ); oi += 32) {
     const int cell = stage[oi];
     const int k = cnt[cell];
     const int e = pos0[cell], b = e - k;
@@ -445,10 +461,10 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     }
   }
   if (STATS) {
-    __syncthreads();   // `red` aliases the point image the pillar loop above was still reading
+    bar();   // `red` aliases the point image the pillar loop above was still reading
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) red[kk * 256 + threadIdx.x] = acc[kk];
-    __syncthreads();
+    bar();
     if (threadIdx.x < 8) {
       for (int gi = 1; gi < 32; ++gi)
 #pragma unroll
@@ -543,6 +559,8 @@ extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, c
   a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.bucket0 = bucket0; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
   a.pts_sorted = pts_sorted; a.cell_rng = cell_rng; a.w_pfn = w_pfn; a.bn_ss = bn_ss; a.partial = stats_partial; a.out = out;
   a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S;
+  static const int dbg = getenv("DF_P2_DBG") ? atoi(getenv("DF_P2_DBG")) : 0;
+  a.dbg = dbg;
   const dim3 grid(q.NB, S);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (sort && canvas) hipLaunchKernelGGL((p2_band_kernel<true, false, true>), grid, dim3(256), 0, st, a, q);
