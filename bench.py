@@ -308,8 +308,8 @@ def main():
                 trainer.step(batch)
             dtb, _, lossb = timed_steps(args.steps)
             trainer.mfma_bf16 = False
-            out["bf16_training"] = {"workload": "the headline step with dtype=bf16 (bf16 MFMA operands in every UNet conv fwd/dgrad/wgrad, "
-                                                "fp32 accumulate, fp32 tensors + master weights + decoder)",
+            out["bf16_training"] = {"workload": "the headline step with dtype=bf16 (bf16 MFMA operands in every UNet conv fwd/dgrad/wgrad and every "
+                                                "decoder GEMM, fp32 accumulate, fp32 tensors + master weights + GRU state)",
                                     "ms_per_step": dtb / args.steps * 1e3, "pairs_per_s": args.batch * args.steps / dtb,
                                     "speedup_vs_fp32": dt / dtb, "loss": float(lossb)}
     if world == 1 and not args.no_extras:

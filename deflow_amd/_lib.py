@@ -86,6 +86,9 @@ _SIGS = {
     "df_upsample2x": [DfImg, DfImg, I, P],
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],
     "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],
+    "df_gru_decoder_fwd_mp": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, I, P],
+    "df_gru_decoder_bwd_mp": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, I, P],
+    "df_gru_wgrad_mp": [P, P, P, I, I, I, P, I, I, P],
     "df_gru_decoder_fwd_bf16": [DfImg, DfImg, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
     "df_gru_wgrad_splits": [],

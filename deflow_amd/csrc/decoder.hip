@@ -273,11 +273,17 @@ bool img64_ok(const df_img& d, int B) {
 }  // namespace
 
 int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
-                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, void* stream);
+                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16, void* stream);
 
 extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
                                   const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts, float* flow,
                                   float* save, void* stream) {
+  return df_gru_decoder_fwd_mp(before, after, coords, offs, counts, B, N, num_iters, wts, flow, save, 0, stream);
+}
+
+extern "C" int df_gru_decoder_fwd_mp(df_img before, df_img after, const int32_t* coords, const float* offs,
+                                     const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts, float* flow,
+                                     float* save, int mfma_bf16, void* stream) {
   DF_REQUIRE(img64_ok(before, B) && img64_ok(after, B), DF_E_SHAPE);
   DF_REQUIRE(before.h == after.h && before.w == after.w, DF_E_SHAPE);
   DF_REQUIRE(coords && offs && counts && flow && B > 0 && N > 0 && num_iters >= 1, DF_E_ARG);
@@ -285,7 +291,7 @@ extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* co
                  wts.b_2 && df_aligned16(wts.w_zr) && df_aligned16(wts.w_q) && df_aligned16(wts.w_1),
              DF_E_ARG);
   static const bool use_v1 = getenv("DF_GRU_V1") != nullptr;  // first-generation kernel (1 workgroup / CU), for A/B
-  if (!use_v1) return df_launch_gru_fwd3(before, after, coords, offs, counts, B, N, num_iters, wts, flow, save, stream);
+  if (!use_v1) return df_launch_gru_fwd3(before, after, coords, offs, counts, B, N, num_iters, wts, flow, save, mfma_bf16, stream);
   GruFwdParams p;
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;
   p.N = N; p.T = num_iters; p.w = wts; p.flow = flow; p.save = save;

@@ -27,7 +27,7 @@ struct Gru3Params {
   int64_t plane_stride, iter_stride;
 };
 
-template <bool SAVE>
+template <bool SAVE, bool BF = false>
 __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
   const float* w_r = p.w.w_zr + 128 * 192;
   const float* w_q = p.w.w_q;
 
-  WStream ws;
+  WStreamT<BF> ws;
   wstream_init(ws, Bs);
-  dma_chunk<128, 192>(w_z, 4, Bs, wave, ws.voff<192>());   // first chunk of the x projection
+  dma_chunk<128, 192>(w_z, 4, Bs, wave, ws.template voff<192>());   // first chunk of the x projection
 
   // ---- x = offset encoder -> A region (temporarily) -> register fragments ------------------------------------------
   f32x4 xf[4];
@@ -200,15 +200,18 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
 
 // Arguments are validated by the C-ABI entry (df_gru_decoder_fwd in decoder.hip), which dispatches here.
 int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
-                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, void* stream) {
+                       int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16, void* stream) {
   Gru3Params p;
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;
   p.N = N; p.T = num_iters; p.w = wts; p.flow = flow; p.save = save;
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   const dim3 grid((N + 63) / 64, B);
-  if (save) hipLaunchKernelGGL(gru_fwd3_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(gru_fwd3_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (save && mfma_bf16) hipLaunchKernelGGL((gru_fwd3_kernel<true, true>), grid, dim3(256), 0, s, p);
+  else if (save) hipLaunchKernelGGL((gru_fwd3_kernel<true, false>), grid, dim3(256), 0, s, p);
+  else if (mfma_bf16) hipLaunchKernelGGL((gru_fwd3_kernel<false, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gru_fwd3_kernel<false, false>), grid, dim3(256), 0, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -47,6 +47,7 @@ struct GruBwd3Params {
   float* bias_partial;  // [blocks][772], layout as in decoder_bwd.hip
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   const float* wt_q = p.wt.wt_q;
   const float* wt_zr = p.wt.wt_zr;
 
-  WStream ws;
+  WStreamT<BF> ws;
   wstream_init(ws, Bs);
-  dma_chunk<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.voff<192>());
+  dma_chunk<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff<192>());
 
   auto lds_to_rows = [&](float* dst) {  // the wave's 16 x 128 A region -> global rows (coalesced; invalid rows dropped)
     const rsrc_t d = make_rsrc(dst + grow0 * 128, row_bytes);
@@ -344,13 +345,14 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 // Arguments are validated by the C-ABI entry (df_gru_decoder_bwd in decoder_bwd.hip), which dispatches here.
 int df_launch_gru_bwd3(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
                        df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
-                       float* xout, float* bias_partial, void* stream) {
+                       float* xout, float* bias_partial, int mfma_bf16, void* stream) {
   GruBwd3Params p;
   p.dflow = dflow; p.offs = offs; p.counts = counts; p.N = N; p.T = num_iters; p.w = wts; p.wt = wtt; p.save = save;
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.xout = xout; p.bias_partial = bias_partial;
-  hipLaunchKernelGGL(gru_bwd3_kernel, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16) hipLaunchKernelGGL(gru_bwd3_kernel<true>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(gru_bwd3_kernel<false>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -499,11 +499,17 @@ __global__ __launch_bounds__(256) void small_outer_kernel(const float* __restric
 
 int df_launch_gru_bwd3(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
                        df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
-                       float* xout, float* bias_partial, void* stream);
+                       float* xout, float* bias_partial, int mfma_bf16, void* stream);
 
 extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N,
                                   int num_iters, df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0,
                                   float* dx, float* dpre1, float* xout, float* bias_partial, void* stream) {
+  return df_gru_decoder_bwd_mp(dflow, offs, counts, B, N, num_iters, wts, wtt, save, dh0, dx, dpre1, xout, bias_partial, 0, stream);
+}
+
+extern "C" int df_gru_decoder_bwd_mp(const float* dflow, const float* offs, const int32_t* counts, int B, int N,
+                                     int num_iters, df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0,
+                                     float* dx, float* dpre1, float* xout, float* bias_partial, int mfma_bf16, void* stream) {
   DF_REQUIRE(dflow && offs && counts && save && dh0 && dx && dpre1 && xout && bias_partial && B > 0 && N > 0 &&
                  num_iters >= 1,
              DF_E_ARG);
@@ -513,7 +519,7 @@ extern "C" int df_gru_decoder_bwd(const float* dflow, const float* offs, const i
              DF_E_ALIGN);
   static const bool use_v1 = getenv("DF_GRU_V1") != nullptr;  // first-generation kernel (1 workgroup / CU), for A/B
   if (!use_v1)
-    return df_launch_gru_bwd3(dflow, offs, counts, B, N, num_iters, wts, wtt, save, dh0, dx, dpre1, xout, bias_partial, stream);
+    return df_launch_gru_bwd3(dflow, offs, counts, B, N, num_iters, wts, wtt, save, dh0, dx, dpre1, xout, bias_partial, mfma_bf16, stream);
   GruBwdParams p;
   p.dflow = dflow; p.offs = offs; p.counts = counts; p.N = N; p.T = num_iters; p.w = wts; p.wt = wtt; p.save = save;
   p.iter_stride = (int64_t)B * N * 128;

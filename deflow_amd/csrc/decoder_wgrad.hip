@@ -29,6 +29,9 @@ struct GruWgradParams {
   float* ws;           // [nsplit][384][192]
 };
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float ring[WD * STG];   // 60 KB
@@ -120,6 +123,29 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
     __syncthreads();   // ... and everyone's; all waves are also done reading slot (i - 1) % WD
     if (i + 2 < nst) issue((i + 2) % WD);
     const float* st = ring + (i % WD) * STG;
+    if constexpr (BF) {
+      // bf16 operands (mixed-precision training): the stage's 16 rows are ONE k step of v_mfma_f32_32x32x16_bf16 -- lane
+      // (column, kh) holds rows 8 kh .. 8 kh + 7
+      bf16x8_t a8[2], b8[3];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a8[0][k] = (__bf16)st[(8 * kh + k) * 128 + wco * 64 + li];
+        a8[1][k] = (__bf16)st[(8 * kh + k) * 128 + wco * 64 + 32 + li];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ci = wci * 96 + 32 * j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          b8[j][k] = (__bf16)((ci < 128) ? st[WP * 128 + (8 * kh + k) * 128 + ci + li] : st[2 * WP * 128 + (8 * kh + k) * 64 + (ci - 128) + li]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0], b8[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1], b8[j], acc[1][j], 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < WP / 2; ++ks) {
       const float a0 = st[a_off + ks * 256], a1 = st[a_off + ks * 256 + 32];
@@ -154,6 +180,11 @@ extern "C" int df_gru_wgrad_splits(void) { return 170; }   // 3 gates x 170 = 51
 
 extern "C" int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters,
                             float* ws, int nsplit, void* stream) {
+  return df_gru_wgrad_mp(save, x, counts, B, N, num_iters, ws, nsplit, 0, stream);
+}
+
+extern "C" int df_gru_wgrad_mp(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters,
+                               float* ws, int nsplit, int mfma_bf16, void* stream) {
   DF_REQUIRE(save && x && counts && ws && B > 0 && N > 0 && num_iters >= 1 && nsplit >= 1, DF_E_ARG);
   DF_REQUIRE(df_aligned16(save) && df_aligned16(x), DF_E_ALIGN);
   DF_REQUIRE((int64_t)B * N * 512 < (int64_t)0x7fffffff, DF_E_SHAPE);  // 32-bit DMA offsets within one iteration's plane
@@ -162,7 +193,8 @@ extern "C" int df_gru_wgrad(const float* save, const float* x, const int32_t* co
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.ws = ws;
-  hipLaunchKernelGGL(gru_wgrad_kernel, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(gru_wgrad_kernel<false>, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -41,10 +41,23 @@ __device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk
                                              (unsigned)((i * 32 * LDW + chunk * 32) * 4), 0, 0);
 }
 
-struct WStream;
-__device__ __forceinline__ void wstream_init(WStream& ws, float* Bs);
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
+  bf16x8_t r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[k] = (__bf16)lo[k];
+    r[4 + k] = (__bf16)hi[k];
+  }
+  return r;
+}
 
-struct WStream {   // the weight-chunk pipeline state shared by consecutive GEMMs
+// BF_ = bf16-operand mode (mixed-precision training, optim.Trainer(dtype="bf16")): a 32-deep k chunk -- the two 16-wide
+// k groups a lane reads as two float4 -- is rounded to bf16 (RNE) and goes through ONE v_mfma_f32_16x16x32_bf16 instead of
+// eight v_mfma_f32_16x16x4_f32; state, gates, accumulators and the saved planes stay fp32.
+template <bool BF_>
+struct WStreamT {   // the weight-chunk pipeline state shared by consecutive GEMMs
+  static constexpr bool BF = BF_;
   float* Bs;
   int par, wave;
   unsigned vrow, vslot; // per-lane DMA source: row within the first 32 (wave * 8 + lane / 8), swizzled slot byte offset
@@ -53,19 +66,30 @@ struct WStream {   // the weight-chunk pipeline state shared by consecutive GEMM
   const float* b_lane; // fragment base: row li of buffer 0
   int bsl[2];          // swizzled slot offsets (floats) of the two 16-wide k groups
 };
+using WStream = WStreamT<false>;
 
 // acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
 // registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
 // (Wn, cn, ROWS_NEXT rows) is fetched during the last chunk.
-template <int ROWS, int NCH, bool XA, int ROWS_NEXT, int LDW = 192, int LDW_NEXT = 192>
+template <int ROWS, int NCH, bool XA, int ROWS_NEXT, int LDW = 192, int LDW_NEXT = 192, class WS>
 __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const float* __restrict__ Wn, int cn,
-                                     const float* a_lane, const f32x4 (&xf)[4], WStream& ws, f32x4 (&acc)[ROWS / 16]) {
+                                     const float* a_lane, const f32x4 (&xf)[4], WS& ws, f32x4 (&acc)[ROWS / 16]) {
   constexpr int NPAIR = ROWS / 32;
   auto chunk = [&](int c, const f32x4 a0, const f32x4 a1) {
     float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
-    if (c + 1 < NCH) dma_chunk<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.voff<LDW>());
-    else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.voff<LDW_NEXT>());
+    if (c + 1 < NCH) dma_chunk<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff<LDW>());
+    else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff<LDW_NEXT>());
     const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
+    if constexpr (WS::BF) {
+      const bf16x8_t a8 = pack_bf16(a0, a1);
+#pragma unroll
+      for (int t = 0; t < ROWS / 16; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pack_bf16(ld4(bb + t * 512 + ws.bsl[0]), ld4(bb + t * 512 + ws.bsl[1])),
+                                                         acc[t], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      return;
+    }
     f32x4 nb0 = ld4(bb + ws.bsl[0]), nb1 = ld4(bb + 512 + ws.bsl[0]);
 #pragma unroll
     for (int j = 0; j < 2 * NPAIR; ++j) {
@@ -97,7 +121,8 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
   ws.par = (ws.par + NCH) & 1;
 }
 
-__device__ __forceinline__ void wstream_init(WStream& ws, float* Bs) {
+template <class WS>
+__device__ __forceinline__ void wstream_init(WS& ws, float* Bs) {
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   ws.Bs = Bs;
   ws.par = 0;

@@ -116,8 +116,8 @@ class ConvGRUDecoder(nn.Module):
         # algorithmic work per point (un-hoisted count): 589 824 * T / 4 + 12 870 FLOP; fused-minimum traffic
         # 128 * 4 B gathered + 36 B of coordinates / offsets / flow
         with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
-            call("df_gru_decoder_fwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
-                 ptr(sv), stream())
+            call("df_gru_decoder_fwd_mp", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
+                 ptr(sv), int(ops.MFMA_BF16), stream())
         return flow, sv
 
     def run_bf16(self, before: DfImg, after: DfImg, ps: PointSet):
@@ -159,8 +159,8 @@ class ConvGRUDecoder(nn.Module):
         nblocks = B * ((N + 63) // 64)
         bias_partial = torch.zeros(nblocks, 772, **f32)
         with ops.timed("gru_bwd", flops=2.0 * B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
-            call("df_gru_decoder_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), s)
+            call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
+                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), int(ops.MFMA_BF16), s)
         bias_g = torch.empty(772, **f32)
         if nblocks >= 2048:  # tens of thousands of per-workgroup rows: two-stage column sum
             staged = torch.empty(64, 772, **f32)
@@ -207,7 +207,7 @@ class ConvGRUDecoder(nn.Module):
                 nsplit = call("df_gru_wgrad_splits")
                 ws = torch.empty(nsplit, 384, 192, **f32)
                 with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
-                    call("df_gru_wgrad", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, s)
+                    call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, int(ops.MFMA_BF16), s)
                 dW_all = torch.empty(384, 192, **f32)
                 call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
                 dW_zr, dW_q = dW_all[:256], dW_all[256:]

@@ -172,9 +172,10 @@ class Trainer:
             raise ValueError(f"unknown loss_fn {loss_fn!r}")
         if dtype not in ("fp32", "bf16"):
             raise ValueError(f"unknown dtype {dtype!r} (fp32, bf16)")
-        # dtype="bf16" (BASELINE configs[4] "bf16 MFMA"; Lightning's precision="bf16-mixed"): every convolution of the UNet --
-        # forward, data gradient, weight gradient -- multiplies bf16-rounded operands on v_mfma_f32_32x32x16_bf16 with fp32
-        # accumulation; master weights, Adam state, activations, BatchNorm statistics, the point decoder and the loss stay
+        # dtype="bf16" (BASELINE configs[4] "bf16 MFMA"; Lightning's precision="bf16-mixed"): every GEMM-shaped kernel -- the
+        # UNet's convolutions (forward, data gradient, weight gradient) and the point decoder's gate / head GEMMs (forward,
+        # backward, gate weight gradients) -- multiplies bf16-rounded operands on v_mfma_f32_{32x32x16,16x16x32}_bf16 with fp32
+        # accumulation; master weights, Adam state, activations, BatchNorm statistics, GRU state and gates, and the loss stay
         # fp32 (no loss scaling needed: bf16 has fp32's exponent range)
         self.mfma_bf16 = dtype == "bf16"
         self.loss_fn = loss_fn

@@ -258,6 +258,11 @@ typedef struct df_gru_weights {
 int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
                        const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts,
                        float* flow, float* save, void* stream);
+/* mixed-precision form (Trainer(dtype="bf16")): mfma_bf16 != 0 rounds the operands of every gate / head GEMM to bf16 on the
+ * way into v_mfma_f32_16x16x32_bf16; hidden state, gate math, accumulators and the saved planes stay fp32. */
+int df_gru_decoder_fwd_mp(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
+                          int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16,
+                          void* stream);
 typedef struct df_gru_weights_t {          /* transposed copies (df_weight_transpose) for the data-gradient GEMMs */
   const float* wt_zr; /* [192,256] */
   const float* wt_q;  /* [192,128] */
@@ -272,6 +277,9 @@ typedef struct df_gru_weights_t {          /* transposed copies (df_weight_trans
 int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
                        df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
                        float* xout, float* partial, void* stream);
+int df_gru_decoder_bwd_mp(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters,
+                          df_gru_weights wts, df_gru_weights_t wtt, float* save, float* dh0, float* dx, float* dpre1,
+                          float* xout, float* bias_partial, int mfma_bf16, void* stream);
 /* Weight gradients of the three GRU gate convolutions in one streaming pass over the planes df_gru_decoder_fwd saved
  * and df_gru_decoder_bwd overwrote (replaces autograd's six 1x1 conv weight-gradient GEMMs over [REF decoder.py:139-147]):
  * ws[split][384][192] partial tiles, rows 0..127 dW_z, 128..255 dW_r, 256..383 dW_q, columns [h | x]; sum the splits
@@ -279,6 +287,8 @@ int df_gru_decoder_bwd(const float* dflow, const float* offs, const int32_t* cou
 int df_gru_wgrad_splits(void);
 int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,
                  int nsplit, void* stream);
+int df_gru_wgrad_mp(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,
+                    int nsplit, int mfma_bf16, void* stream);
 /* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
  * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
  * with accumulate_* != 0, added to.  dbefore.ptr == NULL skips the `before` image. */

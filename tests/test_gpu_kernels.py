@@ -472,6 +472,37 @@ def test_gru_decoder_golden(dev, golden_dir, iters):
         check(f"gru grad {k}", p.grad, torch.from_numpy(g["gw." + k]), tol=5e-4)
 
 
+@pytest.mark.parametrize("iters", [4, 8])
+def test_gru_decoder_bf16_operand_mode(dev, golden_dir, iters):
+    """the decoder kernels in mixed-precision mode (ops.mfma_bf16; gate / head GEMM operands rounded to bf16, fp32 state,
+    gates, accumulators and saved planes) against the REAL reference's fp32 vectors: flow and every gradient within 2e-2 of
+    the largest element (bf16 keeps 8 mantissa bits through 3 x iters GEMMs; measured a few 1e-3)."""
+    import os
+    from deflow_amd import ops
+    from deflow_amd.decoder import ConvGRUDecoder
+    g = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}.npz")))
+    m = _load_head(ConvGRUDecoder, g, dev, num_iters=iters)
+    before = torch.from_numpy(g["before"]).to(dev).requires_grad_(True)
+    after = torch.from_numpy(g["after"]).to(dev).requires_grad_(True)
+    infos = [{"voxel_coords": torch.from_numpy(g[f"vc{i}"]), "point_offsets": torch.from_numpy(g[f"off{i}"])} for i in range(3)]
+    with ops.mfma_bf16(True):
+        flows = m(before, after, infos)
+        for i in (0, 2):
+            check(f"bf16-mode gru it{iters} flow{i}", flows[i], torch.from_numpy(g[f"flow{i}"]), tol=2e-2)
+        loss = sum((f * torch.from_numpy(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows))
+        loss.backward()
+    torch.cuda.synchronize()
+    check("bf16-mode gru d(before)", before.grad, torch.from_numpy(g["gbefore"]), tol=2e-2)
+    check("bf16-mode gru d(after)", after.grad, torch.from_numpy(g["gafter"]), tol=2e-2)
+    for k, p in m.named_parameters():
+        check(f"bf16-mode gru grad {k}", p.grad, torch.from_numpy(g["gw." + k]), tol=2e-2)
+    # the result must differ from the fp32 kernels' (the switch really selects the bf16 MFMA path) ...
+    f32 = m(before.detach(), after.detach(), infos)
+    assert float((f32[0] - flows[0].detach()).abs().max()) > 0
+    # ... and must not leak: the fp32 call above matches the golden at the fp32 tolerance
+    check("fp32 after bf16 mode", f32[0], torch.from_numpy(g["flow0"]))
+
+
 def test_linear_decoder_golden(dev, golden_dir):
     import os
     from deflow_amd.decoder import LinearDecoder
