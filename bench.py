@@ -251,7 +251,10 @@ def main():
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), same workload
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"] if args.batch == PER_GPU_BATCH else None
+                kk = json.load(f)["kernels"]
+                # rocprof prints the full template list (the trailing `false` = fp32 operands)
+                ent = kk.get(dom) or kk.get(dom[:-1] + ",false>")
+                traffic = ent["hbm_bytes_per_launch"] if (ent and args.batch == PER_GPU_BATCH) else None
         except Exception:
             traffic = None
         mfma = {k: v for k, v in summ.items() if v["flops"] > 0 and not k.startswith("gru_")}
@@ -292,8 +295,8 @@ def main():
                 summ[k]["flops"] *= vf
                 summ[k]["bytes"] *= vf
         entry("gru_fwd", ["gru_fwd"], "gather + T GRU steps + head, training form; bytes = fused minimum (548 B/point)")
-        entry("gru_bwd", ["gru_bwd"], "data gradients (flops = 2 x the un-hoisted forward count, SURVEY 8d -- the hoisted kernels execute "
-                                      "about 25 % fewer, so this can exceed what the pipe did); bytes = (T+2) state planes + dflow/offsets per point")
+        entry("gru_bwd", ["gru_bwd"], "data gradients (flops = the forward's un-hoisted count: the same GEMMs against transposed weights); "
+                                      "bytes = (T+2) state planes + dflow/offsets per point")
         entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = one read of the three gate-gradient planes + h|x rows per step")
         out["roofline_hbm"] = hbm
 

@@ -158,7 +158,9 @@ class ConvGRUDecoder(nn.Module):
         dflow = dflow.contiguous()
         nblocks = B * ((N + 63) // 64)
         bias_partial = torch.zeros(nblocks, 772, **f32)
-        with ops.timed("gru_bwd", flops=2.0 * B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
+        # data gradients = the forward's GEMMs against the transposed weights: the same FLOP count (the weight gradients are
+        # gru_wgrad's)
+        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
             call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
                  ptr(dpre1), ptr(xbuf), ptr(bias_partial), int(ops.MFMA_BF16), s)
         bias_g = torch.empty(772, **f32)
