@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   __shared__ int stage[CHUNK];        // cell of a bucket element -> its position after ranking
   __shared__ float spts[CHUNK * 3];   // sorted points with bucket position < CHUNK (the rest is read back from L2)
   __shared__ int misc[12];
+  __shared__ int clsw[5 * 4];      // per size class: occupied cells of each wavefront
   static_assert(CHUNK * 3 >= 256 * 8, "the statistics reduction reuses the point image");
   float* red = spts;
   const df_pillar_geom& g = q.g;
@@ -296,30 +297,54 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     if (kreg[e] >= 0) atomicAdd(&cnt[kreg[e]], 1);
   for (int i = CHUNK + threadIdx.x; i < n; i += 256) atomicAdd(&cnt[a.in_key[g0 + i] - base_key], 1);
   bar();
-  int occ_ex, occ_mask = 0;   // this thread's 8 cells: number of occupied cells before them / which of them are occupied
-  {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread), and of the occupancy flags -> occupied-cell list
+  // occupied cells are listed BY SIZE CLASS (1, 2, 3-4, 5-8, 9+ points): the 8 pillars a wavefront walks together in the
+  // pillar loop then have similar lengths, instead of every step costing the longest of 8 random pillars
+  constexpr int NCLS = 5;
+  auto size_class = [](int k) { return k <= 1 ? 0 : k == 2 ? 1 : k <= 4 ? 2 : k <= 8 ? 3 : 4; };
+  int cls_ex[NCLS];            // this thread's first slot inside each class
+  int occ_mask = 0, cell_cls = 0;   // which of this thread's 8 cells are occupied / their classes (3 bits each)
+  {  // exclusive scan of cnt -> pos0 (8 consecutive cells per thread), and of the per-class occupancy counts
     const int c0 = threadIdx.x * (BAND_CELLS / 256);
-    int loc[BAND_CELLS / 256], sum = 0, nocc = 0;
+    int loc[BAND_CELLS / 256], sum = 0, ncls[NCLS] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < BAND_CELLS / 256; ++k) {
       loc[k] = (c0 + k < ncb) ? cnt[c0 + k] : 0;
       sum += loc[k];
-      if (loc[k] > 0) { ++nocc; occ_mask |= 1 << k; }
+      if (loc[k] > 0) {
+        const int c = size_class(loc[k]);
+        occ_mask |= 1 << k;
+        cell_cls |= c << (3 * k);
+#pragma unroll
+        for (int q = 0; q < NCLS; ++q) ncls[q] += (c == q);
+      }
     }
-    int wt, wo;
+    int wt;
     int ex = wave_excl_scan(sum, lane, wt);
-    occ_ex = wave_excl_scan(nocc, lane, wo);
-    if (lane == 63) { misc[2 + wave] = wt; misc[8 + wave] = wo; }
-    bar();
-    for (int w = 0; w < wave; ++w) { ex += misc[2 + w]; occ_ex += misc[8 + w]; }
+    if (lane == 63) misc[2 + wave] = wt;
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q) {
+      int wo;
+      cls_ex[q] = wave_excl_scan(ncls[q], lane, wo);
+      if (lane == 63) clsw[q * 4 + wave] = wo;
+    }
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) ex += misc[2 + w];
+    int base = 0;   // class q starts after all cells of classes < q
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q) {
+      for (int w = 0; w < wave; ++w) cls_ex[q] += clsw[q * 4 + w];
+      cls_ex[q] += base;
+      base += clsw[q * 4] + clsw[q * 4 + 1] + clsw[q * 4 + 2] + clsw[q * 4 + 3];
+    }
+    if (threadIdx.x == 0) misc[8] = base;
 #pragma unroll
     for (int k = 0; k < BAND_CELLS / 256; ++k) {
       if (c0 + k < ncb) pos0[c0 + k] = SORT ? ex : ex + loc[k];   // !SORT: the run END right away
       ex += loc[k];
     }
   }
-  bar();
-  const int n_occ = misc[8] + misc[9] + misc[10] + misc[11];
+  __syncthreads();
+  const int n_occ = misc[8];
   float* __restrict__ op = CANVAS ? reinterpret_cast<float*>(a.out.ptr) + df_img_base(a.out, s) + (int64_t)row0 * g.gx * a.out.ld : nullptr;
   const bool prefilled = CANVAS;
   // zeros into the band's empty cells (128 B each, 8 lanes x 16 B) as soon as the histogram is known; every canvas byte is
@@ -399,12 +424,14 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // list of the band's occupied cells (the ranking scratch is free now): the pillar loop below then keeps all 32 lane
   // groups busy instead of having most of them skip empty cells while one walks a pillar
-  {
-    int o = occ_ex;
 #pragma unroll
-    for (int k = 0; k < BAND_CELLS / 256; ++k)
-      if ((occ_mask >> k) & 1) stage[o++] = threadIdx.x * (BAND_CELLS / 256) + k;
-  }
+  for (int k = 0; k < BAND_CELLS / 256; ++k)
+    if ((occ_mask >> k) & 1) {
+      const int c = (cell_cls >> (3 * k)) & 7;
+#pragma unroll
+      for (int q = 0; q < NCLS; ++q)
+        if (c == q) stage[cls_ex[q]++] = threadIdx.x * (BAND_CELLS / 256) + k;
+    }
   if (a.cell_rng)   // dense [start, end) table, 8 B per cell
     for (int cell = threadIdx.x; cell < ncb; cell += 256) {
       const int k = cnt[cell], e = pos0[cell];
