@@ -351,7 +351,11 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   // written exactly once.  Measured at B = 16 (tools/bench_pillar.py, DF_P2_DBG ablations): this stream runs at 7.5 TB/s
   // (7.8 us per pair), the pillar loop costs 4 us (VALU-bound), the sort 1.5 us, hist + scan + scatter 6.1 us -- and the
   // parts add up rather than overlap; filling after the pillar loop in every other workgroup (so that half of a CU's waves
-  // would compute while the other half stream) measured the same within noise and is not kept.
+  // would compute while the other half stream) measured the same within noise and is not kept.  Neither is carrying the
+  // zeros on the two small kernels in front (as a prologue of their workgroups: the single in-order vmcnt makes every wave
+  // wait for its zero stores before it can use a loaded point; as dedicated store-only workgroups: the kernels simply get as
+  // much longer as the stream takes, 5.1 TB/s there) with this kernel writing occupied cells only: 27.7-28.8 us per pair
+  // against 23.4 -- kernel-trace: hist 19 -> 144 us, this kernel 278 -> 147 us, nothing overlapped.
   if (CANVAS && !(a.dbg & 2)) {
     const int zg = threadIdx.x >> 3, zs = threadIdx.x & 7;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -455,7 +459,11 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       else { const float* gq = gpts + (g0 + i) * 3; p[0] = gq[0]; p[1] = gq[1]; p[2] = gq[2]; }
     };
     float mx, my, mz, ctx, cty, ctz;
-    {  // pillar mean: plain left-to-right sums in input order, as pfn_mean (csrc/pillar_common.h) does
+    if (k == 1) {   // ~45 % of the pillars: the mean IS the point (x / 1 = x exactly) -- no sum loop, no IEEE divisions
+      float p[3];
+      ld(b, p);
+      mx = p[0]; my = p[1]; mz = p[2];
+    } else {  // pillar mean: plain left-to-right sums in input order, as pfn_mean (csrc/pillar_common.h) does
       float sx = 0.f, sy = 0.f, sz = 0.f;
       for (int i = b; i < e; ++i) { float p[3]; ld(i, p); sx += p[0]; sy += p[1]; sz += p[2]; }
       const float inv = (float)k;
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       }
     }
     if (CANVAS) {
-      if (a.mode == 0) {
+      if (a.mode == 0 && k > 1) {
         const float cntf = (float)k;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) r[kk] = r[kk] / cntf;

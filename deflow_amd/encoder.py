@@ -140,6 +140,11 @@ class DynamicEmbedder(nn.Module):
         R = call("df_pillar2_rows_per_band", H, W)
         if R <= 0:
             raise RuntimeError(f"pillarise: a {H}x{W} grid is not supported (rows wider than 2048 cells)")
+        # few samples (B = 1 inference: S = 2): thinner bands, so that the band kernel still has >= ~2048 workgroups to spread
+        # over the 256 CUs (one workgroup per (band, sample); its latency chain shortens with the band)
+        rmin = int(os.environ.get("DF_P2_MIN_WGS", "2048"))
+        while R > 1 and S * ((H + R - 1) // R) < rmin and (H + R // 2 - 1) // (R // 2) <= 512:
+            R //= 2
         NB = (H + R - 1) // R
         ncol = NB + 1
         nblk = (N + call("df_pillar2_tile") - 1) // call("df_pillar2_tile")
