@@ -369,6 +369,30 @@ def main():
                                  "frac_mfma_bf16": 1564e9 / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                  "frac_hbm": 3.85e9 / (bf_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
         del big, bb
+        # ... and the TRAINING step at that shape (configs[4]: "1024x1024 BEV grid, 160k-pt pair, 8 GRU iters, bf16 MFMA"): 4 pairs
+        # per GPU (the activation footprint of 16 pairs at 512x512), fp32 and bf16 MFMA, same Trainer
+        del trainer, model
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        big = deflow_amd.DeFlow(voxel_size=[0.1, 0.1, 6], grid_feature_size=[1024, 1024], num_iters=8).to(dev).train()
+        tb = Trainer(big, lr=2e-4)
+        bb = synth_batch(4, 160000, seed=20240116, device=dev)
+        res4 = {}
+        for name, flag in (("fp32", False), ("bf16", True)):
+            tb.mfma_bf16 = flag
+            for _ in range(2):
+                tb.step(bb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                l4 = tb.step(bb)
+            torch.cuda.synchronize()
+            res4[name] = (time.perf_counter() - t1) / 3 * 1e3
+        out["bf16_training"]["configs4_shape"] = {
+            "workload": "train step, 4 pairs per GPU, 160000 pts/cloud, 1024x1024, 8 GRU iters (BASELINE configs[4] per GPU)",
+            "fp32_ms_per_step": res4["fp32"], "bf16_ms_per_step": res4["bf16"], "bf16_pairs_per_s": 4e3 / res4["bf16"],
+            "speedup_vs_fp32": res4["fp32"] / res4["bf16"], "loss": float(l4)}
+        del big, bb, tb
     if use_dist:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:

@@ -394,6 +394,39 @@ def test_pillar_bands_equal_first_generation(dev, monkeypatch, S, N, grid, ext, 
         assert torch.equal(c2, c1)
 
 
+@pytest.mark.parametrize("H,W,N", [(40, 72, 5000), (104, 24, 3000), (8, 1000, 4097)])
+def test_pillar_bands_rectangular_grids(dev, monkeypatch, H, W, N):
+    """non-square grids whose height is not a multiple of the band height, a width that is not a power of two, a single-band
+    grid: both generations must agree bit for bit (eval) and no canvas byte may stay unwritten"""
+    from deflow_amd.encoder import DynamicEmbedder
+    from deflow_amd._lib import img
+    vs, rng = [0.2, 0.2, 6], [-0.1 * W, -0.1 * H, -3, 0.1 * W, 0.1 * H, 3]
+    g = torch.Generator().manual_seed(H * W)
+    pts = torch.cat([(torch.rand(3, N, 1, generator=g) - 0.5) * 0.22 * W, (torch.rand(3, N, 1, generator=g) - 0.5) * 0.22 * H,
+                     torch.rand(3, N, 1, generator=g) * 6.6 - 3.3], 2)
+    pts[:, -N // 40:] = float("nan")
+    res = []
+    for v1 in (False, True):
+        if v1:
+            monkeypatch.setenv("DF_PILLAR_V1", "1")
+        else:
+            monkeypatch.delenv("DF_PILLAR_V1", raising=False)
+        torch.manual_seed(9)
+        emb = DynamicEmbedder(vs, [H, W], rng, 32).to(dev).eval()
+        canvas = torch.zeros(3, H, W, 32, device=dev) if v1 else torch.full((3, H, W, 32), float("nan"), device=dev)
+        with torch.no_grad():
+            st = emb.pillarize(pts.to(dev), img(canvas), False)
+        torch.cuda.synchronize()
+        res.append((st, canvas))
+    monkeypatch.delenv("DF_PILLAR_V1", raising=False)
+    (s2, c2), (s1, c1) = res
+    tot = int(s1.counts.sum())
+    assert tot > N and torch.equal(s2.counts, s1.counts)
+    assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
+    assert torch.equal(s2.cell_rng, s1.cell_rng) and torch.equal(s2.coords_c[0, :int(s1.counts[0])], s1.coords_c[0, :int(s1.counts[0])])
+    assert torch.isfinite(c2).all() and torch.equal(c2, c1)
+
+
 def test_pillar_bands_degenerate_clouds(dev, monkeypatch):
     """buckets far beyond the LDS chunk (5000 points in ONE cell, 3000 in one row), an all-NaN sample, a sample with a
     single point, max mode, and the merged two-cloud image layout"""

@@ -550,6 +550,67 @@ def test_bf16_training_trajectory(dev):
     assert ops.MFMA_BF16 is False, "the switch must not leak out of Trainer.step"
 
 
+def test_configs4_shape_training_step(dev):
+    """BASELINE configs[4] as a TRAINING shape: 1024 x 1024 grid (voxel 0.1 m), 160 000 points per cloud, 8 GRU iterations, one
+    pair.  fp32 step against the fp32 oracle (loss 1e-4, every parameter gradient 2e-4 -- the fp64 twin of this shape costs
+    minutes); then the same step with dtype=bf16 against the fp32 HIP step: loss within 2e-2, every gradient finite and
+    pointing the same way (cosine > 0.99 per tensor except the BatchNorm-shadowed biases, whose true value is 0)."""
+    import deflow_amd
+    import parity
+    from oracle import ref_torch as O
+    from deflow_amd import ops
+    from deflow_amd.synth import synth_pair
+    cfg = dict(voxel_size=[0.1, 0.1, 6], grid_feature_size=[1024, 1024], num_iters=8)
+    torch.manual_seed(46)
+    ref = O.DeFlow(**cfg)
+    mine = deflow_amd.DeFlow(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    ref.train(); mine.train()
+    p = synth_pair(78, 160000)
+    batch = {"pc0": p[0][None], "pc1": p[1][None], "pose0": torch.eye(4)[None], "pose1": torch.linalg.inv(p[2])[None],
+             "ego_motion": p[2][None], "flow": p[3][None]}
+    res_r = ref(batch)
+    loss_r = O.training_loss(res_r, batch)
+    loss_r.backward()
+    bd = to_dev(batch, dev)
+    res_m = mine(bd)
+    loss_m = O.training_loss(res_m, bd)
+    loss_m.backward()
+    check("configs[4]-shape train flow", res_m["flow"][0], res_r["flow"][0], 2e-4)
+    check("configs[4]-shape train loss", loss_m.reshape(1), loss_r.reshape(1), 1e-4)
+    pr = dict(ref.named_parameters())
+    g32, worst = {}, 0.0
+    for k, q in mine.named_parameters():
+        g32[k] = q.grad.detach().clone()
+        if parity.is_bn_shadowed_bias(k):
+            continue
+        e = rel_err(q.grad, pr[k].grad)
+        worst = max(worst, e)
+        parity.record("cfg4_train", "grad " + k, err_hip_vs_oracle32=e, bound=2e-4, ok=e <= 2e-4)
+        assert e <= 2e-4, (k, e)
+    print(f"[parity] configs[4]-shape training step: worst parameter-gradient error vs fp32 oracle {worst:.2e}")
+    mine.zero_grad(set_to_none=True)
+    with ops.mfma_bf16(True):
+        res_b = mine(bd)
+        loss_b = O.training_loss(res_b, bd)
+        loss_b.backward()
+    torch.cuda.synchronize()
+    e = abs(float(loss_b) - float(loss_m)) / abs(float(loss_m))
+    print(f"[parity] configs[4]-shape bf16 step: loss {float(loss_b):.5f} vs fp32 {float(loss_m):.5f} (rel {e:.2e})")
+    assert e <= 2e-2
+    worst_cos = 1.0
+    for k, q in mine.named_parameters():
+        assert torch.isfinite(q.grad).all(), k
+        if parity.is_bn_shadowed_bias(k):
+            continue
+        a, b = q.grad.flatten().double(), g32[k].flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        worst_cos = min(worst_cos, cos)
+        assert cos > 0.99, (k, cos)
+    print(f"[parity] configs[4]-shape bf16 step: worst gradient cosine vs fp32 {worst_cos:.5f}")
+
+
 def test_train_mode_forward_without_grad_is_repeatable():
     """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
     (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
@@ -1013,5 +1074,5 @@ def test_bench_line_contract(dev):
     for k in ("pillarise_fwd", "bn_gelu_apply", "bn_gelu_bwd", "gru_fwd", "gru_bwd", "gru_wgrad", "pillarise_fwd_inference_b16"):
         assert k in d["roofline_hbm"] and 0 < d["roofline_hbm"][k]["frac"] < 1.2, k
     assert d["forward_only"]["ms_per_pair"] > 0 and d["bf16_inference"]["ms_per_pair"] > 0
-    assert d["bf16_training"]["speedup_vs_fp32"] > 1.2
+    assert d["bf16_training"]["speedup_vs_fp32"] > 1.2 and d["bf16_training"]["configs4_shape"]["bf16_ms_per_step"] > 0
     assert "cpu_baseline" not in d   # --no-cpu-baseline
