@@ -192,3 +192,44 @@ def test_scatter_max_restatement_selects_first_maximal_point():
             hit = torch.nonzero(gy[members, c]).flatten()
             first = int(torch.nonzero(y[members, c] == want[c]).flatten()[0])
             assert hit.tolist() == [first], (p, c)
+
+
+@pytest.mark.parametrize("iters", [1, 4, 8])
+def test_f64_twins_pin_the_oracle_in_double(golden_dir, iters):
+    """tests/golden/*_f64.npz = the REAL reference classes executed in float64 (oracle/gen_golden_f64.py).  The oracle in
+    double must reproduce them to round-off -- this pins the fp64 yardstick the GPU tests measure both fp32 sides against."""
+    g = _load(golden_dir, f"g2_grudecoder_it{iters}.npz")
+    g64 = _load(golden_dir, f"g2_grudecoder_it{iters}_f64.npz")
+    m = O.ConvGRUDecoder(num_iters=iters)
+    _load_w(m, g)
+    m = m.double()
+    before = _t(g["before"]).double().requires_grad_(True)
+    after = _t(g["after"]).double().requires_grad_(True)
+    infos = [{"voxel_coords": _t(g[f"vc{i}"]), "point_offsets": _t(g[f"off{i}"]).double()} for i in range(3)]
+    flows = m(before, after, infos)
+    for i, f in enumerate(flows):
+        assert g64[f"flow{i}"].dtype == np.float64
+        _close(f, g64[f"flow{i}"], rtol=1e-11, atol=1e-13)
+    sum((f * _t(g[f"gflow{i}"]).double()).sum() for i, f in enumerate(flows)).backward()
+    _close(before.grad, g64["gbefore"], rtol=1e-10, atol=1e-13)
+    for k, p in m.named_parameters():
+        _close(p.grad, g64["gw." + k], rtol=1e-10, atol=1e-12)
+    # and the fp32 golden sits where fp32 arithmetic should: ~1e-7 .. 1e-6 from the double result
+    e = float(np.abs(g["flow0"].astype(np.float64) - g64["flow0"]).max() / np.abs(g64["flow0"]).max())
+    assert 0 < e < 1e-5, e
+
+
+@pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1", "skip1x1"])
+def test_f64_twin_convwithnorms(golden_dir, tag):
+    g = _load(golden_dir, f"g4_convwithnorms_{tag}.npz")
+    g64 = _load(golden_dir, f"g4_convwithnorms_{tag}_f64.npz")
+    cin, cout = g["w0.conv.weight"].shape[1], g["w0.conv.weight"].shape[0]
+    m = O.ConvWithNorms(cin, cout, int(g["k"]), int(g["s"]), int(g["p"]))
+    _load_w(m, g, "w0.")
+    m = m.double().train(bool(g["train"]))
+    x = _t(g["x"]).double().requires_grad_(True)
+    y = m(x)
+    _close(y, g64["y"], rtol=1e-11, atol=1e-13)
+    y.backward(_t(g["gy"]).double())
+    _close(x.grad, g64["gx"], rtol=1e-10, atol=1e-13)
+    _close(m.batchnorm.running_var, g64["running_var"], rtol=1e-12, atol=1e-14)
