@@ -281,7 +281,8 @@ def test_convwithnorms_golden(dev, golden_dir, tag):
     tape = []
     _cwn_forward(m, img(xd), img(z), n, 1, bool(g["train"]), tape)
     _, _, _, yc, bn_ss, ipg, groups, frozen = tape[0]
-    dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(nhwc(t(g["gy"])).to(dev)), yc, bn_ss, ipg, groups, frozen=frozen)
+    gzd = nhwc(t(g["gy"])).to(dev)    # keep it alive: img() holds a raw pointer, a temporary's block would be handed to `dy`
+    dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(gzd), yc, bn_ss, ipg, groups, frozen=frozen)
     wd = ops.ohwi(m.conv.weight)
     dx = torch.empty_like(xd)
     ops.conv2d(img(dy), ops.weight_transpose(wd), None, img(dx), 3, m.stride, mode=ops.CONV_DGRAD)
