@@ -87,7 +87,7 @@ def test_conv_pair_views_and_accumulate(dev):
     out2 = base.to(dev).clone()
     ops.conv2d(img_pair(catd, 32), ops.ohwi(wd), b.to(dev), img_pair(out2, 64), 3, 1, accumulate=True)
     got2 = torch.cat([out2[..., :64], out2[..., 64:]], 0).cpu() - torch.cat([base[..., :64], base[..., 64:]], 0)
-    check("conv accumulate", nchw(got2), want, tol=5e-4)
+    check("conv accumulate", nchw(got2), want, tol=1e-4)   # (the difference of two ~N(0,1)+conv values: one extra fp32 rounding)
 
 
 @pytest.mark.parametrize("cin,cout,k,s,n,h,w", [(64, 64, 3, 1, 2, 16, 16), (32, 64, 3, 2, 2, 16, 16), (64, 128, 3, 2, 1, 32, 16),
@@ -208,7 +208,10 @@ def test_conv_bf16_operand_mode(dev, cin, cout, k, s, n, h, w):
 # ---------------------------------------------------------------------------- BN + GELU -----------
 @pytest.mark.parametrize("groups", [1, 2])
 def test_convwithnorms_train_fwd_bwd(dev, groups):
-    """conv + BatchNorm2d(batch stats, per group) + GELU, forward, running stats and full backward"""
+    """conv + BatchNorm2d(batch stats, per group) + GELU, forward, running stats and full backward; every tensor against the
+    oracle in fp32 AND in float64 (three-way bound of tests/parity.py)"""
+    import copy
+    import parity
     from deflow_amd import ops
     from deflow_amd.unet import ConvWithNorms, _cwn_forward
     from deflow_amd._lib import img
@@ -218,34 +221,39 @@ def test_convwithnorms_train_fwd_bwd(dev, groups):
     ref = O.ConvWithNorms(cin, cout, 3, 1, 1).train()
     with torch.no_grad():
         ref.batchnorm.weight.uniform_(0.5, 1.5); ref.batchnorm.bias.uniform_(-0.3, 0.3)
+    ref64 = copy.deepcopy(ref).double()
     mine = ConvWithNorms(cin, cout, 3, 1, 1).train()
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(dev)
     x = torch.randn(n, cin, h, w, requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
     ipg = n // groups
-    outs = [ref(x[g * ipg:(g + 1) * ipg]) for g in range(groups)]  # one reference call per group, in order
-    want = torch.cat(outs, 0)
+    want = torch.cat([ref(x[g * ipg:(g + 1) * ipg]) for g in range(groups)], 0)  # one reference call per group, in order
+    want64 = torch.cat([ref64(x64[g * ipg:(g + 1) * ipg]) for g in range(groups)], 0)
     gz = torch.randn(want.shape)
     want.backward(gz)
+    want64.backward(gz.double())
     xd = nhwc(x.detach()).to(dev)
     z = torch.empty(n, h, w, cout, device=dev)
     tape = []
     _cwn_forward(mine, img(xd), img(z), n, groups, True, tape)
-    check(f"cwn train fwd g{groups}", nchw(z), want)
-    check("running_mean", mine.batchnorm.running_mean, ref.batchnorm.running_mean)
-    check("running_var", mine.batchnorm.running_var, ref.batchnorm.running_var)
+    name = f"cwn_train_g{groups}"
+    parity.three_way(name, "z", nchw(z), want, want64)
+    parity.three_way(name, "running_mean", mine.batchnorm.running_mean, ref.batchnorm.running_mean, ref64.batchnorm.running_mean)
+    parity.three_way(name, "running_var", mine.batchnorm.running_var, ref.batchnorm.running_var, ref64.batchnorm.running_var)
     _, m, xi, y, bn_ss, ipg_, groups_, _frozen = tape[0]
-    dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(nhwc(gz).to(dev)), y, bn_ss, ipg_, groups_)
+    gzd = nhwc(gz).to(dev)           # kept alive: img() holds a raw pointer
+    dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(gzd), y, bn_ss, ipg_, groups_)
     wd = ops.ohwi(mine.conv.weight)
     dx = torch.empty_like(xd)
     ops.conv2d(img(dy), ops.weight_transpose(wd), None, img(dx), 3, 1, mode=ops.CONV_DGRAD)
     dw = torch.empty_like(wd)
     ops.conv2d_wgrad(img(xd), img(dy), 3, 1, dw)
-    check("cwn dx", nchw(dx), x.grad, tol=5e-4)
-    check("cwn dW", dw.permute(0, 3, 1, 2), ref.conv.weight.grad, tol=5e-4)
-    check("cwn dgamma", dgamma, ref.batchnorm.weight.grad, tol=5e-4)
-    check("cwn dbeta", dbeta, ref.batchnorm.bias.grad, tol=5e-4)
-    assert float(dbias.abs().max()) <= 1e-3 * float(gz.abs().sum())  # mathematically zero under BatchNorm
+    parity.three_way(name, "dx", nchw(dx), x.grad, x64.grad)
+    parity.three_way(name, "dW", dw.permute(0, 3, 1, 2), ref.conv.weight.grad, ref64.conv.weight.grad)
+    parity.three_way(name, "dgamma", dgamma, ref.batchnorm.weight.grad, ref64.batchnorm.weight.grad)
+    parity.three_way(name, "dbeta", dbeta, ref.batchnorm.bias.grad, ref64.batchnorm.bias.grad)
+    assert float(dbias.abs().max()) <= 1e-6 * float(dy.abs().sum())  # exactly zero under BatchNorm (fp64 oracle: ~1e-17)
 
 
 @pytest.mark.parametrize("tag", ["train_s1", "train_s2", "eval_s1", "skip1x1"])
@@ -488,12 +496,16 @@ def test_pillar_bands_degenerate_clouds(dev, monkeypatch):
 
 
 def test_pillarize_backward(dev):
+    """pillar feature net backward (dW, dgamma, dbeta) against the oracle in fp32 and float64 (three-way bound)"""
+    import copy
+    import parity
     from deflow_amd.encoder import DynamicEmbedder
     from deflow_amd._lib import img
     from oracle import ref_torch as O
     vs, rng, dims = [0.2, 0.2, 6], [-6.4, -6.4, -3, 6.4, 6.4, 3], [64, 64]
     torch.manual_seed(22)
     ref = O.DynamicEmbedder(vs, dims, rng, 32).train()
+    ref64 = copy.deepcopy(ref).double()
     mine = DynamicEmbedder(vs, dims, rng, 32).train()
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(dev)
@@ -501,13 +513,17 @@ def test_pillarize_backward(dev):
     out, _ = ref(pts)
     gout = torch.randn(out.shape)
     out.backward(gout)
+    out64, _ = ref64(pts.double())
+    out64.backward(gout.double())
     canvas = torch.zeros(2, 64, 64, 32, device=dev)
     st = mine.pillarize(pts.to(dev), img(canvas), True)
-    dW, dgamma, dbeta = mine.pillarize_bwd(st, img(nhwc(gout).to(dev)), None)
-    lin, bn = ref.feature_net.pfn_layers[0][0], ref.feature_net.pfn_layers[0][1]
-    check("pfn dW", dW, lin.weight.grad, tol=5e-4)
-    check("pfn dgamma", dgamma, bn.weight.grad, tol=5e-4)
-    check("pfn dbeta", dbeta, bn.bias.grad, tol=5e-4)
+    parity.three_way("pfn", "canvas", nchw(canvas), out, out64)
+    goutd = nhwc(gout).to(dev)       # kept alive: img() holds a raw pointer
+    dW, dgamma, dbeta = mine.pillarize_bwd(st, img(goutd), None)
+    for k, got in (("0.weight", dW), ("1.weight", dgamma), ("1.bias", dbeta)):
+        p32 = dict(ref.feature_net.pfn_layers[0].named_parameters())[k]
+        p64 = dict(ref64.feature_net.pfn_layers[0].named_parameters())[k]
+        parity.three_way("pfn", "grad " + k, got, p32.grad, p64.grad)
 
 
 # ---------------------------------------------------------------------------- decoder -------------
