@@ -247,8 +247,11 @@ struct P2Band {
   int dbg;   // timing ablations (env DF_P2_DBG): bit 0 = no pillar loop, bit 1 = no zero stores, bit 2 = no sort / copy
 };
 
-template <bool SORT, bool STATS, bool CANVAS>
+// BC = LDS cell-table size (cells per band <= BC): 2048, or 1024 for thin bands -- 24.7 KB of LDS instead of 32.9, i.e. 6
+// instead of 4 resident workgroups per CU
+template <bool SORT, bool STATS, bool CANVAS, int BC = BAND_CELLS>
 __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
+  constexpr int BAND_CELLS = BC;      // (shadows the file-level maximum inside this kernel)
   __shared__ int cnt[BAND_CELLS];     // points per cell of the band
   __shared__ int pos0[BAND_CELLS];    // running / final END position of each cell's run, relative to the bucket
   __shared__ int stage[CHUNK];        // cell of a bucket element -> its position after ranking
@@ -598,9 +601,16 @@ extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, c
   a.dbg = dbg;
   const dim3 grid(q.NB, S);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (sort && canvas) hipLaunchKernelGGL((p2_band_kernel<true, false, true>), grid, dim3(256), 0, st, a, q);
-  else if (sort) hipLaunchKernelGGL((p2_band_kernel<true, true, false>), grid, dim3(256), 0, st, a, q);
-  else hipLaunchKernelGGL((p2_band_kernel<false, false, true>), grid, dim3(256), 0, st, a, q);
+  const bool thin = (int64_t)q.R * g.gx <= 1024;
+  if (thin) {
+    if (sort && canvas) hipLaunchKernelGGL((p2_band_kernel<true, false, true, 1024>), grid, dim3(256), 0, st, a, q);
+    else if (sort) hipLaunchKernelGGL((p2_band_kernel<true, true, false, 1024>), grid, dim3(256), 0, st, a, q);
+    else hipLaunchKernelGGL((p2_band_kernel<false, false, true, 1024>), grid, dim3(256), 0, st, a, q);
+  } else {
+    if (sort && canvas) hipLaunchKernelGGL((p2_band_kernel<true, false, true>), grid, dim3(256), 0, st, a, q);
+    else if (sort) hipLaunchKernelGGL((p2_band_kernel<true, true, false>), grid, dim3(256), 0, st, a, q);
+    else hipLaunchKernelGGL((p2_band_kernel<false, false, true>), grid, dim3(256), 0, st, a, q);
+  }
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
