@@ -359,12 +359,14 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   // wait for its zero stores before it can use a loaded point; as dedicated store-only workgroups: the kernels simply get as
   // much longer as the stream takes, 5.1 TB/s there) with this kernel writing occupied cells only: 27.7-28.8 us per pair
   // against 23.4 -- kernel-trace: hist 19 -> 144 us, this kernel 278 -> 147 us, nothing overlapped.
-  if (CANVAS && !(a.dbg & 2)) {
-    const int zg = threadIdx.x >> 3, zs = threadIdx.x & 7;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int c = zg; c < ncb; c += 32)
-      if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * zs, z);
-  }
+  // SQ counters (profiles/r02_pmc_band.txt): waves wait 53 % of their cycles, VALU 34 % busy.  A wave that streams zeros is
+  // stuck in its store loop -- 64 stores fill the vmcnt window, every further one waits for HBM -- so the stream is given to
+  // ONE wavefront, after the last barrier, while the other three walk the pillars (see below).  That, too, measures the same
+  // (22.7-23.6 us; ablations unchanged: no zero stores 14.4, no pillar loop 20.1, neither 8.9): while the chip's HBM queues
+  // are full of the 58 MB-per-pair zero stream, every workgroup's two dependent global round trips at its start (bucket
+  // table, then bucket contents) take several times longer, so the stream's 9 us are paid on top of the rest wherever the
+  // stores are issued from.  Hiding them needs another, compute-bound kernel running beside (the UNet of the previous
+  // forward on a second stream) -- not done.
   if (SORT && !(a.dbg & 4)) {
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
       const int m = min(CHUNK, n - c0);
@@ -453,7 +455,19 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       if (cnt[cell] == 0) st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
   }
   bar();
-  for (int oi = grp; oi < ((a.dbg & 1) ? 0 : n_occ); oi += 32) {
+  // ---- from here on no workgroup barrier (canvas kernels): wave 3 streams the zeros of the band's empty cells (128 B each,
+  // 8 lanes x 16 B; every canvas byte is written exactly once) while waves 0-2 walk the pillars
+  const int ngrp = CANVAS ? 24 : 32;
+  if (CANVAS && wave == 3) {
+    if (!(a.dbg & 2)) {
+      const int zg = lane >> 3;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int c = zg; c < ncb; c += 8)
+        if (cnt[c] == 0) st4(op + (int64_t)c * a.out.ld + 4 * sub, z);
+    }
+    return;
+  }
+  for (int oi = grp; oi < ((a.dbg & 1) ? 0 : n_occ); oi += ngrp) {
     const int cell = stage[oi];
     const int k = cnt[cell];
     const int e = pos0[cell], b = e - k;
