@@ -311,6 +311,20 @@ def main():
                 trainer.step(batch)
             dtb, _, lossb = timed_steps(args.steps)
             trainer.mfma_bf16 = False
+            # the same bf16 step replayed as ONE captured HIP graph (Trainer.capture): host-free steps
+            trainer.capture(batch)
+            for _ in range(2):
+                trainer.step_captured()
+            barrier()
+            tg0 = time.perf_counter()
+            for _ in range(args.steps):
+                trainer.step_captured()
+            host_ms = (time.perf_counter() - tg0) / args.steps * 1e3
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - tg0) / args.steps * 1e3
+            trainer.mfma_bf16 = False
+            out["hip_graph"] = {"workload": "the bf16 step above as one captured HIP graph (Trainer.capture / step_captured)",
+                                "ms_per_step": graph_ms, "host_ms_per_step": host_ms, "eager_ms_per_step": dtb / args.steps * 1e3}
             out["bf16_training"] = {"workload": "the headline step with dtype=bf16 (bf16 MFMA operands in every UNet conv fwd/dgrad/wgrad and every "
                                                 "decoder GEMM, fp32 accumulate, fp32 tensors + master weights + GRU state)",
                                     "ms_per_step": dtb / args.steps * 1e3, "pairs_per_s": args.batch * args.steps / dtb,

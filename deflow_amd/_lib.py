@@ -103,6 +103,7 @@ _SIGS = {
     "df_deflow_loss_bwd": [P, P, P, I, I, P, P, F, P, I, P],
     "df_gather_gt": [P, P, P, P, I, I, P, I, P],
     "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
+    "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
 _RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
 _RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status

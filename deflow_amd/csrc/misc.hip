@@ -133,10 +133,17 @@ __global__ __launch_bounds__(256) void gather_gt_kernel(const float* __restrict_
   }
 }
 
+// step_dev != nullptr: the step number is read from device memory and the bias corrections are computed here (double, as
+// on the host) -- the form a captured HIP graph replays, where a host-side step count would be frozen at capture time
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                   float gscale) {
+                                                   float gscale, const int32_t* __restrict__ step_dev) {
+  if (step_dev) {
+    const double st = (double)*step_dev;
+    bc1 = (float)(1.0 - pow((double)b1, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
 #pragma unroll
@@ -201,6 +208,19 @@ extern "C" int df_gather_gt(const float* flow, const float* pose_flow, const int
   return DF_OK;
 }
 
+extern "C" int df_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                float beta1, float beta2, float eps, const int32_t* step_dev, float grad_scale, void* stream) {
+  DF_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && n > 0 && (n % 4) == 0, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(param) && df_aligned16(grad) && df_aligned16(exp_avg) && df_aligned16(exp_avg_sq), DF_E_ALIGN);
+  const int64_t n4 = n / 4;
+  int64_t grid = (n4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad,
+                     exp_avg, exp_avg_sq, n4, lr, beta1, beta2, eps, 1.f, 1.f, grad_scale, step_dev);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 extern "C" int df_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                             float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
   DF_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && (n % 4) == 0 && step >= 1, DF_E_ARG);
@@ -211,7 +231,8 @@ extern "C" int df_adam_step(float* param, const float* grad, float* exp_avg, flo
   int64_t grid = (n4 + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad,
-                     exp_avg, exp_avg_sq, n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     exp_avg, exp_avg_sq, n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale,
+                     (const int32_t*)nullptr);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -340,6 +340,10 @@ int df_gather_gt(const float* flow, const float* pose_flow, const int64_t* idx_c
  * parameter; grad/exp_avg/exp_avg_sq are arenas of the same layout.  n % 4 == 0. */
 int df_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                  float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* the same step with the step number read from device memory (*step_dev >= 1, incremented by the caller before the
+ * launch): the form that can be captured in a HIP graph and replayed -- nothing about the step is a host-side constant */
+int df_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, const int32_t* step_dev, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -611,6 +611,41 @@ def test_configs4_shape_training_step(dev):
     print(f"[parity] configs[4]-shape bf16 step: worst gradient cosine vs fp32 {worst_cos:.5f}")
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_captured_step_equals_eager(dev, dtype):
+    """Trainer.capture / step_captured: the whole training step (forward, loss, hand-sequenced backward, Adam -- several
+    hundred launches) replayed as ONE HIP graph on new batches must leave the parameters, the Adam moments and the losses an
+    eager Trainer leaves (the engine is deterministic; Adam's step number lives on the device in the captured form)."""
+    import deflow_amd
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+
+    def fresh():
+        torch.manual_seed(77)
+        m = deflow_amd.DeFlow(**SMALL, num_iters=2).to(dev).train()
+        return m, Trainer(m, lr=1e-3, dtype=dtype)
+
+    bs = [synth_batch(2, 1500, seed=300 + i, grid_hw=(64, 64), device=dev) for i in range(2)]
+    seq = [bs[1], bs[0], bs[1], bs[1]]
+    m1, t1 = fresh()
+    for _ in range(2):
+        t1.step(bs[0])                      # = the two warm-up steps capture() runs
+    want = [float(t1.step(b)) for b in seq]
+    m2, t2 = fresh()
+    t2.capture(bs[0])
+    got = [float(t2.step_captured(b)) for b in seq]
+    torch.cuda.synchronize()
+    assert t2.opt.step_count == t1.opt.step_count == 6 and int(t2.opt.step_dev) == 6
+    print(f"[parity] captured vs eager losses ({dtype}):", [f"{g:.6f}/{w:.6f}" for g, w in zip(got, want)])
+    assert got == want, (got, want)
+    check("captured params", t2.flat.param, t1.flat.param, 1e-6)
+    check("captured exp_avg_sq", t2.opt.exp_avg_sq, t1.opt.exp_avg_sq, 1e-6)
+    for (k, a), (_, b) in zip(m2.named_buffers(), m1.named_buffers()):
+        assert torch.equal(a, b), k          # BatchNorm running statistics and counters moved inside the graph too
+    with pytest.raises(ValueError):
+        t2.step_captured(synth_batch(2, 1400, seed=1, grid_hw=(64, 64), device=dev))
+
+
 def test_train_mode_forward_without_grad_is_repeatable():
     """model.train() under torch.no_grad() keeps no tape: layer outputs must still outlive the kernels that read them
     (regression: the UNet freed each activation as soon as the next layer's buffers were allocated, and the allocator
