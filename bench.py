@@ -310,7 +310,6 @@ def main():
             for _ in range(2):
                 trainer.step(batch)
             dtb, _, lossb = timed_steps(args.steps)
-            trainer.mfma_bf16 = False
             # the same bf16 step replayed as ONE captured HIP graph (Trainer.capture): host-free steps
             trainer.capture(batch)
             for _ in range(2):

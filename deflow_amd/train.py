@@ -25,7 +25,7 @@ import torch
 DEFAULTS: Dict[str, Any] = {
     "model": "deflow", "lr": 2e-4, "epochs": 1, "batch_size": 16, "loss_fn": "deflowLoss", "num_workers": 0,
     "voxel_size": [0.2, 0.2, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
-    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dtype": "fp32", "dist_backend": "nccl", "resume": False,
+    "model.target.num_iters": 4, "model.target.decoder_option": "gru", "gradient_clip_val": 0.0, "sync_bn": False, "dtype": "fp32", "graph": False, "dist_backend": "nccl", "resume": False,
     "train_data": "synthetic", "val_data": "synthetic", "pairs_per_epoch": 64, "points_per_cloud": 80000,
     "stage_dir": "", "checkpoint": "", "save_checkpoint": "", "seed": 20240116, "wandb_mode": "disabled", "slurm_id": "", "log_every": 50,   # Lightning's log_every_n_steps default; each log line syncs
 }
@@ -140,12 +140,25 @@ def main(argv=None):
         train_loader, train_sampler = scene_loader(str(cfg["train_data"]), shuffle=True)
     if cfg["val_data"] != "synthetic":
         val_loader, _ = scene_loader(str(cfg["val_data"]), shuffle=False)
+    use_graph = str(cfg["graph"]).lower() in ("1", "true") and world == 1 and float(cfg["gradient_clip_val"]) == 0.0
     gstep, log_step, log_t = gstep0, gstep0, time.perf_counter()
     for epoch in range(start_epoch, int(cfg["epochs"])):
         if train_loader is not None:
             train_sampler.set_epoch(epoch)
         for batch in (train_loader if train_loader is not None else synthetic_epoch(epoch)):
-            loss = trainer.step(batch)
+            if use_graph:
+                # graph=true: the step is captured once as a HIP graph (on the first batch, which thereby also serves as the two
+                # warm-up steps capture needs) and replayed for every batch of the same shapes; other shapes run eagerly
+                if getattr(trainer, "_graph", None) is None:
+                    trainer.capture(batch)
+                    loss = trainer._graph_loss
+                else:
+                    try:
+                        loss = trainer.step_captured(batch)
+                    except ValueError:
+                        loss = trainer.step(batch)
+            else:
+                loss = trainer.step(batch)
             gstep += 1
             if rank == 0 and gstep % int(cfg["log_every"]) == 0:
                 lv = float(loss)  # reads the loss back: the only host sync of the loop, so the rate below is a true one

@@ -1109,4 +1109,5 @@ def test_bench_line_contract(dev):
         assert k in d["roofline_hbm"] and 0 < d["roofline_hbm"][k]["frac"] < 1.2, k
     assert d["forward_only"]["ms_per_pair"] > 0 and d["bf16_inference"]["ms_per_pair"] > 0
     assert d["bf16_training"]["speedup_vs_fp32"] > 1.2 and d["bf16_training"]["configs4_shape"]["bf16_ms_per_step"] > 0
+    assert d["hip_graph"]["host_ms_per_step"] < 5.0 and d["hip_graph"]["ms_per_step"] < 1.1 * d["hip_graph"]["eager_ms_per_step"]
     assert "cpu_baseline" not in d   # --no-cpu-baseline
