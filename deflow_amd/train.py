@@ -151,7 +151,7 @@ def main(argv=None):
                 # warm-up steps capture needs) and replayed for every batch of the same shapes; other shapes run eagerly
                 if getattr(trainer, "_graph", None) is None:
                     trainer.capture(batch)
-                    loss = trainer._graph_loss
+                    loss = trainer.step_captured()      # (capture records the launches, it does not run them)
                 else:
                     try:
                         loss = trainer.step_captured(batch)

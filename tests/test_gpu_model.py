@@ -379,6 +379,14 @@ def test_trainer_learns_and_cli_runs(dev, tmp_path):
     m2 = deflow_amd.DeFlow(**SMALL, num_iters=2)
     r = m2.load_from_checkpoint(ck)
     assert not r.missing_keys and not r.unexpected_keys
+    # the same command with the step captured as a HIP graph and bf16 MFMA operands (synthetic batches have constant shapes)
+    ck2 = os.path.join(tmp_path, "cli_graph.ckpt")
+    T.main(["model=deflow", "lr=2e-4", "epochs=1", "batch_size=2", "loss_fn=deflowLoss", "model.target.num_iters=2",
+            "voxel_size=[0.2, 0.2, 6]", "point_cloud_range=[-6.4, -6.4, -3, 6.4, 6.4, 3]", "pairs_per_epoch=8",
+            "points_per_cloud=1200", "dtype=bf16", "graph=true", "log_every=1", f"save_checkpoint={ck2}"])
+    sd = torch.load(ck2, map_location="cpu", weights_only=False)
+    assert sd["global_step"] == 4 and sd["optimizer_states"][0]["step"] == 6   # 2 capture warm-ups + 1 captured + 3 replays
+    assert all(torch.isfinite(v).all() for v in sd["state_dict"].values() if v.dtype.is_floating_point)
 
 
 def test_edge_cases_empty_ragged_and_big_grid(dev):
