@@ -93,9 +93,17 @@ class ConvGRUDecoder(nn.Module):
         g = self.gru
         wz, wr = g.convz.weight.detach(), g.convr.weight.detach()
         bz, br = g.convz.bias.detach(), g.convr.bias.detach()
-        # [z rows | r rows]: free when the parameter arena lays convz/convr out back to back, else one small cat
-        w_zr = torch.as_strided(wz, (256, 192), (192, 1)) if _adjacent(wz, wr) else torch.cat([wz, wr], 0).view(256, 192)
-        b_zr = torch.as_strided(bz, (256,), (1,)) if _adjacent(bz, br) else torch.cat([bz, br], 0)
+        # [z rows | r rows]: free when the parameter arena lays convz/convr out back to back, else one small cat -- cached
+        # until a parameter changes (two launches per inference forward otherwise)
+        if _adjacent(wz, wr) and _adjacent(bz, br):
+            w_zr, b_zr = torch.as_strided(wz, (256, 192), (192, 1)), torch.as_strided(bz, (256,), (1,))
+        else:
+            key = (ops.PARAM_GEN[0], wz._version, wr._version, bz._version, br._version, wz.data_ptr(), wr.data_ptr())
+            c = getattr(self, "_df_zr", None)
+            if c is None or c[0] != key or torch.is_grad_enabled():
+                c = (key, torch.cat([wz, wr], 0).view(256, 192), torch.cat([bz, br], 0))
+                self._df_zr = c
+            w_zr, b_zr = c[1], c[2]
         w_q = g.convq.weight.detach().view(128, 192)
         keep = [w_zr, b_zr, w_q]
         W = DfGruWeights(ptr(self.offset_encoder.weight.detach()), ptr(self.offset_encoder.bias.detach()), ptr(w_zr),
