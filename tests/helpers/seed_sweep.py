@@ -1,8 +1,9 @@
 """Parity of the training step against the oracle over many seeds and ragged shapes (confidence beyond the fixed-seed tests):
 worst flow / loss / gradient error over the sweep."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import torch
 from test_gpu_model import build_pair, make_batch, to_dev, rel_err
 from oracle import ref_torch as O
