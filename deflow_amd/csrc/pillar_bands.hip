@@ -16,10 +16,11 @@
 //            order-preserving compaction the result dict needs (points, voxel coords, indices, centre offsets) and
 //            the bucketed (key, index, xyz) arrays
 //   band     the workgroup owning a band: LDS histogram of its <= 2048 cells -> scan -> one wavefront assigns stable
-//            positions chunk by chunk (segmented rank = popcount of the equal-cell lane mask below the lane) while the
-//            other three stream zeros into the band's EMPTY canvas cells -> permuted copy into the sorted arrays and an
-//            LDS image of the sorted points -> 8 lanes per occupied pillar walk its run in LDS: 9-d feature,
-//            Linear(9->32) + BN1d + ReLU, mean / max, one 128-B store per pillar.
+//            positions chunk by chunk (segmented rank = popcount of the equal-cell lane mask below the lane) ->
+//            permuted copy into the sorted arrays and an LDS image of the sorted points -> after the last barrier one
+//            wavefront streams zeros into the band's EMPTY canvas cells while the other three walk the occupied
+//            pillars (8 lanes each, run read from LDS): 9-d feature, Linear(9->32) + BN1d + ReLU, mean / max, one
+//            128-B store per pillar.
 // Training needs the BatchNorm1d batch statistics before it can normalise: band<sort, stats> leaves per-band partial
 // sums (fp32, finalised in fp64 by df_pfn_bn_finalize), band<canvas> then re-derives the cell table from the sorted keys.
 #include <cstdlib>
@@ -349,7 +350,6 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   __syncthreads();
   const int n_occ = misc[8];
   float* __restrict__ op = CANVAS ? reinterpret_cast<float*>(a.out.ptr) + df_img_base(a.out, s) + (int64_t)row0 * g.gx * a.out.ld : nullptr;
-  const bool prefilled = CANVAS;
   // zeros into the band's empty cells (128 B each, 8 lanes x 16 B) as soon as the histogram is known; every canvas byte is
   // written exactly once.  Measured at B = 16 (tools/bench_pillar.py, DF_P2_DBG ablations): this stream runs at 7.5 TB/s
   // (7.8 us per pair), the pillar loop costs 4 us (VALU-bound), the sort 1.5 us, hist + scan + scatter 6.1 us -- and the
@@ -449,11 +449,6 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       v.y = k ? (int32_t)(g0 + e) : 0;
       *reinterpret_cast<int2*>(a.cell_rng + 2 * ((int64_t)base_key + cell)) = v;
     }
-  if (CANVAS && !prefilled) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int cell = grp; cell < ncb; cell += 32)
-      if (cnt[cell] == 0) st4(op + (int64_t)cell * a.out.ld + 4 * sub, z);
-  }
   bar();
   // ---- from here on no workgroup barrier (canvas kernels): wave 3 streams the zeros of the band's empty cells (128 B each,
   // 8 lanes x 16 B; every canvas byte is written exactly once) while waves 0-2 walk the pillars
