@@ -22,7 +22,7 @@ tr.step(batch)
 torch.cuda.synchronize()
 ops.PROFILER = None
 rows = {}
-for name, flops, e0, e1, tag in prof.records:
+for name, flops, e0, e1, tag, *_ in prof.records:
     d = rows.setdefault((name, tag), [0, 0.0, 0.0])
     d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1)
 tot = sum(v[2] for v in rows.values())
