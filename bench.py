@@ -17,7 +17,8 @@ skipped or cached between steps.  Prints ONE JSON line on rank 0 (contract in th
   bf16_inference  BASELINE configs[4] shape (1024x1024, 160k points, 8 iterations, bf16 MFMA), after the training region
   cpu_baseline    the CPU oracle (oracle/ref_torch.py, a PyTorch port of the reference algorithm) timed on this host:
                   median of 5 after 2 warm-ups, training step and forward only
-  (N > 1) rccl_ranks, per-rank step times, allreduce_exposed_ms (steps with vs without the gradient collectives).
+  (N > 1) rccl_ranks, per-rank step times, bf16_training over all ranks, allreduce_exposed_ms (steps with vs without the
+          gradient collectives).
 """
 import argparse
 import json
@@ -159,11 +160,18 @@ def main():
 
     import torch
     assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
+    # test hook (tests/test_gpu_model.py): all ranks on cuda:0 with gloo carrying the collectives, so the N > 1 flow of this file
+    # runs end to end with the real kernels on a one-GPU box (RCCL refuses two ranks on one device).  Never a measurement.
+    share_gpu = os.environ.get("DF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
-    if use_dist:
+    if use_dist and share_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
 
     import deflow_amd
@@ -208,7 +216,17 @@ def main():
     dt = float(t.item())
 
     exposed = None
+    bf16_multi = None
     if world > 1 and not args.no_extras:
+        # BASELINE configs[4] ("bf16 MFMA, 8xMI355X"): the same data-parallel step with dtype=bf16, collectives on, timed the same way
+        trainer.mfma_bf16 = True
+        for _ in range(2):
+            trainer.step(batch)
+        dtb_, _, lossb_ = timed_steps(args.steps)
+        trainer.mfma_bf16 = False
+        tb_ = torch.tensor([dtb_], dtype=torch.float64, device=dev)
+        dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+        bf16_multi = (float(tb_.item()), float(lossb_))
         # how much of the gradient all-reduce is NOT hidden behind the backward: the same steps without the collectives
         # (replicas drift apart afterwards -- nothing is measured after this)
         trainer.collective = trainer.sink.collective = False
@@ -235,6 +253,13 @@ def main():
         out["per_rank_ms_per_step"] = {"min": min(float(x[0]) for x in per_rank), "max": max(float(x[0]) for x in per_rank)}
     if exposed is not None:
         out["allreduce_exposed_ms"] = exposed
+    if share_gpu:
+        out["collective_backend"] = "gloo, all ranks on cuda:0 (DF_BENCH_SHARE_GPU test hook: not a measurement)"
+    if bf16_multi is not None:
+        out["bf16_training"] = {"workload": "the headline data-parallel step with dtype=bf16 (bf16 MFMA operands, fp32 accumulate / tensors / "
+                                            "master weights), gradient collectives on, MAX over ranks",
+                                "ms_per_step": bf16_multi[0] / args.steps * 1e3, "pairs_per_s": world * args.batch * args.steps / bf16_multi[0],
+                                "speedup_vs_fp32": dt / bf16_multi[0], "loss": bf16_multi[1]}
     if prof is not None and os.environ.get("DF_BENCH_DUMP"):
         with open(os.environ["DF_BENCH_DUMP"], "w") as f:
             per = len(prof.records) // args.steps
@@ -303,8 +328,8 @@ def main():
     if not args.no_extras:
         # BASELINE configs[4] names "bf16 MFMA": the same training step with the UNet convolutions (forward, data gradient,
         # weight gradient) on bf16 MFMA operands, fp32 accumulation, fp32 tensors / master weights (Trainer(dtype="bf16")).
-        # Timed AFTER and reported BESIDE the fp32 headline, never instead of it.  (With N > 1 the gradient collectives are off
-        # at this point -- see allreduce_exposed_ms -- so the block is only emitted on one GPU.)
+        # Timed AFTER and reported BESIDE the fp32 headline, never instead of it.  (N > 1: measured above, before the collectives
+        # are switched off for allreduce_exposed_ms.)
         if world == 1:
             trainer.mfma_bf16 = True
             for _ in range(2):

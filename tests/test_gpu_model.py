@@ -1,5 +1,6 @@
 """GPU: the model=deflow plugin end to end against the CPU oracle (same weights, same seeded inputs), the
 reference-generated orchestration golden (G5), and size-independent properties at the BASELINE config sizes."""
+import math
 import os
 
 import numpy as np
@@ -1119,3 +1120,29 @@ def test_bench_line_contract(dev):
     assert d["bf16_training"]["speedup_vs_fp32"] > 1.2 and d["bf16_training"]["configs4_shape"]["bf16_ms_per_step"] > 0
     assert d["hip_graph"]["host_ms_per_step"] < 5.0 and d["hip_graph"]["ms_per_step"] < 1.1 * d["hip_graph"]["eager_ms_per_step"]
     assert "cpu_baseline" not in d   # --no-cpu-baseline
+
+
+def test_bench_two_ranks_share_the_gpu(dev):
+    """`python bench.py --gpus 2` started bare -- the way the driver starts it -- with the real kernels: the file launches its own
+    two ranks, both on this box's one GPU with gloo carrying the collectives (DF_BENCH_SHARE_GPU test hook; RCCL refuses two ranks
+    on one device), and rank 0 prints the one JSON line with the N > 1 fields.  Losses of the ranks' shards stay finite, both ranks
+    report, value = 2 x 16 pairs per step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DF_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=root, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["rccl_ranks"] == [0, 0] and "gloo" in d["collective_backend"]
+    assert 0 < d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.05
+    assert "allreduce_exposed_ms" in d and math.isfinite(d["allreduce_exposed_ms"])
+    assert math.isfinite(d["config"]["loss"]) and math.isfinite(d["bf16_training"]["loss"])
+    assert d["bf16_training"]["pairs_per_s"] > d["value"]
+    assert d["roofline"]["kernel"].startswith("conv_") and "cpu_baseline" not in d and "forward_only" not in d
