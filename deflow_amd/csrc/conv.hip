@@ -753,6 +753,7 @@ struct WgradParams {
   unsigned x_bytes, dy_bytes;  // DMA path: buffer extents (0 = use the register-staged kernels)
   float* bias_ws;              // optional [splits][N]: per-split column sums of dy (bias gradient), written by ci-tile 0
   int bf16;                    // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
+  int xcd_map;                 // ring kernel: all (ci, co) tiles of a split on one XCD (shared x / dy tiles hit its L2)
 };
 
 // chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
@@ -1174,9 +1175,22 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
   const int li = lane & 31, kh = lane >> 5;
   const int quad = wave & 3, ky = wave >> 2;
   const int wci = quad & 1, wco = quad >> 1;
-  const int ci0 = blockIdx.x * LC, co0 = blockIdx.y * LC, split = blockIdx.z;
+  // The (ci, co) tiles of one split read the same x and dy tiles.  Hardware deals workgroups to the 8 XCDs round-robin in
+  // linear-id order, which would put them behind 4..32 different L2s (every tile re-read from HBM: 2.7x the tensors,
+  // profiles/r02_pmc_hbm_bytes.txt); the remap gives each XCD whole splits, tiles of a split dispatched back to back.
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * LC, co0 = by * LC;
   const bool wave_active = (ci0 + wci * 32) < p.K;
-  const bool do_bias = p.bias_ws && blockIdx.x == 0;
+  const bool do_bias = p.bias_ws && bx == 0;
   float bsum = 0.f;
   const int lp = lane >> 4, lc4 = lane & 15;
   const int my_ops = (NOPS - wave + 11) / 12;     // 3 for waves 0..9, 2 for waves 10, 11
@@ -1195,46 +1209,82 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
   const int nst = max(c_end - c_begin, 0);
   const bool ci_ok = ci0 + lc4 * 4 < p.K;
 
-  auto issue = [&](int ch, int buf) {
-    const WgChunk c = wg_chunk(p, ch, P);
+  // DMA addressing, strength-reduced: chunks are issued in order, so a wave-uniform cursor (image, row, segment: scalar
+  // registers, advanced without divisions) carries the per-stage part and every lane keeps the lane-constant part of its
+  // (at most three) ops -- per stage and op one add, the border compares and a select.  (With wg_chunk()'s divisions and
+  // 64-bit per-lane products redone per stage this was ~500 VALU instructions per wave and stage: invisible behind the fp32
+  // MFMAs, the limiter of the bf16-operand form.)
+  unsigned loff[3];      // lane-constant byte offset of op i inside its tile (relative to the stage's uniform base)
+  int lpx[3], lqy[3];    // dy op: pixel; x op: column offset xi - pad, row offset qy - pad (qy = 3: never valid)
+  bool lis_y[3], lany[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave + 12 * i;
+    lis_y[i] = j < NYI;
+    lany[i] = j < NOPS;
+    if (j < NYI) {
+      lpx[i] = 4 * j + lp;
+      lqy[i] = 0;
+      loff[i] = (unsigned)((lpx[i] * p.dy.ld + co0 + lc4 * 4) * 4);
+    } else {
+      const int q = 4 * (j - NYI) + lp;
+      const int qy = q / XW, xi = q - qy * XW;
+      lpx[i] = xi - p.pad;
+      lqy[i] = (qy < 3 && ci_ok) ? qy - p.pad : (1 << 28);
+      loff[i] = (unsigned)((((qy - p.pad) * wx + xi - p.pad) * p.x.ld + ci0 + lc4 * 4) * 4);
+    }
+  }
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  int64_t cur_yimg = df_img_base(p.dy, cur_n), cur_ximg = df_img_base(p.x, cur_n);
+  auto issue = [&](int buf) {   // loads the cursor's chunk into ring slot `buf`, then advances the cursor
     float* dYs = lds + buf * STG;
     float* Xs = dYs + YSZ;
-    const int64_t yb = df_img_base(p.dy, c.n) + (int64_t)c.oy * wy * p.dy.ld + co0 + lc4 * 4;
-    const int64_t xb = df_img_base(p.x, c.n) + ci0 + lc4 * 4;
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = (unsigned)((cur_yimg + ((int64_t)cur_oy * wy + ox0) * p.dy.ld) * 4);
+    const unsigned xbase = (unsigned)((cur_ximg + ((int64_t)cur_oy * STRIDE * wx + ox0 * STRIDE) * p.x.ld) * 4);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int j = wave + 12 * i;
-      if (j < NYI) {
-        const int px = 4 * j + lp;
-        const bool ok = c.ox0 + px < wy;
-        const unsigned vo = ok ? (unsigned)((yb + (int64_t)(c.ox0 + px) * p.dy.ld) * 4) : DMA_BAD;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + j * 256), 16, vo, 0, 0, 0);
-      } else if (j < NOPS) {
-        const int k = j - NYI;
-        const int q = 4 * k + lp;
-        const int qy = q / XW, xi = q - qy * XW;
-        const int iy = c.oy * STRIDE + qy - p.pad, ix = c.ox0 * STRIDE + xi - p.pad;
-        const bool ok = ci_ok && qy < 3 && (unsigned)iy < (unsigned)hx && (unsigned)ix < (unsigned)wx;
-        const unsigned vo = ok ? (unsigned)((xb + ((int64_t)iy * wx + ix) * p.x.ld) * 4) : DMA_BAD;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + k * 256), 16, vo, 0, 0, 0);
+      if (lis_y[i]) {
+        const bool ok = ox0 + lpx[i] < wy;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + j * 256), 16, ok ? ybase + loff[i] : DMA_BAD, 0, 0, 0);
+      } else if (lany[i]) {
+        const bool ok = (unsigned)(cur_oy * STRIDE + lqy[i]) < (unsigned)hx && (unsigned)(ox0 * STRIDE + lpx[i]) < (unsigned)wx;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + (j - NYI) * 256), 16, ok ? xbase + loff[i] : DMA_BAD, 0, 0, 0);
+      }
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      if (++cur_oy == p.dy.h) {
+        cur_oy = 0;
+        ++cur_n;
+        cur_yimg = df_img_base(p.dy, cur_n);
+        cur_ximg = df_img_base(p.x, cur_n);
       }
     }
   };
 
-  static_assert(D == 2 || D == 3, "ring depth");
+  static_assert(D >= 2 && D <= 4, "ring depth");
   static_assert(NOPS <= 36 && P % 8 == 0, "at most three DMA ops per wave and stage");
-  if (nst > 0) issue(c_begin, 0);
-  if (D == 3 && nst > 1) issue(c_begin + 1, 1);
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < nst) issue(d);
   for (int i = 0; i < nst; ++i) {
-    // this wave's DMA share of stage i has landed (D = 3: at most the ops of stage i + 1 still in flight) ...
-    if (D == 3 && i + 1 < nst) {
-      if (my_ops == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this wave's DMA share of stage i has landed (D > 2: the ops of the D - 2 stages after it may still be in flight) ...
+    const int ahead = min(D - 2, nst - 1 - i) * my_ops;
+    switch (ahead) {
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
     __syncthreads();   // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D
-    if (i + D - 1 < nst) issue(c_begin + i + D - 1, (i + D - 1) % D);
+    if (i + D - 1 < nst) issue((i + D - 1) % D);
     const float* dyb = lds + (i % D) * STG;
     const float* xbuf = dyb + YSZ;
     if (wave_active && BF) {
@@ -1649,6 +1699,8 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
   p.chunks_per_split = (int)((chunks + splits - 1) / splits);
   DF_REQUIRE((int64_t)p.chunks_per_split * splits >= chunks, DF_E_SHAPE);
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // Measured on MI355X (bs16 step): DMA-fed kernels win for 3x3 stride 1 (register-staged 124.7 -> 4-wave DMA 128.4 ->
   // 12-wave 131-132 TFLOP/s); for 1x1 and stride 2 the register-prefetch kernels are faster (1x1: 12.0 vs 14.8 ms/step;
@@ -1668,6 +1720,9 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
     if (stride == 1 && wgrad_ring_depth(ksize, stride) == 3)
       return launch_wgrad_dma(wgrad3_ring_kernel<32, 3>, grid, 3 * ring_stage, s, p, 768);
     if (stride == 1 && wgrad_ring_depth(ksize, stride) == 2) {
+      static const int bfd = getenv("DF_WGRAD_RING_BF") ? atoi(getenv("DF_WGRAD_RING_BF")) : 2;
+      if (p.bf16 && bfd == 4) return launch_wgrad_dma(wgrad3_ring_kernel<32, 4, 1, true>, grid, 4 * ring_stage, s, p, 768);
+      if (p.bf16 && bfd == 3) return launch_wgrad_dma(wgrad3_ring_kernel<32, 3, 1, true>, grid, 3 * ring_stage, s, p, 768);
       if (p.bf16) return launch_wgrad_dma(wgrad3_ring_kernel<32, 2, 1, true>, grid, 2 * ring_stage, s, p, 768);
       return launch_wgrad_dma(wgrad3_ring_kernel<32, 2>, grid, 2 * ring_stage, s, p, 768);
     }
