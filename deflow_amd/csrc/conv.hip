@@ -725,6 +725,157 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
   return DF_OK;
 }
 
+// ---- bf16-operand form of the haloed 3x3 kernel with bf16 TILES IN LDS (df_conv2d_w16) ------------------------------
+// conv_halo_kernel<.., BF = true> keeps fp32 tiles in LDS and rounds the fragments as they leave it: every MFMA operand
+// costs two ds_read_b128 + four v_cvt_pk, each element is converted once per consuming wave, and at 3 fragments per 2 MFMAs
+// the kernel is LDS-bound at ~27 % matrix-pipe time (measured 22 %, profiles/r02_pmc_conv_bf16.txt).  Here
+//   * the weights arrive pre-cast (bf16 copy of the [Cout, 9, K] tensor, one cast per step): LDS-DMA as before, half the bytes;
+//   * the fp32 activation halo goes global -> registers -> v_cvt_pk -> LDS once per workgroup (8 floats = one 16-B slot
+//     per thread and (ty, kc) group), prefetched one group ahead;
+//   * every fragment is ONE ds_read_b128 (8 consecutive k of a row), no conversion in the loop.
+// Rows are 64 B (32 bf16); 16-B slots XOR-swizzled with (row >> 2) & 3: any 16 consecutive rows (a b128 service group,
+// whatever the tap shift) cover all 64 banks once.  Accumulator layout = conv_halo_kernel's, so the fp32 epilogues
+// (bias / statistics / BN+GELU / accumulate) are shared.
+constexpr int LDH = 16;   // floats per bf16 tile row
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HR = 132;                 // halo rows: 130 used
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RB = (BN + 127) / 128;              // weight DMA passes (a wave moves 16 rows of 64 B per instruction)
+  static_assert(WM * WN == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][HR][LDH]
+  float* Bs = lds + 2 * HR * LDH;       // [2][3 taps][BN][LDH]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BK;
+  const bool fwd = p.mode == DF_CONV_FWD;
+  RowDecode dec;
+  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = 0; dec.py = dec.px = 0; dec.hh = dec.wh = 0;
+  int n, oy, ox0;
+  dec(m0, n, oy, ox0);
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // A staging: thread -> (halo row tid >> 2, physical slot tid & 3); rows 128, 129 are a second item of threads 0..7.
+  // Halo row j holds input pixel (oy - 1 + ty, ox0 - 1 + j); physical slot s holds k = 8 (s ^ swz(j)) .. + 7 of the chunk.
+  const int arow = tid >> 2, aslot = tid & 3;
+  auto a_off = [&](int j) -> unsigned {
+    const int ix = ox0 - 1 + j;
+    const bool ok = ix >= 0 && ix < wx;
+    const int sl = aslot ^ ((j >> 2) & 3);
+    return ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+  };
+  const unsigned aoff0 = a_off(arow);
+  const unsigned aoff1 = tid < 8 ? a_off(BM + arow) : DMA_BAD;
+  const int brow = wave * 16 + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);   // (row >> 2) & 3 = (lane >> 4) & 3
+  unsigned boff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + brow + 128 * i) * 9 * p.K + bslot * 8) * 2);
+
+  f32x4 ra0, ra1, rb0, rb1;
+  auto fetch_a = [&](int ty, int kc) {              // group (ty, kc)'s halo -> registers
+    const bool row_ok = (unsigned)(oy - 1 + ty) < (unsigned)hx;
+    const unsigned soff = (unsigned)((ty * wx * ldx + kc * BK) * 4);
+    const unsigned v0 = row_ok ? aoff0 : DMA_BAD;
+    ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0, soff, 0));
+    ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0 + 16, soff, 0));
+    if (tid < 8) {
+      const unsigned v1 = row_ok ? aoff1 : DMA_BAD;
+      rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1, soff, 0));
+      rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1 + 16, soff, 0));
+    }
+  };
+  auto stash_a = [&](int abuf) {                    // registers -> bf16 -> LDS
+    float* a = As + abuf * HR * LDH;
+    *reinterpret_cast<bf16x8_t*>(a + arow * LDH + aslot * 4) = pack_bf16(ra0, ra1);
+    if (tid < 8) *reinterpret_cast<bf16x8_t*>(a + (BM + arow) * LDH + aslot * 4) = pack_bf16(rb0, rb1);
+  };
+  auto load_b = [&](int ty, int kc, int bbuf) {     // the three horizontal taps' weight tiles of group (ty, kc)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int wtap = fwd ? ty * 3 + tx : (2 - ty) * 3 + (2 - tx);
+      const unsigned soff = (unsigned)((wtap * p.K + kc * BK) * 2);
+      float* b = Bs + (bbuf * 3 + tx) * BN * LDH + wave * 16 * LDH;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        if (wave * 16 + 128 * i < BN)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 128 * LDH), 16, boff[i], soff, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // One stage = one (vertical tap, k chunk) group = three taps x two k-steps (12 MFMAs per wave at 128 x 128): a third of the
+  // barriers of the per-tap pipeline, and the next group's operands have a whole group of MFMAs to arrive.
+  const int ngroups = 3 * KC;
+  fetch_a(0, 0);
+  load_b(0, 0, 0);
+  stash_a(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int g = 0; g < ngroups; ++g) {
+    if (g + 1 < ngroups) {
+      const int ty1 = (g + 1) / KC, kc1 = (g + 1) - ty1 * KC;
+      load_b(ty1, kc1, (g + 1) & 1);
+      fetch_a(ty1, kc1);
+    }
+    const float* a0 = As + (g & 1) * HR * LDH + (wm * TM * 32 + li) * LDH;
+    const float* b0 = Bs + (g & 1) * 3 * BN * LDH + (wn * TN * 32 + li) * LDH;
+    const int sb = (li >> 2) & 3;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const float* a = a0 + tx * LDH;
+      const float* b = b0 + tx * BN * LDH;
+      const int sa = ((li + tx) >> 2) & 3;
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+        bf16x8_t a8[TM], b8[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * LDH + (((2 * q + kh) ^ sa) * 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    // the next group's halo: its ring slot was last read in group g - 1 (behind the previous barrier)
+    if (g + 1 < ngroups) stash_a((g + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
+#endif
+}
+
+template <int BN, int WM, int WN>
+static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
+  const size_t tiles = (size_t)2 * (132 + 3 * BN) * LDH * sizeof(float);
+  const size_t epi = (size_t)(2 * 128 + WM * BN * 2) * sizeof(float);   // conv_epilogue: rowoff[BM] (int64) + red[WM][BN][2]
+  const size_t lds_bytes = tiles > epi ? tiles : epi;
+  DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+
 // 8-wave forms (512 threads; wave tile 64 x 32 resp. 32 x 32, 32 / 16 accumulator registers): the same LDS footprint
 // and DMA traffic as the 4-wave kernels but twice the waves per SIMD to cover each other's barrier and DMA waits
 // (measured +2..4 % on the 128 x 128 tile).  DMA path only.
@@ -1541,10 +1692,39 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
   return df_conv2d_mp(x, w, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, stream);
 }
 
+// w16 != nullptr: the pre-cast bf16 weights of df_conv2d_w16 (w is then unused); query: return 1 / 0 = "the w16 form
+// exists for this call" without launching anything
+static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
+                       int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                       int accumulate, int mfma_bf16, bool query, void* stream);
+
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                             int accumulate, int mfma_bf16, void* stream) {
-  DF_REQUIRE(img_ok(x) && img_ok(y) && w && df_aligned16(w), DF_E_ALIGN);
+  return conv2d_impl(x, w, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, mfma_bf16,
+                     false, stream);
+}
+
+extern "C" int df_conv2d_w16(df_img x, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
+                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                             int accumulate, void* stream) {
+  DF_REQUIRE(w16 && df_aligned16(w16), DF_E_ALIGN);
+  return conv2d_impl(x, nullptr, w16, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 1, false,
+                     stream);
+}
+
+extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi) {
+  static const int on = getenv("DF_CONV_W16") ? atoi(getenv("DF_CONV_W16")) : 1;
+  if (!on || (ksize != 1 && ksize != 3)) return 0;
+  const int r = conv2d_impl(x, nullptr, x.ptr, nullptr, y, ksize, stride, ksize / 2, mode, epi, nullptr, nullptr, nullptr, 0, 1,
+                            true, nullptr);
+  return r == 1 ? 1 : 0;
+}
+
+static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
+                       int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                       int accumulate, int mfma_bf16, bool query, void* stream) {
+  DF_REQUIRE(img_ok(x) && img_ok(y) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
   DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
   DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
   DF_REQUIRE(mode == DF_CONV_FWD || mode == DF_CONV_DGRAD, DF_E_ARG);
@@ -1605,12 +1785,22 @@ extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img 
     const int64_t yext = ((int64_t)(y.grp_size - 1) * y.img_stride + (ygroups - 1) * y.grp_off + (int64_t)y.h * y.w * y.ld) * 4;
     p.y_bytes = (!wide_epi && y.img_stride >= 0 && y.grp_off >= 0 && yext < (int64_t)0xFFFFFFFFll - (16 << 20)) ? (unsigned)yext : 0u;
   }
-  g_last_dma = p.x_bytes != 0;
+  if (!query) g_last_dma = p.x_bytes != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // haloed-A kernel: 3x3 stride 1 (fwd / dgrad), rows of 128 output pixels inside one image row, full tiles only
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
   const bool halo_ok = use_halo && p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && (y.w % 128) == 0 &&
                        x.w == y.w && x.h == y.h && (var == 128128 || var == 128064);
+  if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed form exists
+    const bool ok = halo_ok && (p.K % BK) == 0;
+    if (query) return ok ? 1 : 0;
+    DF_REQUIRE(ok, DF_E_SHAPE);
+    p.w = reinterpret_cast<const float*>(w16);
+    p.w_bytes = p.w_bytes / 2;
+    p.bf16 = 1;
+    if (var == 128128) return launch_conv_halo_w16<128, 2, 4>(p, s);
+    return launch_conv_halo_w16<64, 4, 2>(p, s);
+  }
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
     case 64064: return launch_conv<64, 64, 2, 2>(p, s);
@@ -1633,6 +1823,7 @@ extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img 
     }
   }
 }
+
 
 static inline bool wgrad_use_1x1(int ksize, int cout) { return ksize == 1 && (cout % 128) == 0; }
 static inline int wgrad_cit(int cin) { return cin >= 128 ? 128 : 64; }

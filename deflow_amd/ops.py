@@ -144,14 +144,26 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("df_conv2d_mp", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
-         int(accumulate), int(MFMA_BF16), stream())
+    w16 = MFMA_BF16 and ks == 3 and stride == 1 and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1
+    if w16:
+        # bf16 tiles in LDS (conv_halo_w16_kernel): the weights are cast once per call (they change every optimizer step and
+        # each conv uses them once per direction), the activations stay fp32 in memory
+        wb = torch.empty(w_ohwi.numel(), dtype=torch.bfloat16, device=w_ohwi.device)
+        call("df_cast_bf16", ptr(w_ohwi), ptr(wb), w_ohwi.numel() // x.c, x.c, x.c, x.c, stream())
+        call("df_conv2d_w16", x, ptr(wb), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+             int(accumulate), stream())
+    else:
+        call("df_conv2d_mp", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+             int(accumulate), int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
-        prof.records.append((_conv_variant(x, y, ks, stride, mode, epi) + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
+        name = _conv_variant(x, y, ks, stride, mode, epi)
+        if w16:
+            name = name.replace("conv_halo_kernel", "conv_halo_w16_kernel")
+        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:

@@ -188,6 +188,15 @@ int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksiz
                  int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                  int accumulate, int mfma_bf16, void* stream);
 int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the launcher will pick for DF_EPI_STATS */
+/* The bf16-operand conv with PRE-CAST weights: w16 = df_cast_bf16 of the [Cout,kh,kw,Cin] weights (one cast per optimizer
+ * step).  Activations in and out stay fp32; the workgroup converts its input halo once on the way into LDS, tiles are bf16 in
+ * LDS, every MFMA operand is one 16-byte LDS read.  Exists for the haloed 3x3 stride-1 form only (forward and data gradient,
+ * W % 128 == 0, Cin % 32 == 0, Cout % 64 == 0): df_conv2d_w16_ok() == 1 says so for a call, other shapes get DF_E_SHAPE and use
+ * df_conv2d_mp.  Results are those of df_conv2d_mp(mfma_bf16 = 1) up to fp32 summation order.
+ * [REF decoder.py:202-220 under torch.autocast(bfloat16)] */
+int df_conv2d_w16(df_img x, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
+                  const float* scale, const float* shift, float* stats_partial, int accumulate, void* stream);
+int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);
 int df_conv2d_last_dma(void); /* 1 if the previous df_conv2d call launched the LDS-DMA kernel (profiling tools) */
