@@ -205,6 +205,53 @@ def test_conv_bf16_operand_mode(dev, cin, cout, k, s, n, h, w):
     assert e < 2e-2
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,grp", [(128, 128, 2, 40, 128, 2), (64, 64, 4, 10, 256, 2), (256, 128, 2, 36, 128, 1),
+                                                (128, 64, 2, 12, 384, 2)])
+def test_conv_w16_matches_bf16_operand_kernel(dev, cin, cout, n, h, w, grp):
+    """df_conv2d_w16 (bf16 tiles in LDS, pre-cast weights, register-staged halo) against df_conv2d_mp(mfma_bf16 = 1) (fp32
+    tiles, fragments rounded on the way out of LDS): the same bf16 products in another summation order, for every epilogue the
+    UNet uses -- bias, BatchNorm statistics (y AND the per-tile partial sums), folded BN + GELU -- forward and data gradient,
+    plain and accumulating, on image groups with a channel-strided input (the concat buffers of the up path)."""
+    from deflow_amd import ops
+    from deflow_amd._lib import DfImg, call, img, ptr, stream
+    g = torch.Generator().manual_seed(cin + cout + w)
+    ldx = cin + 64                                   # x is a channel slice of a wider NHWC buffer
+    xbuf = torch.randn(n, h, w, ldx, generator=g).to(dev)
+    x = DfImg(xbuf.data_ptr() + 4 * 32, n, h, w, cin, ldx, n // grp, h * w * ldx, (n // grp) * h * w * ldx)
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin)).to(dev)
+    w16 = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+    call("df_cast_bf16", ptr(wt), ptr(w16), wt.numel() // cin, cin, cin, cin, stream())
+    assert torch.equal(w16.view(wt.shape).float(), _bf16_round(wt))
+    bias = torch.randn(cout, generator=g).to(dev)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    bm = ops.conv_tile_m((n // grp) * h * w, cout)
+    tiles = n * h * w // bm
+    for mode in (ops.CONV_FWD, ops.CONV_DGRAD):
+        for epi in (ops.EPI_BIAS, ops.EPI_STATS, ops.EPI_BN_GELU):
+            for acc in (0, 1):
+                if mode == ops.CONV_DGRAD and epi != ops.EPI_BIAS or acc and epi != ops.EPI_BIAS:
+                    continue
+                yq = DfImg(xbuf.data_ptr(), n, h, w, cout, cout, n // grp, h * w * cout, (n // grp) * h * w * cout)  # (shape query only)
+                assert call("df_conv2d_w16_ok", x, yq, 3, 1, mode, epi) == 1
+                outs = []
+                for form in ("mp", "w16"):
+                    y = torch.full((n, h, w, cout), 0.25, device=dev)
+                    yi = DfImg(y.data_ptr(), n, h, w, cout, cout, n // grp, h * w * cout, (n // grp) * h * w * cout)
+                    st = torch.zeros(tiles, cout, 2, device=dev)
+                    b_ = bias if mode == ops.CONV_FWD else None
+                    if form == "mp":
+                        call("df_conv2d_mp", x, ptr(wt), ptr(b_), yi, 3, 1, 1, mode, epi, ptr(scale), ptr(shift), ptr(st), acc, 1, stream())
+                    else:
+                        call("df_conv2d_w16", x, ptr(w16), ptr(b_), yi, 3, 1, 1, mode, epi, ptr(scale), ptr(shift), ptr(st), acc, stream())
+                    outs.append((y, st))
+                tag = f"w16 vs mp {cin}->{cout} mode{mode} epi{epi} acc{acc}"
+                check(tag + " y", outs[1][0], outs[0][0], 2e-5)
+                if epi == ops.EPI_STATS:
+                    check(tag + " stats", outs[1][1], outs[0][1], 2e-5)
+                    assert float(outs[0][1].abs().max()) > 0
+    del xbuf
+
+
 # ---------------------------------------------------------------------------- BN + GELU -----------
 @pytest.mark.parametrize("groups", [1, 2])
 def test_convwithnorms_train_fwd_bwd(dev, groups):
