@@ -737,10 +737,14 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
 // whatever the tap shift) cover all 64 banks once.  Accumulator layout = conv_halo_kernel's, so the fp32 epilogues
 // (bias / statistics / BN+GELU / accumulate) are shared.
 constexpr int LDH = 16;   // floats per bf16 tile row
-template <int BN, int WM, int WN>
+// SEG = 1: the tile's 128 output pixels are one run of an image row (W % 128 == 0), halo = 130 pixels.  SEG = 2: W == 64, the
+// tile is two whole image rows, halo = 2 x 66 pixels (halo row 66 s + c + tx feeds output pixel (oy + s, c)); 32-row MFMA
+// blocks never straddle the two rows.
+template <int BN, int WM, int WN, int SEG = 1>
 __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 128, HR = 132;                 // halo rows: 130 used
+  constexpr int BM = 128, HR = 132;                 // halo rows: 130 (SEG = 1) / 132 (SEG = 2) used
+  constexpr int SW = BM / SEG + 2;                  // halo pixels per segment
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int RB = (BN + 127) / 128;              // weight DMA passes (a wave moves 16 rows of 64 B per instruction)
   static_assert(WM * WN == 8, "8 waves");
@@ -768,14 +772,18 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
   // A staging: thread -> (halo row tid >> 2, physical slot tid & 3); rows 128, 129 are a second item of threads 0..7.
   // Halo row j holds input pixel (oy - 1 + ty, ox0 - 1 + j); physical slot s holds k = 8 (s ^ swz(j)) .. + 7 of the chunk.
   const int arow = tid >> 2, aslot = tid & 3;
+  constexpr int XT = (SEG * SW - BM) * 4;           // threads with a second item (halo rows >= 128)
+  auto a_seg = [&](int j) { return SEG == 1 ? 0 : j / SW; };
   auto a_off = [&](int j) -> unsigned {
-    const int ix = ox0 - 1 + j;
+    const int sg = a_seg(j);
+    const int ix = ox0 - 1 + j - sg * SW;
     const bool ok = ix >= 0 && ix < wx;
     const int sl = aslot ^ ((j >> 2) & 3);
-    return ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+    return ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
   };
   const unsigned aoff0 = a_off(arow);
-  const unsigned aoff1 = tid < 8 ? a_off(BM + arow) : DMA_BAD;
+  const unsigned aoff1 = tid < XT ? a_off(BM + arow) : DMA_BAD;
+  const int aseg0 = a_seg(arow), aseg1 = a_seg(BM + arow);
   const int brow = wave * 16 + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);   // (row >> 2) & 3 = (lane >> 4) & 3
   unsigned boff[RB];
 #pragma unroll
@@ -783,13 +791,12 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
 
   f32x4 ra0, ra1, rb0, rb1;
   auto fetch_a = [&](int ty, int kc) {              // group (ty, kc)'s halo -> registers
-    const bool row_ok = (unsigned)(oy - 1 + ty) < (unsigned)hx;
     const unsigned soff = (unsigned)((ty * wx * ldx + kc * BK) * 4);
-    const unsigned v0 = row_ok ? aoff0 : DMA_BAD;
+    const unsigned v0 = (unsigned)(oy + aseg0 - 1 + ty) < (unsigned)hx ? aoff0 : DMA_BAD;
     ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0, soff, 0));
     ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0 + 16, soff, 0));
-    if (tid < 8) {
-      const unsigned v1 = row_ok ? aoff1 : DMA_BAD;
+    if (tid < XT) {
+      const unsigned v1 = (unsigned)(oy + aseg1 - 1 + ty) < (unsigned)hx ? aoff1 : DMA_BAD;
       rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1, soff, 0));
       rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1 + 16, soff, 0));
     }
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
   auto stash_a = [&](int abuf) {                    // registers -> bf16 -> LDS
     float* a = As + abuf * HR * LDH;
     *reinterpret_cast<bf16x8_t*>(a + arow * LDH + aslot * 4) = pack_bf16(ra0, ra1);
-    if (tid < 8) *reinterpret_cast<bf16x8_t*>(a + (BM + arow) * LDH + aslot * 4) = pack_bf16(rb0, rb1);
+    if (tid < XT) *reinterpret_cast<bf16x8_t*>(a + (BM + arow) * LDH + aslot * 4) = pack_bf16(rb0, rb1);
   };
   auto load_b = [&](int ty, int kc, int bbuf) {     // the three horizontal taps' weight tiles of group (ty, kc)
 #pragma unroll
@@ -841,12 +848,16 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
     for (int tx = 0; tx < 3; ++tx) {
       const float* a = a0 + tx * LDH;
       const float* b = b0 + tx * BN * LDH;
-      const int sa = ((li + tx) >> 2) & 3;
 #pragma unroll
       for (int q = 0; q < BK / 16; ++q) {
         bf16x8_t a8[TM], b8[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * LDH + (((2 * q + kh) ^ sa) * 4));
+        for (int i = 0; i < TM; ++i) {
+          // output rows of block i sit 2 halo rows further per completed segment (SEG = 2: blocks 2, 3 of the tile)
+          const int sh = SEG == 1 ? 0 : 2 * ((wm * TM + i) * 32 / (BM / SEG));
+          const int sa = ((li + tx + sh) >> 2) & 3;
+          a8[i] = *reinterpret_cast<const bf16x8_t*>(a + (i * 32 + sh) * LDH + (((2 * q + kh) ^ sa) * 4));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4));
 #pragma unroll
@@ -864,13 +875,13 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
 #endif
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int SEG = 1>
 static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
   const size_t tiles = (size_t)2 * (132 + 3 * BN) * LDH * sizeof(float);
   const size_t epi = (size_t)(2 * 128 + WM * BN * 2) * sizeof(float);   // conv_epilogue: rowoff[BM] (int64) + red[WM][BN][2]
   const size_t lds_bytes = tiles > epi ? tiles : epi;
-  DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+  DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN, SEG>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN, SEG>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1792,15 +1803,17 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
   const bool halo_ok = use_halo && p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && (y.w % 128) == 0 &&
                        x.w == y.w && x.h == y.h && (var == 128128 || var == 128064);
-  if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed form exists
-    const bool ok = halo_ok && (p.K % BK) == 0;
+  if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed forms exist (W % 128 == 0, or W == 64 as row pairs)
+    const bool two = p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && y.w == 64 && (y.h % 2) == 0 && x.w == y.w &&
+                     x.h == y.h && (var == 128128 || var == 128064);
+    const bool ok = (halo_ok || two) && (p.K % BK) == 0;
     if (query) return ok ? 1 : 0;
     DF_REQUIRE(ok, DF_E_SHAPE);
     p.w = reinterpret_cast<const float*>(w16);
     p.w_bytes = p.w_bytes / 2;
     p.bf16 = 1;
-    if (var == 128128) return launch_conv_halo_w16<128, 2, 4>(p, s);
-    return launch_conv_halo_w16<64, 4, 2>(p, s);
+    if (halo_ok) return var == 128128 ? launch_conv_halo_w16<128, 2, 4>(p, s) : launch_conv_halo_w16<64, 4, 2>(p, s);
+    return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 2>(p, s) : launch_conv_halo_w16<64, 4, 2, 2>(p, s);
   }
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);

@@ -162,7 +162,8 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
         name = _conv_variant(x, y, ks, stride, mode, epi)
         if w16:
-            name = name.replace("conv_halo_kernel", "conv_halo_w16_kernel")
+            bn = 128 if y.c % 128 == 0 else 64
+            name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
 
 

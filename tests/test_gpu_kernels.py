@@ -206,7 +206,7 @@ def test_conv_bf16_operand_mode(dev, cin, cout, k, s, n, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w,grp", [(128, 128, 2, 40, 128, 2), (64, 64, 4, 10, 256, 2), (256, 128, 2, 36, 128, 1),
-                                                (128, 64, 2, 12, 384, 2)])
+                                                (128, 64, 2, 12, 384, 2), (256, 256, 4, 64, 64, 2), (128, 64, 6, 32, 64, 3)])
 def test_conv_w16_matches_bf16_operand_kernel(dev, cin, cout, n, h, w, grp):
     """df_conv2d_w16 (bf16 tiles in LDS, pre-cast weights, register-staged halo) against df_conv2d_mp(mfma_bf16 = 1) (fp32
     tiles, fragments rounded on the way out of LDS): the same bf16 products in another summation order, for every epilogue the
