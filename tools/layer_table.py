@@ -11,7 +11,7 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 B = int(os.environ.get("B", 16))
 model = DeFlow().to(dev)
-tr = Trainer(model, lr=2e-4)
+tr = Trainer(model, lr=2e-4, dtype=(sys.argv[1] if len(sys.argv) > 1 else "fp32"))
 batch = synth_batch(B, 80000, device=dev)
 for _ in range(2):
     tr.step(batch)
