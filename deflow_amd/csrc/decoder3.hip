@@ -115,13 +115,30 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[t][r] = c_lane[r * LDH + 16 * t];
 
+  // Saved planes.  bf16 mode: planes 0..4 (h_in, z, r, q, r*h -- read back by the backward kernels, which round them to bf16
+  // operands or use them in elementwise gradient formulas) are stored as bf16 in the first half of each row's 512-byte slot:
+  // half the bytes of the kernels' dominant HBM stream; plane 5 (h_T, also the fp32 operand of the head's generic weight
+  // gradient) stays fp32.
   auto save_rows = [&](int plane, int it) {  // coalesced copy of the wave's 16 x 128 A region
     const rsrc_t dst = make_rsrc(p.save + plane * p.plane_stride + it * p.iter_stride + grow0 * 128, row_bytes);
+    if (BF && plane < 5) {
+      const unsigned ho = (lane >> 5) * 512 + (lane & 31) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) buf_st4_bf16(dst, ho + j * 1024, ld4(r_lane + 2 * j * LDH));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) buf_st4(dst, rl_off + j * 1024, ld4(r_lane + 2 * j * LDH));
   };
   auto save_regs = [&](int plane, int it, const f32x4 (&v)[8]) {  // C-layout registers -> [row][128]
     const rsrc_t dst = make_rsrc(p.save + plane * p.plane_stride + it * p.iter_stride + grow0 * 128, row_bytes);
+    if (BF) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st1_bf16(dst, (4 * lq + r) * 512 + (16 * t + li) * 2, v[t][r]);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll

@@ -82,6 +82,13 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) buf_st4(d, rl_off + j * 1024, ld4(r_lane + 2 * j * LDH));
   };
+  auto lds_to_plane = [&](float* dst) {  // ... into a saved plane (bf16 mode: bf16 half rows, see decoder3.hip)
+    if (!BF) { lds_to_rows(dst); return; }
+    const rsrc_t d = make_rsrc(dst + grow0 * 128, row_bytes);
+    const unsigned ho = (lane >> 5) * 512 + (lane & 31) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) buf_st4_bf16(d, ho + j * 1024, ld4(r_lane + 2 * j * LDH));
+  };
   auto lds_to_c = [&](f32x4 (&v)[8]) {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -98,6 +105,13 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   // are outside the buffer range and read as 0
   auto c_load = [&](f32x4 (&v)[8], const float* src) {
     const rsrc_t s0 = make_rsrc(src + grow0 * 128, row_bytes);
+    if (BF) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[t][r] = buf_ld1_bf16(s0, (4 * lq + r) * 512 + (16 * t + li) * 2);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -243,13 +257,13 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
       c_to_lds(z);
     }
     wave_lds_sync();
-    lds_to_rows(pl_z);  // dz_pre replaces z
+    lds_to_plane(pl_z);  // dz_pre replaces z
     colsum(0);
     gemm<128, 4, false, 64, 256, 256>(wt_zr, 0, wt_zr + 128 * 256, 0, a_lane, xf, ws, dh);
     gemm<64, 4, false, 128, 256, 128>(wt_zr + 128 * 256, 0, wt_q, 0, a_lane, xf, ws, dxa);
     c_to_lds(q);
     wave_lds_sync();
-    lds_to_rows(pl_q);  // dq_pre replaces q
+    lds_to_plane(pl_q);  // dq_pre replaces q
     colsum(2);
     {
       f32x4 drh[8];
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     }
     c_to_lds(q);
     wave_lds_sync();
-    lds_to_rows(pl_r);  // dr_pre replaces r
+    lds_to_plane(pl_r);  // dr_pre replaces r
     colsum(1);
     gemm<128, 4, false, 64, 256, 256>(wt_zr + 128, 0, wt_zr + 128 * 256 + 128, 0, a_lane, xf, ws, dh);
     if (it > 0) gemm<64, 4, false, 128, 256, 256>(wt_zr + 128 * 256 + 128, 0, wt_zr, 0, a_lane, xf, ws, dxa);

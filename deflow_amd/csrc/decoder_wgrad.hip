@@ -15,13 +15,17 @@
 namespace {
 
 constexpr int WP = 16;                          // rows per stage
-constexpr int WD = 3;                           // ring depth
-constexpr int STG = WP * (128 + 128 + 64);      // floats per stage: G[16][128], H[16][128], X[16][64]
+constexpr int WD_F32 = 3, STG_F32 = WP * (128 + 128 + 64);   // fp32 planes: ring depth, floats per stage G[16][128] H[16][128] X[16][64]
+// bf16 planes: G and H tiles are half the size.  Measured at the bench shape (bf16 mode, 2.40 ms before): bf16 planes alone 2.40
+// (not HBM-bound), the wave-uniform H / X branch hoisted 1.98 (a per-element select between the bf16 and the fp32 tile had
+// compiled to a scalar branch per LDS read), gates of a split on one XCD 1.99, a 5-deep ring in the same 60 KB 2.01 (not
+// latency-bound either): what is left is the 40 scalar LDS reads per wave and stage behind 6 MFMAs.
+constexpr int WD_BF = 3, STG_BF = WP * (64 + 64 + 64);
 constexpr unsigned BAD = 0xFFFFFFFFu - (8u << 20);  // always outside the buffer range -> the DMA writes zeros
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct GruWgradParams {
-  const float* save;   // planes as written by the forward / backward kernels: [6][T][B*N][128]
+  const float* save;   // planes as written by the forward / backward kernels: [6][T][B*N][128]; bf16 mode: bf16 half rows
   const float* x;      // [B*N][64] offset encoding
   const int32_t* counts;
   int B, N, T, nsplit;
@@ -34,11 +38,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 template <bool BF>
 __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WD = BF ? WD_BF : WD_F32, STG = BF ? STG_BF : STG_F32, OPS = BF ? 3 : 5;   // OPS: DMA instructions per wave and stage
+  constexpr int GSZ = BF ? WP * 64 : WP * 128;   // floats of the G (and H) tile
   __shared__ __attribute__((aligned(16))) float ring[WD * STG];   // 60 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
   const int wco = wave & 1, wci = wave >> 1;
-  const int split = blockIdx.x, gate = blockIdx.y;   // gate 0: z, 1: r, 2: q
+  // The three gates of a split stream the same x rows (z and r also the same h_in rows): XCD-aware order -- every XCD gets a
+  // contiguous range of (split, gate) pairs, the gates of a split back to back -- lets two of the three reads hit that L2.
+  const int lg = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = lg / 3, gate = lg - 3 * split;   // gate 0: z, 1: r, 2: q
   const float* gplane = p.save + (1 + gate) * p.plane_stride;
   const float* hplane = p.save + (gate == 2 ? 4 : 0) * p.plane_stride;
 
@@ -65,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
 
   auto issue = [&](int buf) {   // DMA the stage at the cursor into ring slot `buf`, then advance the cursor
     float* G = ring + buf * STG;
-    float* H = G + WP * 128;
-    float* X = H + WP * 128;
+    float* H = G + GSZ;
+    float* X = H + GSZ;
     const int cnt = p.counts[ib];
     const int row0 = ic * WP;                         // first row of the chunk within the sample
     const int64_t srow = (int64_t)ib * p.N + row0;    // global row
@@ -74,13 +83,23 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
         const_cast<float*>(gplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(hplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
+    if constexpr (BF) {
+      // bf16 planes (written by the bf16-mode forward / backward kernels): a row is 128 bf16 = 256 B at the head of its
+      // 512-B slot; one DMA instruction moves 4 rows, the wave's share of the stage is one instruction per plane.
+      // LDS tiles G, H: [16 rows][128 bf16]
+      const int r = 4 * wave + (lane >> 4);
+      const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 512 + (lane & 15) * 16) : BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + wave * 256), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + wave * 256), 16, vo, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int op = 2 * wave + k;                    // rows 2 op, 2 op + 1
-      const int r = 2 * op + g_row;
-      const unsigned vo = (row0 + r < cnt) ? (unsigned)(((srow + r) * 128 + g_c4 * 4) * 4) : BAD;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + op * 256), 16, vo, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + op * 256), 16, vo, 0, 0, 0);
+      for (int k = 0; k < 2; ++k) {
+        const int op = 2 * wave + k;                    // rows 2 op, 2 op + 1
+        const int r = 2 * op + g_row;
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)(((srow + r) * 128 + g_c4 * 4) * 4) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + op * 256), 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + op * 256), 16, vo, 0, 0, 0);
+      }
     }
     {
       const int r = 4 * wave + x_row;
@@ -114,30 +133,50 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
     else { b_off[j] = 2 * WP * 128 + kh * 64 + (ci - 128) + li; b_pitch[j] = 128; }
   }
 
-  if (nst > 0) issue(0);
-  if (nst > 1) issue(1);
+#pragma unroll
+  for (int d = 0; d < WD - 1; ++d)
+    if (d < nst) issue(d);
   for (int i = 0; i < nst; ++i) {
-    // this wave's DMA for stage i has landed (5 ops per stage per wave, at most one younger stage in flight) ...
-    if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this wave's DMA for stage i has landed (OPS instructions per stage and wave; the WD - 2 younger stages may be in flight) ...
+    switch (min(WD - 2, nst - 1 - i) * OPS) {
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
     __syncthreads();   // ... and everyone's; all waves are also done reading slot (i - 1) % WD
-    if (i + 2 < nst) issue((i + 2) % WD);
+    if (i + WD - 1 < nst) issue((i + WD - 1) % WD);
     const float* st = ring + (i % WD) * STG;
     if constexpr (BF) {
       // bf16 operands (mixed-precision training): the stage's 16 rows are ONE k step of v_mfma_f32_32x32x16_bf16 -- lane
       // (column, kh) holds rows 8 kh .. 8 kh + 7
       bf16x8_t a8[2], b8[3];
+      const __bf16* g16 = reinterpret_cast<const __bf16*>(st);         // G tile: bf16 [16][128]
+      const __bf16* h16 = reinterpret_cast<const __bf16*>(st + GSZ);   // H tile: bf16 [16][128]
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        a8[0][k] = (__bf16)st[(8 * kh + k) * 128 + wco * 64 + li];
-        a8[1][k] = (__bf16)st[(8 * kh + k) * 128 + wco * 64 + 32 + li];
+        a8[0][k] = g16[(8 * kh + k) * 128 + wco * 64 + li];
+        a8[1][k] = g16[(8 * kh + k) * 128 + wco * 64 + 32 + li];
       }
+      // columns of [H | X]: wave column group 0 owns h columns 0..95, group 1 owns h 96..127 and x 0..63 (one wave-uniform
+      // branch; a per-element select between the bf16 H tile and the fp32 X tile compiles to a branch per LDS read)
+      auto ld_h = [&](int ci) {
+        bf16x8_t v;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int ci = wci * 96 + 32 * j;
+        for (int k = 0; k < 8; ++k) v[k] = h16[(8 * kh + k) * 128 + ci + li];
+        return v;
+      };
+      auto ld_x = [&](int cx) {
+        bf16x8_t v;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          b8[j][k] = (__bf16)((ci < 128) ? st[WP * 128 + (8 * kh + k) * 128 + ci + li] : st[2 * WP * 128 + (8 * kh + k) * 64 + (ci - 128) + li]);
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)st[2 * GSZ + (8 * kh + k) * 64 + cx + li];
+        return v;
+      };
+      if (wci == 0) {
+        b8[0] = ld_h(0); b8[1] = ld_h(32); b8[2] = ld_h(64);
+      } else {
+        b8[0] = ld_h(96); b8[1] = ld_x(0); b8[2] = ld_x(32);
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -193,8 +232,8 @@ extern "C" int df_gru_wgrad_mp(const float* save, const float* x, const int32_t*
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.ws = ws;
-  if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(gru_wgrad_kernel<false>, dim3(nsplit, 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(gru_wgrad_kernel<false>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

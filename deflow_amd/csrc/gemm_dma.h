@@ -29,6 +29,26 @@ __device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
 __device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
 }
+// bf16 saved planes of the mixed-precision GRU (planes 0..4 of the save buffer in bf16 mode): a row keeps its 512-byte slot and
+// holds 128 bf16 in the first 256 bytes, so plane / iteration / row offsets are those of the fp32 layout.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float bf16_float(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ void buf_st4_bf16(rsrc_t r, unsigned voff, f32x4 v) {   // 4 floats -> 4 bf16 (8 bytes)
+  bf16x2_t a, b;
+  a[0] = (__bf16)v[0]; a[1] = (__bf16)v[1]; b[0] = (__bf16)v[2]; b[1] = (__bf16)v[3];
+  u32x2_t w;
+  w[0] = __builtin_bit_cast(unsigned, a);
+  w[1] = __builtin_bit_cast(unsigned, b);
+  __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_st1_bf16(rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), r, voff, 0, 0);
+}
+__device__ __forceinline__ float buf_ld1_bf16(rsrc_t r, unsigned voff) {
+  return bf16_float(__builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0));
+}
 
 // 32-deep k chunk `chunk` of ROWS weight rows (LDW floats apart) -> LDS buffer, all four waves cooperating: one DMA
 // instruction moves 8 rows x 128 B, wave w takes row groups w, w + 4, ...  voff = WStream::voff<LDW>.

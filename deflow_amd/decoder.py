@@ -126,6 +126,10 @@ class ConvGRUDecoder(nn.Module):
         with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
             call("df_gru_decoder_fwd_mp", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
                  ptr(sv), int(ops.MFMA_BF16), stream())
+        if sv is not None:
+            # in bf16 mode planes 0..4 hold bf16 half rows (csrc/decoder3.hip): the backward kernels must run in the mode the
+            # forward ran in, whatever ops.MFMA_BF16 says by then
+            sv.df_bf16 = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
         return flow, sv
 
     def run_bf16(self, before: DfImg, after: DfImg, ps: PointSet):
@@ -154,6 +158,7 @@ class ConvGRUDecoder(nn.Module):
         dev, T, s = dflow.device, self.num_iters, stream()
         f32 = dict(dtype=torch.float32, device=dev)
         BN = B * N
+        bf = int(getattr(sv, "df_bf16", ops.MFMA_BF16))   # the mode the planes were written in
         W, keep = self._weights()
         w_zr, b_zr, w_q = keep
         w1 = self.decoder[0].weight.detach()
@@ -170,7 +175,7 @@ class ConvGRUDecoder(nn.Module):
         # gru_wgrad's)
         with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
             call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), int(ops.MFMA_BF16), s)
+                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), bf, s)
         bias_g = torch.empty(772, **f32)
         if nblocks >= 2048:  # tens of thousands of per-workgroup rows: two-stage column sum
             staged = torch.empty(64, 772, **f32)
@@ -204,7 +209,8 @@ class ConvGRUDecoder(nn.Module):
             x_rep = rows_img(xbuf, 0, T, 64, 64, 0)          # the same x rows for every iteration
             x_one = rows_img(xbuf, 0, 1, 64, 64, BN * 64)
             kw = dict(row_counts=ps.counts, rows_per_seg=N)
-            if os.environ.get("DF_GRU_WGRAD_V1"):  # six generic 1x1 weight-gradient GEMMs (first generation), for A/B
+            if os.environ.get("DF_GRU_WGRAD_V1") and not bf:  # six generic 1x1 weight-gradient GEMMs (first generation), for A/B
+                # (fp32 planes only: in bf16 mode the planes are bf16 half rows that only the fused kernel reads)
                 dW_zr = torch.empty(256, 192, **f32)
                 dW_q = torch.empty(128, 192, **f32)
                 ops.conv2d_wgrad(h_in, dz, 1, 1, dW_zr, ld_co=192, dw_off=0, **kw)
@@ -217,7 +223,7 @@ class ConvGRUDecoder(nn.Module):
                 nsplit = call("df_gru_wgrad_splits")
                 ws = torch.empty(nsplit, 384, 192, **f32)
                 with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
-                    call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, int(ops.MFMA_BF16), s)
+                    call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, bf, s)
                 dW_all = torch.empty(384, 192, **f32)
                 call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
                 dW_zr, dW_q = dW_all[:256], dW_all[256:]
