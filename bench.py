@@ -350,7 +350,8 @@ def main():
             out["hip_graph"] = {"workload": "the bf16 step above as one captured HIP graph (Trainer.capture / step_captured)",
                                 "ms_per_step": graph_ms, "host_ms_per_step": host_ms, "eager_ms_per_step": dtb / args.steps * 1e3}
             out["bf16_training"] = {"workload": "the headline step with dtype=bf16 (bf16 MFMA operands in every UNet conv fwd/dgrad/wgrad and every "
-                                                "decoder GEMM, fp32 accumulate, fp32 tensors + master weights + GRU state)",
+                                                "decoder GEMM, fp32 accumulate; fp32 activations, gradients, master weights and GRU state; 3x3 conv tiles and the GRU's "
+                                                "saved planes in bf16)",
                                     "ms_per_step": dtb / args.steps * 1e3, "pairs_per_s": args.batch * args.steps / dtb,
                                     "speedup_vs_fp32": dt / dtb, "loss": float(lossb)}
     if world == 1 and not args.no_extras:
