@@ -1843,11 +1843,20 @@ static inline bool wgrad_use_1x1(int ksize, int cout) { return ksize == 1 && (co
 static inline int wgrad_cit(int cin) { return cin >= 128 ? 128 : 64; }
 static inline int wgrad_ring_depth(int ksize, int stride) {   // 12-wave kernel: 0 = off, 3 = one workgroup per CU with a
   static const int ring = getenv("DF_WGRAD_RING") ? atoi(getenv("DF_WGRAD_RING")) : 2;   // 3-deep ring, 2 = two per CU
-  // stride 2 (three small layers) measured slower with this form (16-pixel chunks, idle ci waves at Cin = 32): 3.06 vs
-  // 2.41 ms per step for the register-prefetch kernel, which therefore keeps them
+  // (stride 2: wgrad_ring_s2() below)
   return (ksize == 3 && stride == 1) ? ring : 0;
 }
-static inline int wgrad_chunk(int ksize, int stride) { (void)ksize; (void)stride; return 32; }  // output pixels per chunk
+// stride-2 3x3 weight gradient on the 12-wave ring kernel too (16-pixel chunks: 3 x 33 input pixels per stage, 29 KB, two
+// workgroups per CU).  Round 1 measured this form SLOWER than the register-prefetch kernel (3.06 vs 2.41 ms per step); with the
+// ring kernel's strength-reduced DMA addressing it is faster: fp32 87 -> 97 and 99 -> 110 TFLOP/s on the two layers, bf16
+// mode 78 -> 254 and 80 -> 284 (tools/ab_wgrad_s2.py).  DF_WGRAD_RING_S2=0: the register-prefetch kernel (A/B, tests).
+static inline int wgrad_ring_s2() {
+  static const int on = getenv("DF_WGRAD_RING_S2") ? atoi(getenv("DF_WGRAD_RING_S2")) : 1;
+  return on;
+}
+static inline int wgrad_chunk(int ksize, int stride) {   // output pixels per chunk
+  return (ksize == 3 && stride == 2 && wgrad_ring_s2()) ? 16 : 32;
+}
 
 extern "C" int df_conv2d_wgrad_splits(df_img x, df_img dy, int ksize, int stride) {
   const int P = wgrad_chunk(ksize, stride);
@@ -1912,7 +1921,8 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
   // s2 needs 116 KB LDS = 1 workgroup/CU), so those keep them.  DF_WGRAD_DMA_ALL=1 forces the DMA kernels everywhere and
   // DF_WGRAD_RING=0 the 4-wave DMA form for 3x3 (A/B runs, tests).
   static const int dma_all = getenv("DF_WGRAD_DMA_ALL") ? atoi(getenv("DF_WGRAD_DMA_ALL")) : 0;
-  if (p.x_bytes && ((dma_all && !(bias_ws && ksize == 1 && (dy.c % 128) == 0)) || (ksize == 3 && stride == 1))) {
+  if (p.x_bytes && ((dma_all && !(bias_ws && ksize == 1 && (dy.c % 128) == 0)) || (ksize == 3 && stride == 1) ||
+                    (ksize == 3 && stride == 2 && wgrad_ring_s2()))) {
     if (wgrad_use_1x1(ksize, dy.c)) {
       const int cit = wgrad_cit(x.c);
       dim3 g1((x.c + cit - 1) / cit, dy.c / 128, splits);
@@ -1932,6 +1942,11 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
       return launch_wgrad_dma(wgrad3_ring_kernel<32, 2>, grid, 2 * ring_stage, s, p, 768);
     }
     if (stride == 1) return launch_wgrad_dma(wgrad_dma_kernel<3, 1, 32>, grid, bytes(3, 1), s, p);
+    if (wgrad_ring_s2()) {
+      const size_t st2 = (size_t)(16 * 64 + ((3 * 33 + 3) / 4) * 4 * 64) * 4;
+      if (p.bf16) return launch_wgrad_dma(wgrad3_ring_kernel<16, 2, 2, true>, grid, 2 * st2, s, p, 768);
+      return launch_wgrad_dma(wgrad3_ring_kernel<16, 2, 2>, grid, 2 * st2, s, p, 768);
+    }
     return launch_wgrad_dma(wgrad_dma_kernel<3, 2, 32>, grid, bytes(3, 2), s, p);
   }
   if (wgrad_use_1x1(ksize, dy.c)) {

@@ -300,7 +300,7 @@ def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
 def _wgrad3_name(stride: int) -> str:
     ring = int(os.environ.get("DF_WGRAD_RING", "2"))   # mirrors df_conv2d_wgrad's dispatch for 3x3 kernels
     if stride == 2:
-        return "wgrad_kernel<3,2,32>"
+        return "wgrad3_ring_kernel<16,2,2>" if os.environ.get("DF_WGRAD_RING_S2", "1") != "0" else "wgrad_kernel<3,2,32>"
     return f"wgrad3_ring_kernel<32,{ring},1>" if ring in (2, 3) else "wgrad_dma_kernel<3,1,32>"
 
 

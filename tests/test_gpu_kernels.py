@@ -123,7 +123,7 @@ BIG_CONV_CASES = [  # cin, cout, k, stride, n, h, w, forward kernel, dgrad kerne
     (128, 64, 3, 1, 2, 64, 128, "conv_halo_kernel<64,4,2>", "conv_halo_kernel<128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
     (256, 128, 3, 1, 3, 64, 64, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
     (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1x1_kernel<128>"),
-    (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad_kernel<3,2,32>"),
+    (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad3_ring_kernel<16,2,2>"),
 ]
 
 

@@ -750,7 +750,7 @@ def test_sparse_edge_kernels_match_dense(B, N, grid):
 # forms of the SAME kernel get their own run.  Four runs of ~30 s instead of seven.
 @pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1", "DF_CONV_WIDE_EPI": "1", "DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1", "DF_PILLAR_V1": "1"},
                                  {"DF_WGRAD_DMA_ALL": "1", "DF_CONV_HALO": "0", "DF_DENSE_CANVAS_GRAD": "1"},
-                                 {"DF_WGRAD_RING": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0", "DF_SIDE_STREAM": "1"},
+                                 {"DF_WGRAD_RING": "0", "DF_WGRAD_RING_S2": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0", "DF_SIDE_STREAM": "1"},
                                  {"DF_WGRAD_RING": "3", "DF_MERGE_CLOUDS": "0", "DF_NO_FUSED_BIAS": "1"}])
 def test_alternate_kernel_paths(env):
     """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors), the all-DMA wgrad variants, the
