@@ -1376,14 +1376,16 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
   // (at most three) ops -- per stage and op one add, the border compares and a select.  (With wg_chunk()'s divisions and
   // 64-bit per-lane products redone per stage this was ~500 VALU instructions per wave and stage: invisible behind the fp32
   // MFMAs, the limiter of the bf16-operand form.)
+  // Ops are dealt j = wave + 12 i: only op 0 can be a dY op (NYI <= 12), ops 1 and 2 are X ops -- one wave-uniform branch per
+  // stage instead of a descriptor select per op (the scalar unit is shared by the CU's 24 waves: at 86 SALU instructions per
+  // wave and stage the bf16-operand form was bound by it, profiles/r02_pmc_conv_bf16.txt).
+  static_assert(NYI <= 12 && NOPS > 12, "op 0 is the only dY op; every wave has an op 1");
+  const bool op0_y = wave < NYI, op2_on = wave + 24 < NOPS;
   unsigned loff[3];      // lane-constant byte offset of op i inside its tile (relative to the stage's uniform base)
-  int lpx[3], lqy[3];    // dy op: pixel; x op: column offset xi - pad, row offset qy - pad (qy = 3: never valid)
-  bool lis_y[3], lany[3];
+  int lpx[3], lqy[3];    // dY op: pixel; X op: column offset xi - pad, row offset qy - pad (invalid: never in range)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = wave + 12 * i;
-    lis_y[i] = j < NYI;
-    lany[i] = j < NOPS;
     if (j < NYI) {
       lpx[i] = 4 * j + lp;
       lqy[i] = 0;
@@ -1396,36 +1398,48 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
       loff[i] = (unsigned)((((qy - p.pad) * wx + xi - p.pad) * p.x.ld + ci0 + lc4 * 4) * 4);
     }
   }
+  // LDS destinations of the three ops inside a ring slot (floats)
+  const int ldst0 = op0_y ? wave * 256 : YSZ + (wave - NYI) * 256;
+  const int ldst1 = YSZ + (wave + 12 - NYI) * 256, ldst2 = YSZ + (wave + 24 - NYI) * 256;
   int cur_n, cur_oy, cur_seg;
   {
     const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
     cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
   }
-  int64_t cur_yimg = df_img_base(p.dy, cur_n), cur_ximg = df_img_base(p.x, cur_n);
+  // byte offsets of the cursor's row start (32-bit: the DMA path requires tensors below 4 GB), advanced incrementally
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * STRIDE * wx * p.x.ld) * 4);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 4), xrow_step = (unsigned)(STRIDE * wx * p.x.ld * 4);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 4), xseg_step = (unsigned)(P * STRIDE * p.x.ld * 4);
   auto issue = [&](int buf) {   // loads the cursor's chunk into ring slot `buf`, then advances the cursor
-    float* dYs = lds + buf * STG;
-    float* Xs = dYs + YSZ;
+    float* slot = lds + buf * STG;
     const int ox0 = cur_seg * P;
-    const unsigned ybase = (unsigned)((cur_yimg + ((int64_t)cur_oy * wy + ox0) * p.dy.ld) * 4);
-    const unsigned xbase = (unsigned)((cur_ximg + ((int64_t)cur_oy * STRIDE * wx + ox0 * STRIDE) * p.x.ld) * 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int j = wave + 12 * i;
-      if (lis_y[i]) {
-        const bool ok = ox0 + lpx[i] < wy;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(dYs + j * 256), 16, ok ? ybase + loff[i] : DMA_BAD, 0, 0, 0);
-      } else if (lany[i]) {
-        const bool ok = (unsigned)(cur_oy * STRIDE + lqy[i]) < (unsigned)hx && (unsigned)(ox0 * STRIDE + lpx[i]) < (unsigned)wx;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(Xs + (j - NYI) * 256), 16, ok ? xbase + loff[i] : DMA_BAD, 0, 0, 0);
-      }
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+    const int iy0 = cur_oy * STRIDE, ix0 = ox0 * STRIDE;
+    if (op0_y) {
+      const bool ok = ox0 + lpx[0] < wy;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(slot + ldst0), 16, ok ? ybase + loff[0] : DMA_BAD, 0, 0, 0);
+    } else {
+      const bool ok = (unsigned)(iy0 + lqy[0]) < (unsigned)hx && (unsigned)(ix0 + lpx[0]) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst0), 16, ok ? xbase + loff[0] : DMA_BAD, 0, 0, 0);
+    }
+    {
+      const bool ok = (unsigned)(iy0 + lqy[1]) < (unsigned)hx && (unsigned)(ix0 + lpx[1]) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst1), 16, ok ? xbase + loff[1] : DMA_BAD, 0, 0, 0);
+    }
+    if (op2_on) {
+      const bool ok = (unsigned)(iy0 + lqy[2]) < (unsigned)hx && (unsigned)(ix0 + lpx[2]) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst2), 16, ok ? xbase + loff[2] : DMA_BAD, 0, 0, 0);
     }
     if (++cur_seg == p.chunks_per_row) {
       cur_seg = 0;
-      if (++cur_oy == p.dy.h) {
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {   // next image: its base need not follow the previous one
         cur_oy = 0;
         ++cur_n;
-        cur_yimg = df_img_base(p.dy, cur_n);
-        cur_ximg = df_img_base(p.x, cur_n);
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
       }
     }
   };
@@ -1437,13 +1451,16 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
     if (d < nst) issue(d);
   for (int i = 0; i < nst; ++i) {
     // this wave's DMA share of stage i has landed (D > 2: the ops of the D - 2 stages after it may still be in flight) ...
-    const int ahead = min(D - 2, nst - 1 - i) * my_ops;
-    switch (ahead) {
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    if constexpr (D == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      switch (min(D - 2, nst - 1 - i) * my_ops) {
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
     }
     __syncthreads();   // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D
     if (i + D - 1 < nst) issue((i + D - 1) % D);
