@@ -651,14 +651,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int st = 0;
+  int ty = 0, kc = 0;   // group g = (ty, kc), counted without divisions (the scalar unit is shared by the CU's waves)
   for (int g = 0; g < ngroups; ++g) {
-    const int ty = g / KC, kc = g - ty * KC;
+    const int kc1 = (kc + 1 == KC) ? 0 : kc + 1, ty1 = (kc + 1 == KC) ? ty + 1 : ty;   // group g + 1
 #pragma unroll 1
     for (int tx = 0; tx < 3; ++tx, ++st) {
       // prefetch: the next stage's weights; at the first stage of a group also the next group's A halo
       if (tx < 2) load_b(ty, tx + 1, kc, (st + 1) & 1);
-      else if (g + 1 < ngroups) load_b((g + 1) / KC, 0, (g + 1) % KC, (st + 1) & 1);
-      if (tx == 0 && g + 1 < ngroups) load_a((g + 1) / KC, (g + 1) % KC, (g + 1) & 1);
+      else if (g + 1 < ngroups) load_b(ty1, 0, kc1, (st + 1) & 1);
+      if (tx == 0 && g + 1 < ngroups) load_a(ty1, kc1, (g + 1) & 1);
       const float* a = As + (g & 1) * HR * LDT + (wm * TM * 32 + li + tx) * LDT;
       const float* b = Bs + (st & 1) * BN * LDT + (wn * TN * 32 + li) * LDT;
       const int sa = ((li + tx) >> 1) & 7, sb = (li >> 1) & 7;
@@ -705,6 +706,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    ty = ty1;
+    kc = kc1;
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
 #endif
@@ -835,9 +838,10 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
   stash_a(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int ty1 = 0, kc1 = 0;   // group g + 1 = (ty1, kc1), counted without divisions
   for (int g = 0; g < ngroups; ++g) {
+    if (++kc1 == KC) { kc1 = 0; ++ty1; }
     if (g + 1 < ngroups) {
-      const int ty1 = (g + 1) / KC, kc1 = (g + 1) - ty1 * KC;
       load_b(ty1, kc1, (g + 1) & 1);
       fetch_a(ty1, kc1);
     }
