@@ -744,13 +744,15 @@ constexpr int LDH = 16;   // floats per bf16 tile row
 // tile is two whole image rows, halo = 2 x 66 pixels (halo row 66 s + c + tx feeds output pixel (oy + s, c)); 32-row MFMA
 // blocks never straddle the two rows.
 template <int BN, int WM, int WN, int SEG = 1>
-__global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, HR = 132;                 // halo rows: 130 (SEG = 1) / 132 (SEG = 2) used
   constexpr int SW = BM / SEG + 2;                  // halo pixels per segment
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int RB = (BN + 127) / 128;              // weight DMA passes (a wave moves 16 rows of 64 B per instruction)
-  static_assert(WM * WN == 8, "8 waves");
+  constexpr int NW = WM * WN, NT = 64 * NW;         // waves, threads (8 waves: wave tile 64 x 32 at BN = 128; 4 waves: 64 x 64)
+  constexpr int RB = (BN + 16 * NW - 1) / (16 * NW);   // weight DMA passes (a wave moves 16 rows of 64 B per instruction)
+  constexpr int NIT = (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte LDS slot each) per thread
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                      // [2][HR][LDH]
   float* Bs = lds + 2 * HR * LDH;       // [2][3 taps][BN][LDH]
@@ -772,42 +774,46 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-  // A staging: thread -> (halo row tid >> 2, physical slot tid & 3); rows 128, 129 are a second item of threads 0..7.
-  // Halo row j holds input pixel (oy - 1 + ty, ox0 - 1 + j); physical slot s holds k = 8 (s ^ swz(j)) .. + 7 of the chunk.
-  const int arow = tid >> 2, aslot = tid & 3;
-  constexpr int XT = (SEG * SW - BM) * 4;           // threads with a second item (halo rows >= 128)
-  auto a_seg = [&](int j) { return SEG == 1 ? 0 : j / SW; };
-  auto a_off = [&](int j) -> unsigned {
-    const int sg = a_seg(j);
+  // A staging: item e of a thread = LDS slot (tid + e NT): halo row (tid + e NT) >> 2, physical slot tid & 3 (NT % 4 == 0).
+  // Halo row j holds input pixel (oy - 1 + ty [+ segment], ox0 - 1 + j [- segment start]); physical slot s holds
+  // k = 8 (s ^ swz(j)) .. + 7 of the chunk.  The last item covers the few rows past a multiple of NT / 4.
+  const int aslot = tid & 3;
+  unsigned aoff[NIT];
+  int aseg[NIT];
+  bool aon[NIT];
+#pragma unroll
+  for (int e = 0; e < NIT; ++e) {
+    const int j = (tid + e * NT) >> 2;
+    const int sg = SEG == 1 ? 0 : j / SW;
     const int ix = ox0 - 1 + j - sg * SW;
-    const bool ok = ix >= 0 && ix < wx;
+    aon[e] = j < SEG * SW;
+    aseg[e] = sg;
     const int sl = aslot ^ ((j >> 2) & 3);
-    return ok ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
-  };
-  const unsigned aoff0 = a_off(arow);
-  const unsigned aoff1 = tid < XT ? a_off(BM + arow) : DMA_BAD;
-  const int aseg0 = a_seg(arow), aseg1 = a_seg(BM + arow);
+    aoff[e] = (aon[e] && ix >= 0 && ix < wx)
+                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+  }
   const int brow = wave * 16 + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);   // (row >> 2) & 3 = (lane >> 4) & 3
   unsigned boff[RB];
 #pragma unroll
-  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + brow + 128 * i) * 9 * p.K + bslot * 8) * 2);
+  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + brow + 16 * NW * i) * 9 * p.K + bslot * 8) * 2);
 
-  f32x4 ra0, ra1, rb0, rb1;
+  f32x4 ra[NIT][2];
   auto fetch_a = [&](int ty, int kc) {              // group (ty, kc)'s halo -> registers
     const unsigned soff = (unsigned)((ty * wx * ldx + kc * BK) * 4);
-    const unsigned v0 = (unsigned)(oy + aseg0 - 1 + ty) < (unsigned)hx ? aoff0 : DMA_BAD;
-    ra0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0, soff, 0));
-    ra1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v0 + 16, soff, 0));
-    if (tid < XT) {
-      const unsigned v1 = (unsigned)(oy + aseg1 - 1 + ty) < (unsigned)hx ? aoff1 : DMA_BAD;
-      rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1, soff, 0));
-      rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v1 + 16, soff, 0));
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      if (e + 1 < NIT || aon[e]) {
+        const unsigned v = (unsigned)(oy + aseg[e] - 1 + ty) < (unsigned)hx ? aoff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, soff, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, soff, 0));
+      }
     }
   };
   auto stash_a = [&](int abuf) {                    // registers -> bf16 -> LDS
     float* a = As + abuf * HR * LDH;
-    *reinterpret_cast<bf16x8_t*>(a + arow * LDH + aslot * 4) = pack_bf16(ra0, ra1);
-    if (tid < XT) *reinterpret_cast<bf16x8_t*>(a + (BM + arow) * LDH + aslot * 4) = pack_bf16(rb0, rb1);
+#pragma unroll
+    for (int e = 0; e < NIT; ++e)
+      if (e + 1 < NIT || aon[e]) *reinterpret_cast<bf16x8_t*>(a + (tid + e * NT) * 4) = pack_bf16(ra[e][0], ra[e][1]);
   };
   auto load_b = [&](int ty, int kc, int bbuf) {     // the three horizontal taps' weight tiles of group (ty, kc)
 #pragma unroll
@@ -817,8 +823,8 @@ __global__ __launch_bounds__(512) void conv_halo_w16_kernel(ConvParams p) {
       float* b = Bs + (bbuf * 3 + tx) * BN * LDH + wave * 16 * LDH;
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        if (wave * 16 + 128 * i < BN)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 128 * LDH), 16, boff[i], soff, 0, 0);
+        if (wave * 16 + 16 * NW * i < BN)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + i * 16 * NW * LDH), 16, boff[i], soff, 0, 0);
     }
   };
 
@@ -885,7 +891,7 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
   const size_t epi = (size_t)(2 * 128 + WM * BN * 2) * sizeof(float);   // conv_epilogue: rowoff[BM] (int64) + red[WM][BN][2]
   const size_t lds_bytes = tiles > epi ? tiles : epi;
   DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN, SEG>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN, SEG>), dim3(p.tiles_m * p.tiles_n), dim3(512), lds_bytes, s, p);
+  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN, SEG>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1833,8 +1839,13 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     p.w = reinterpret_cast<const float*>(w16);
     p.w_bytes = p.w_bytes / 2;
     p.bf16 = 1;
-    if (halo_ok) return var == 128128 ? launch_conv_halo_w16<128, 2, 4>(p, s) : launch_conv_halo_w16<64, 4, 2>(p, s);
-    return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 2>(p, s) : launch_conv_halo_w16<64, 4, 2, 2>(p, s);
+    static const int w4 = getenv("DF_W16_WAVES4") ? atoi(getenv("DF_W16_WAVES4")) : 0;   // bit 0: 128-wide, bit 1: 64-wide tiles on 4 waves
+    if (halo_ok) {
+      if (var == 128128) return (w4 & 1) ? launch_conv_halo_w16<128, 2, 2>(p, s) : launch_conv_halo_w16<128, 2, 4>(p, s);
+      return (w4 & 2) ? launch_conv_halo_w16<64, 2, 2>(p, s) : launch_conv_halo_w16<64, 4, 2>(p, s);
+    }
+    if (var == 128128) return (w4 & 1) ? launch_conv_halo_w16<128, 2, 2, 2>(p, s) : launch_conv_halo_w16<128, 2, 4, 2>(p, s);
+    return (w4 & 2) ? launch_conv_halo_w16<64, 2, 2, 2>(p, s) : launch_conv_halo_w16<64, 4, 2, 2>(p, s);
   }
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
