@@ -230,8 +230,9 @@ class ConvGRUDecoder(nn.Module):
             # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
             dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
             dW1t = torch.empty(192, 32, **f32)
-            ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
-            ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
+            with ops.mfma_bf16(bool(bf)):   # the head's generic weight gradients follow the forward's mode too
+                ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
+                ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
             dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
         g = self.gru
         grads[g.convz.weight] = dW_zr[:128].unsqueeze(2)

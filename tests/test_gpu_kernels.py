@@ -632,6 +632,20 @@ def test_gru_decoder_bf16_operand_mode(dev, golden_dir, iters):
     check("bf16-mode gru d(after)", after.grad, torch.from_numpy(g["gafter"]), tol=2e-2)
     for k, p in m.named_parameters():
         check(f"bf16-mode gru grad {k}", p.grad, torch.from_numpy(g["gw." + k]), tol=2e-2)
+    # the backward runs in the mode the forward SAVED its planes in (bf16 half rows), whatever the switch says by then: forward
+    # inside the context, backward outside it -> the same gradients as above, bit for bit
+    g_in = {k: p.grad.clone() for k, p in m.named_parameters()}
+    gb_in = before.grad.clone()
+    for p in m.parameters():
+        p.grad = None
+    before.grad = after.grad = None
+    with ops.mfma_bf16(True):
+        flows2 = m(before, after, infos)
+    sum((f * torch.from_numpy(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows2)).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(before.grad, gb_in)
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, g_in[k]), k
     # the result must differ from the fp32 kernels' (the switch really selects the bf16 MFMA path) ...
     f32 = m(before.detach(), after.detach(), infos)
     assert float((f32[0] - flows[0].detach()).abs().max()) > 0
