@@ -113,6 +113,34 @@ class SideStream:
 
 
 SIDE: Optional[SideStream] = None
+_SIDE_CACHE: dict = {}
+
+
+class side_stream:
+    """with ops.side_stream(on, device): ...  -- the backward inside puts its weight-gradient GEMMs on the second stream (on =
+    True), keeps them on the main stream (False), or leaves the process-wide setting alone (None).  optim.Trainer turns it on
+    for dtype="bf16" on one GPU: in that mode no kernel saturates the matrix pipe, so two streams overlap (52.2 -> 49.2 ms per
+    step); the fp32 step, MFMA-bound end to end, loses 1 % to it and keeps one stream."""
+
+    def __init__(self, on: Optional[bool], device=None):
+        self.on, self.device = on, device
+
+    def __enter__(self):
+        global SIDE
+        self.prev = SIDE
+        if self.on is True:
+            key = str(self.device)
+            if key not in _SIDE_CACHE:
+                _SIDE_CACHE[key] = SideStream(self.device)
+            SIDE = _SIDE_CACHE[key]
+        elif self.on is False:
+            SIDE = None
+        return self
+
+    def __exit__(self, *exc):
+        global SIDE
+        SIDE = self.prev
+        return False
 
 
 def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int) -> str:

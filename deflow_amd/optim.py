@@ -306,10 +306,18 @@ class Trainer:
         ops.PARAM_GEN[0] += 1
         return self._graph_loss
 
+    def _side_on(self) -> Optional[bool]:
+        """weight-gradient GEMMs on a second stream?  DF_SIDE_STREAM=0/1 decides if set; otherwise on in bf16 mode on one GPU
+        (with data-parallel ranks the phase-by-phase gradient delivery -- the overlapped all-reduce -- needs them in order)."""
+        env = os.environ.get("DF_SIDE_STREAM")
+        if env is not None:
+            return None if env == "1" else False   # "1": autograd creates the stream itself (every caller, not only Trainer)
+        return bool(self.mfma_bf16 and not self.collective)
+
     def step(self, batch) -> torch.Tensor:
         self.flat.zero_grad()
         self.sink.begin()
-        with ops.mfma_bf16(self.mfma_bf16):
+        with ops.mfma_bf16(self.mfma_bf16), ops.side_stream(self._side_on(), self.flat.grad.device):
             self.model.forward_padded(batch)
             loss = self.loss_on_last_forward(batch)
             loss.backward()
