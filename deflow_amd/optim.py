@@ -271,9 +271,9 @@ class Trainer:
         """Capture `step(batch)` -- forward, loss, hand-sequenced backward, Adam: ~410 launches -- as one HIP graph on the
         shapes of `batch` (whose tensors become the graph's static inputs; `step_captured(new_batch)` copies into them).  The
         step is sync-free and every host-side quantity the kernels take is constant across steps except Adam's step number,
-        which moves to device memory (df_adam_step_dev).  Replaying costs the host 0.4 ms instead of the ~44 ms it takes
-        Python to enqueue the step; the GPU time is the same (152.3 vs 152.4 ms fp32, 65.7 vs 66.1 ms bf16 measured) -- the
-        point is a host-free step, not a faster one.  One rank only: the RCCL buckets issued from inside the backward are not
+        which moves to device memory (df_adam_step_dev).  Replaying costs the host 0.1-1 ms instead of the ~44 ms it takes
+        Python to enqueue the step; the GPU time is about the same (fp32: equal; bf16, where the step runs on two streams:
+        50.6 ms replayed vs 48.9 eager) -- the point is a host-free step, not a faster one.  One rank only: the RCCL buckets issued from inside the backward are not
         captured."""
         if self.collective:
             raise RuntimeError("Trainer.capture: graph capture of the data-parallel step (RCCL inside the backward) is not supported")
