@@ -47,7 +47,8 @@ struct GruBwd3Params {
   float* bias_partial;  // [blocks][772], layout as in decoder_bwd.hip
 };
 
-template <bool BF>
+// W16 (with BF): p.w.w_1 and p.wt.{wt_zr, wt_q, wt_1} point at bf16 copies (gemm_dma.h, WStreamT<2>)
+template <bool BF, bool W16 = false>
 __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   float* Aw = As + wave * 16 * LDH;
   const int wp0 = p0 + wave * 16;
   const int64_t grow0 = (int64_t)b * p.N + wp0;
-  const float* a_lane = Aw + li * LDH + lq * 4;
+  constexpr int WSC = W16 ? 2 : 1;                   // weight element offsets in floats: halved for bf16 data
+  const float* a_lane = Aw + li * LDH + lq * (W16 ? 8 : 4);
   float* c_lane = Aw + 4 * lq * LDH + li;            // C-layout element (row 4 lq + r, col 16 t + li) = c_lane[r * LDH + 16 t]
   float* r_lane = Aw + (lane >> 5) * LDH + (lane & 31) * 4;  // row copies: float4 j at r_lane + 2 j LDH
   const unsigned nvalid = (unsigned)min(max(cnt - wp0, 0), 16);  // valid rows of this wave's 16-row tile
@@ -73,9 +75,10 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   const float* wt_q = p.wt.wt_q;
   const float* wt_zr = p.wt.wt_zr;
 
-  WStreamT<BF> ws;
+  WStreamT<BF ? (W16 ? 2 : 1) : 0> ws;
   wstream_init(ws, Bs);
-  dma_chunk<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff<192>());
+  if constexpr (W16) dma_chunk16<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff16<192>());
+  else dma_chunk<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff<192>());
 
   auto lds_to_rows = [&](float* dst) {  // the wave's 16 x 128 A region -> global rows (coalesced; invalid rows dropped)
     const rsrc_t d = make_rsrc(dst + grow0 * 128, row_bytes);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     }
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + k * 16);
+    for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + (W16 ? (k >> 1) * 32 + (k & 1) * 4 : k * 16));
     wave_lds_sync();
   }
   {  // h_T rows -> A region
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   for (int t = 0; t < 8; ++t) dh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 4; ++t) dxa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm<128, 1, false, 64, 32, 32>(p.wt.wt_1, 0, p.wt.wt_1 + 128 * 32, 0, a_lane, xf, ws, dh);
-  gemm<64, 1, false, 128, 32, 256>(p.wt.wt_1 + 128 * 32, 0, wt_zr, 0, a_lane, xf, ws, dxa);
+  gemm<128, 1, false, 64, 32, 32>(p.wt.wt_1, 0, p.wt.wt_1 + 128 * 32 / WSC, 0, a_lane, xf, ws, dh);
+  gemm<64, 1, false, 128, 32, 256>(p.wt.wt_1 + 128 * 32 / WSC, 0, wt_zr, 0, a_lane, xf, ws, dxa);
 
   // ---- GRU steps in reverse ----------------------------------------------------------------------------------------
   for (int it = p.T - 1; it >= 0; --it) {
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     wave_lds_sync();
     lds_to_plane(pl_z);  // dz_pre replaces z
     colsum(0);
-    gemm<128, 4, false, 64, 256, 256>(wt_zr, 0, wt_zr + 128 * 256, 0, a_lane, xf, ws, dh);
-    gemm<64, 4, false, 128, 256, 128>(wt_zr + 128 * 256, 0, wt_q, 0, a_lane, xf, ws, dxa);
+    gemm<128, 4, false, 64, 256, 256>(wt_zr, 0, wt_zr + 128 * 256 / WSC, 0, a_lane, xf, ws, dh);
+    gemm<64, 4, false, 128, 256, 128>(wt_zr + 128 * 256 / WSC, 0, wt_q, 0, a_lane, xf, ws, dxa);
     c_to_lds(q);
     wave_lds_sync();
     lds_to_plane(pl_q);  // dq_pre replaces q
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
       c_load(q, pl_r);  // q <- r (lands during the GEMMs)
 #pragma unroll
       for (int t = 0; t < 8; ++t) drh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gemm<128, 4, false, 64, 128, 128>(wt_q, 0, wt_q + 128 * 128, 0, a_lane, xf, ws, drh);
-      gemm<64, 4, false, 128, 128, 256>(wt_q + 128 * 128, 0, wt_zr + 128, 0, a_lane, xf, ws, dxa);
+      gemm<128, 4, false, 64, 128, 128>(wt_q, 0, wt_q + 128 * 128 / WSC, 0, a_lane, xf, ws, drh);
+      gemm<64, 4, false, 128, 128, 256>(wt_q + 128 * 128 / WSC, 0, wt_zr + 128 / WSC, 0, a_lane, xf, ws, dxa);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -285,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     wave_lds_sync();
     lds_to_plane(pl_r);  // dr_pre replaces r
     colsum(1);
-    gemm<128, 4, false, 64, 256, 256>(wt_zr + 128, 0, wt_zr + 128 * 256 + 128, 0, a_lane, xf, ws, dh);
-    if (it > 0) gemm<64, 4, false, 128, 256, 256>(wt_zr + 128 * 256 + 128, 0, wt_zr, 0, a_lane, xf, ws, dxa);
-    else gemm<64, 4, false, 128, 256, 256>(wt_zr + 128 * 256 + 128, 0, nullptr, 0, a_lane, xf, ws, dxa);
+    gemm<128, 4, false, 64, 256, 256>(wt_zr + 128 / WSC, 0, wt_zr + (128 * 256 + 128) / WSC, 0, a_lane, xf, ws, dh);
+    if (it > 0) gemm<64, 4, false, 128, 256, 256>(wt_zr + (128 * 256 + 128) / WSC, 0, wt_zr, 0, a_lane, xf, ws, dxa);
+    else gemm<64, 4, false, 128, 256, 256>(wt_zr + (128 * 256 + 128) / WSC, 0, nullptr, 0, a_lane, xf, ws, dxa);
   }
   // ---- outputs: dh0 [rows,128], dx [rows,64] ----------------------------------------------------------------------
   c_to_lds(dh);
@@ -365,7 +368,8 @@ int df_launch_gru_bwd3(const float* dflow, const float* offs, const int32_t* cou
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.xout = xout; p.bias_partial = bias_partial;
-  if (mfma_bf16) hipLaunchKernelGGL(gru_bwd3_kernel<true>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16 == 2) hipLaunchKernelGGL((gru_bwd3_kernel<true, true>), dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else if (mfma_bf16) hipLaunchKernelGGL(gru_bwd3_kernel<true>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(gru_bwd3_kernel<false>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;

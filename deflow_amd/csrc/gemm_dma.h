@@ -61,6 +61,18 @@ __device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk
                                              (unsigned)((i * 32 * LDW + chunk * 32) * 4), 0, 0);
 }
 
+// The same for PRE-CAST bf16 weights (W points at bf16 data, LDW in elements): a row of the chunk is 64 B, one DMA instruction
+// moves 16 rows, the four waves cover 64 rows per pass.  voff = WStream::voff16<LDW>.
+template <int ROWS, int LDW>
+__device__ __forceinline__ void dma_chunk16(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
+  const rsrc_t r = make_rsrc(W, 0x7fffffffu);
+#pragma unroll
+  for (int i = 0; i < (ROWS + 63) / 64; ++i)
+    if (wave * 16 + 64 * i < ROWS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
+                                               (unsigned)((i * 64 * LDW + chunk * 32) * 2), 0, 0);
+}
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
   bf16x8_t r;
@@ -75,18 +87,28 @@ __device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
 // BF_ = bf16-operand mode (mixed-precision training, optim.Trainer(dtype="bf16")): a 32-deep k chunk -- the two 16-wide
 // k groups a lane reads as two float4 -- is rounded to bf16 (RNE) and goes through ONE v_mfma_f32_16x16x32_bf16 instead of
 // eight v_mfma_f32_16x16x4_f32; state, gates, accumulators and the saved planes stay fp32.
-template <bool BF_>
+// MODE 2 = MODE 1 with the weights pre-cast to bf16 in memory (one cast per optimizer step): the chunk tile is [rows][64 B]
+// (16-byte slots swizzled with (row >> 2) & 3), a B fragment is ONE ds_read_b128 of 8 consecutive k -- the fp32-tile form reads
+// two b128 and converts 8 values per fragment and is LDS-bound (16 points per wave: every wave re-reads every weight fragment).
+// The A operand then holds k = 8 lq .. 8 lq + 7 of the chunk (callers pass a_lane = row + 8 lq and load the x registers to match).
+template <int MODE>
 struct WStreamT {   // the weight-chunk pipeline state shared by consecutive GEMMs
-  static constexpr bool BF = BF_;
+  static constexpr bool BF = MODE != 0;
+  static constexpr bool W16 = MODE == 2;
+  static constexpr int A2 = W16 ? 4 : 16;   // float offset of a lane's second 4-float k group inside a 32-deep chunk
   float* Bs;
   int par, wave;
   unsigned vrow, vslot; // per-lane DMA source: row within the first 32 (wave * 8 + lane / 8), swizzled slot byte offset
   template <int LDW>
   __device__ __forceinline__ unsigned voff() const { return vrow * (unsigned)(LDW * 4) + vslot; }
+  unsigned vrow16, vslot16;   // bf16 weights: row within the first 64 (wave * 16 + lane / 4), swizzled slot byte offset
+  template <int LDW>
+  __device__ __forceinline__ unsigned voff16() const { return vrow16 * (unsigned)(LDW * 2) + vslot16; }
   const float* b_lane; // fragment base: row li of buffer 0
   int bsl[2];          // swizzled slot offsets (floats) of the two 16-wide k groups
+  const float* b_lane16;  // bf16 tiles: row li (16 floats = 64 B per row) + this lane's swizzled slot
 };
-using WStream = WStreamT<false>;
+using WStream = WStreamT<0>;
 
 // acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
 // registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
@@ -97,6 +119,18 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
   constexpr int NPAIR = ROWS / 32;
   auto chunk = [&](int c, const f32x4 a0, const f32x4 a1) {
     float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
+    if constexpr (WS::W16) {
+      if (c + 1 < NCH) dma_chunk16<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff16<LDW>());
+      else if (Wn) dma_chunk16<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff16<LDW_NEXT>());
+      const float* bb = ws.b_lane16 + ((ws.par + c) & 1) * BT;
+      const bf16x8_t a8 = pack_bf16(a0, a1);
+#pragma unroll
+      for (int t = 0; t < ROWS / 16; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, *reinterpret_cast<const bf16x8_t*>(bb + t * 256), acc[t], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      return;
+    }
     if (c + 1 < NCH) dma_chunk<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff<LDW>());
     else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff<LDW_NEXT>());
     const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
@@ -136,7 +170,7 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
     chunk(1, xf[2], xf[3]);
   } else {
 #pragma unroll 1
-    for (int c = 0; c < NCH; ++c) chunk(c, ld4(a_lane + c * 32), ld4(a_lane + c * 32 + 16));
+    for (int c = 0; c < NCH; ++c) chunk(c, ld4(a_lane + c * 32), ld4(a_lane + c * 32 + WS::A2));
   }
   ws.par = (ws.par + NCH) & 1;
 }
@@ -154,6 +188,12 @@ __device__ __forceinline__ void wstream_init(WS& ws, float* Bs) {
   ws.b_lane = Bs + li * 32;
   ws.bsl[0] = ((lq) ^ ((li >> 1) & 7)) * 4;
   ws.bsl[1] = ((4 + lq) ^ ((li >> 1) & 7)) * 4;
+  // bf16 weight tiles: DMA lane -> (row wave * 16 + lane / 4, physical slot lane & 3 holds logical slot ^ ((row >> 2) & 3));
+  // fragment of lane (li, lq) in row block t: row 16 t + li, logical slot lq
+  const int r16 = lane >> 2;
+  ws.vrow16 = (unsigned)(ws.wave * 16 + r16);
+  ws.vslot16 = (unsigned)(((lane & 3) ^ ((r16 >> 2) & 3)) * 16);
+  ws.b_lane16 = Bs + li * 16 + ((lq ^ ((li >> 2) & 3)) * 4);
 }
 
 }  // namespace gd

@@ -112,6 +112,14 @@ class ConvGRUDecoder(nn.Module):
                          ptr(self.decoder[2].bias.detach()))
         return W, keep
 
+    def _weights16(self, W: DfGruWeights, keep: list) -> Tuple[DfGruWeights, list]:
+        """bf16 mode: the GEMM weights (w_zr, w_q, w_1) as bf16 copies -- one cast per use, i.e. per optimizer step -- for the
+        kernels' mfma_bf16 = 2 form (bf16 weight tiles in LDS, csrc/gemm_dma.h); every other field stays fp32"""
+        w_zr, _, w_q = keep
+        c16 = [w_zr.to(torch.bfloat16), w_q.to(torch.bfloat16), self.decoder[0].weight.detach().to(torch.bfloat16)]
+        W2 = DfGruWeights(W.w_off, W.b_off, ptr(c16[0]), W.b_zr, ptr(c16[1]), W.b_q, ptr(c16[2]), W.b_1, W.w_2, W.b_2)
+        return W2, keep + c16
+
     # -- engine ------------------------------------------------------------------------------------------
     def run(self, before: DfImg, after: DfImg, ps: PointSet, save: bool):
         """-> flow [B,N,3] (rows >= counts[b] are not written), save buffer or None."""
@@ -121,15 +129,18 @@ class ConvGRUDecoder(nn.Module):
         T = self.num_iters
         sv = torch.empty((5 * T + 1) * B * N * 128, dtype=torch.float32, device=dev) if save else None
         W, keep = self._weights()
+        bf = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
+        if bf:
+            W, keep = self._weights16(W, keep)
         # algorithmic work per point (un-hoisted count): 589 824 * T / 4 + 12 870 FLOP; fused-minimum traffic
         # 128 * 4 B gathered + 36 B of coordinates / offsets / flow
         with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
             call("df_gru_decoder_fwd_mp", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
-                 ptr(sv), int(ops.MFMA_BF16), stream())
+                 ptr(sv), 2 if bf else 0, stream())
         if sv is not None:
             # in bf16 mode planes 0..4 hold bf16 half rows (csrc/decoder3.hip): the backward kernels must run in the mode the
             # forward ran in, whatever ops.MFMA_BF16 says by then
-            sv.df_bf16 = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
+            sv.df_bf16 = bf
         return flow, sv
 
     def run_bf16(self, before: DfImg, after: DfImg, ps: PointSet):
@@ -165,6 +176,9 @@ class ConvGRUDecoder(nn.Module):
         wt_zr = ops.weight_transpose(w_zr.view(256, 1, 1, 192)).view(192, 256)
         wt_q = ops.weight_transpose(w_q.view(128, 1, 1, 192)).view(192, 128)
         wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
+        if bf:   # the kernels' mfma_bf16 = 2 form: bf16 copies of the GEMM weights
+            W, keep = self._weights16(W, keep)
+            wt_zr, wt_q, wt_1 = wt_zr.to(torch.bfloat16), wt_q.to(torch.bfloat16), wt_1.to(torch.bfloat16)
         WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
         dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
         dpre1, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
@@ -175,7 +189,7 @@ class ConvGRUDecoder(nn.Module):
         # gru_wgrad's)
         with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
             call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), bf, s)
+                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), 2 if bf else 0, s)
         bias_g = torch.empty(772, **f32)
         if nblocks >= 2048:  # tens of thousands of per-workgroup rows: two-stage column sum
             staged = torch.empty(64, 772, **f32)

@@ -271,7 +271,10 @@ int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const
  * way into v_mfma_f32_16x16x32_bf16; hidden state, gate math and accumulators stay fp32.  The saved planes h_in, z, r, q, r*h
  * (and the gate-gradient planes the backward puts in their place) are then stored as bf16 -- 128 values in the first 256 bytes
  * of each row's 512-byte slot, offsets as in the fp32 layout -- which halves the dominant HBM stream of the three kernels; hT
- * stays fp32.  df_gru_decoder_fwd_mp, df_gru_decoder_bwd_mp and df_gru_wgrad_mp of one step must get the same mfma_bf16. */
+ * stays fp32.  df_gru_decoder_fwd_mp, df_gru_decoder_bwd_mp and df_gru_wgrad_mp of one step must get the same mfma_bf16 (zero or
+ * not).  mfma_bf16 == 2 (forward and backward): the GEMM weights -- wts.w_zr, wts.w_q, wts.w_1 and wtt.wt_zr, wtt.wt_q, wtt.wt_1
+ * -- point at bf16 COPIES of the same [rows, cols] arrays (cast once per optimizer step); their tiles are then bf16 in LDS and
+ * every weight fragment is one 16-byte read.  All other fields of the weight structs stay fp32. */
 int df_gru_decoder_fwd_mp(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
                           int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16,
                           void* stream);
