@@ -260,6 +260,10 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   __shared__ int misc[12];
   __shared__ int clsw[5 * 4];      // per size class: occupied cells of each wavefront
   static_assert(CHUNK * 3 >= 256 * 8, "the statistics reduction reuses the point image");
+  // the occupied-cell list reuses the ranking scratch as 16-bit entries: up to BAND_CELLS cells can be occupied, which is
+  // more than CHUNK ints for the wide (2048-cell) band -- an int list overflowed into `spts` beyond 1024 occupied cells
+  static_assert(BAND_CELLS <= 2 * CHUNK && BAND_CELLS <= 65536, "occupied-cell list: BAND_CELLS 16-bit entries must fit in stage[]");
+  unsigned short* occ = reinterpret_cast<unsigned short*>(stage);
   float* red = spts;
   const df_pillar_geom& g = q.g;
   const int band = blockIdx.x, s = blockIdx.y, NB = q.NB, ncol = NB + 1;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
       const int c = (cell_cls >> (3 * k)) & 7;
 #pragma unroll
       for (int q = 0; q < NCLS; ++q)
-        if (c == q) stage[cls_ex[q]++] = threadIdx.x * (BAND_CELLS / 256) + k;
+        if (c == q) occ[cls_ex[q]++] = (unsigned short)(threadIdx.x * (BAND_CELLS / 256) + k);
     }
   if (a.cell_rng)   // dense [start, end) table, 8 B per cell
     for (int cell = threadIdx.x; cell < ncb; cell += 256) {
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
     return;
   }
   for (int oi = grp; oi < ((a.dbg & 1) ? 0 : n_occ); oi += ngrp) {
-    const int cell = stage[oi];
+    const int cell = occ[oi];
     const int k = cnt[cell];
     const int e = pos0[cell], b = e - k;
     auto ld = [&](int i, float (&p)[3]) {

@@ -23,9 +23,23 @@ from .timer import Timing
 from .unet import FastFlow3DUNet
 
 
-def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor) -> torch.Tensor:
-    """inv(pose1) @ pose0 -- 4x4 host-side plumbing ([REF deflow.py:18,67])."""
-    return torch.linalg.inv(pose1) @ pose0
+POSE_INVERSE = "rigid"   # "rigid" | "general" (torch.linalg.inv): see cal_pose0to1
+
+
+def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor, form: Optional[str] = None) -> torch.Tensor:
+    """inv(pose1) @ pose0 -- 4x4 host-side plumbing ([REF deflow.py:18,67]; the helper itself is in the un-vendored
+    OpenSceneFlow submodule: UNPINNED).  "rigid" (default, what upstream is recalled to do) inverts pose1 in closed form --
+    [R^T | R^T (-t)] -- and multiplies in that dtype; "general" is torch.linalg.inv(pose1) @ pose0 (rounds 1-2).  The two differ
+    in the last bits of T, which can move a point sitting on a cell edge into the neighbouring pillar; both are tested."""
+    form = POSE_INVERSE if form is None else form
+    if form == "general":
+        return torch.linalg.inv(pose1) @ pose0
+    if form != "rigid":
+        raise ValueError(f"unknown pose inverse form {form!r} (rigid, general)")
+    inv = torch.eye(4, dtype=pose1.dtype, device=pose1.device)
+    inv[:3, :3] = pose1[:3, :3].T
+    inv[:3, 3] = (pose1[:3, :3].T * -pose1[:3, 3]).sum(axis=1)
+    return inv @ pose0.type(inv.dtype)
 
 
 class DeFlow(nn.Module):

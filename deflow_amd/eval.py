@@ -1,5 +1,7 @@
-"""``python -m deflow_amd.eval checkpoint=<ckpt> av2_mode=val val_data=<dir>``: the reference's evaluation entry for this
-model plugin ([REF README.md:88]: "python eval.py checkpoint=... av2_mode=val  # it will directly prints all metric").
+"""``python -m deflow_amd.eval checkpoint=<ckpt> av2_mode=val dataset_path=<root>``: the reference's evaluation entry for this
+model plugin ([REF README.md:88]: "python eval.py checkpoint=... av2_mode=val  # it will directly prints all metric";
+[REF assets/slurm/2_eval.sh:33-35]: ``eval.py wandb_mode=online dataset_path=/scratch/local/av2/sensor av2_mode=val checkpoint=...``
+-> the scene files under ``<dataset_path>/val``; ``val_data=<dir>`` names the directory directly).
 
 The checkpoint carries its training configuration (``hyper_parameters``, as Lightning checkpoints do), so only the
 checkpoint and the data need naming.  Metrics: deflow_amd/metrics.py (EPE, accuracy, 3-way EPE) averaged over the sweeps
@@ -13,7 +15,7 @@ import sys
 
 import torch
 
-from .train import DEFAULTS, build_model, grid_from, parse_overrides
+from .train import DATA_KEYS, DEFAULTS, _TARGET_ALIASES, build_model, grid_from, parse_overrides
 
 
 def main(argv=None):
@@ -32,15 +34,32 @@ def main(argv=None):
     cfg = dict(DEFAULTS)
     hp = plain(ckpt.get("hyper_parameters", {}))
     saved = flatten(hp.get("cfg", hp) if isinstance(hp, dict) else {})
-    cfg.update({k: v for k, v in saved.items() if k in DEFAULTS})
-    typed = parse_overrides([a for k, a in given.items() if k not in ("av2_mode", "leaderboard_version", "inference_dtype")])
-    cfg.update({k: typed[k] for k in given if k in typed})
+    # nested reference configs name the architecture ``model.name`` (and repeat voxel_size / point_cloud_range under
+    # ``model.target``): map them onto this trainer's keys BEFORE filtering, or a fastflow3d checkpoint is built as DeFlow and
+    # loaded with strict=False
+    saved = {_TARGET_ALIASES.get(k, k): v for k, v in saved.items()}
+    cfg.update({k: v for k, v in saved.items() if k in DEFAULTS and k not in DATA_KEYS and not isinstance(v, dict)})
+    typed = parse_overrides([a for k, a in given.items() if k not in ("leaderboard_version", "inference_dtype")])
+    cfg.update({k: typed[k] for k in typed["_given"] if k in typed})
+    for k in ("train_data", "val_data"):       # dataset_path=<root> [REF 2_eval.sh:33-35] -> <root>/val
+        if typed[k] != DEFAULTS[k]:
+            cfg[k] = typed[k]
+    if cfg["model"] == "fastflow3d":
+        cfg["model.target.decoder_option"] = "linear"
+    if not any(k in given for k in DATA_KEYS):
+        print("[deflow_amd.eval] NOTE: no dataset_path= / val_data= given -- evaluating on seeded SYNTHETIC pairs, not on a "
+              "dataset (the reference reads its config's dataset_path default here)", file=sys.stderr)
+    elif cfg["val_data"] == "synthetic" and given.get("val_data") != "val_data=synthetic":
+        raise SystemExit("a data key was given but no validation directory resulted from it; refusing to fall back to synthetic data")
     assert torch.cuda.is_available(), "evaluation runs on the HIP engine only"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     from .metrics import evaluate_batch
     model = build_model(cfg).to(dev)
-    model.load_from_checkpoint(path)
+    res = model.load_from_checkpoint(path)
+    if res.missing_keys or res.unexpected_keys:   # strict=False as the reference loads [REF deflow.py:47] -- but never silently
+        print(f"[deflow_amd.eval] WARNING: checkpoint / model mismatch (model={cfg['model']}): {len(res.missing_keys)} missing keys "
+              f"{res.missing_keys[:4]}..., {len(res.unexpected_keys)} unexpected keys {res.unexpected_keys[:4]}...", file=sys.stderr)
     model.eval()
     if "inference_dtype" in given:
         model.inference_dtype = given["inference_dtype"].split("=", 1)[1]

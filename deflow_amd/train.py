@@ -31,13 +31,20 @@ DEFAULTS: Dict[str, Any] = {
 }
 
 
-# hydra / wandb / slurm plumbing of the reference's command lines [REF 1_train.sh:28-78]: accepted silently, unused here
-_IGNORED_PREFIXES = ("wandb", "slurm", "hydra", "model.target.", "model.val_monitor", "exp_note", "save_top_model",
-                     "val_every", "dataset_path", "av2_mode", "leaderboard_version", "gpus", "sync_bn", "optimizer")
+# hydra / wandb / slurm plumbing of the reference's command lines [REF 1_train.sh:28-78]: no-op here, accepted silently.
+# Nothing that selects data, the model or the optimizer is in this list: a mistyped ``model.target.num_iter=8`` or
+# ``optimizer.lr=`` must not train with the defaults.
+_IGNORED_PREFIXES = ("wandb", "slurm", "hydra", "model.val_monitor", "exp_note", "save_top_model", "val_every",
+                     "leaderboard_version", "save_res", "output")
+# the keys of the reference's ``model.target`` block that arrive as top-level interpolations upstream (${voxel_size} ...)
+_TARGET_ALIASES = {"model.target.voxel_size": "voxel_size", "model.target.point_cloud_range": "point_cloud_range",
+                   "model.name": "model", "optimizer.lr": "lr"}
+DATA_KEYS = ("dataset_path", "train_data", "val_data")
 
 
 def parse_overrides(argv: List[str]) -> Dict[str, Any]:
     cfg = dict(DEFAULTS)
+    given = set()
     for a in argv:
         if "=" not in a:
             raise SystemExit(f"expected key=value, got {a!r}")
@@ -47,16 +54,51 @@ def parse_overrides(argv: List[str]) -> Dict[str, Any]:
             val = ast.literal_eval(v)
         except (ValueError, SyntaxError):
             val = v
-        if k not in DEFAULTS and not k.startswith(_IGNORED_PREFIXES):
+        k = _TARGET_ALIASES.get(k, k)
+        if k == "dataset_path":
+            # the reference's data root [REF 2_eval.sh:33-35; 1_train.sh:12-14]: <root>/train and <root>/val hold the scene files
+            # (upstream's config interpolates train_data / val_data from it); explicit train_data= / val_data= win
+            cfg["dataset_path"] = str(val)
+        elif k == "av2_mode":
+            if val not in ("val", "test"):
+                raise SystemExit(f"unknown av2_mode {val!r} (val, test)")
+            cfg["av2_mode"] = val
+        elif k == "gpus":
+            print(f"[deflow_amd.train] note: gpus={val} is set by the launcher here (python -m torch.distributed.run "
+                  "--nproc-per-node N -m deflow_amd.train ...): one process per GPU", file=sys.stderr)
+            continue
+        elif k == "model.target.grid_feature_size":
+            cfg["_grid_feature_size"] = list(val)        # checked against voxel_size / point_cloud_range below
+            continue
+        elif k == "optimizer.name":
+            if str(val).lower() != "adam":
+                raise SystemExit(f"optimizer.name={val!r}: this trainer implements Adam (the reference's optimizer) only")
+            continue
+        elif k.startswith(("model.target.", "optimizer.")) and k not in DEFAULTS:
+            known = sorted(x for x in list(DEFAULTS) + list(_TARGET_ALIASES) if x.startswith(("model.target.", "optimizer.")))
+            raise SystemExit(f"unknown override {k!r}; known: {', '.join(known)}, model.target.grid_feature_size")
+        elif k not in DEFAULTS and not k.startswith(_IGNORED_PREFIXES):
             print(f"[deflow_amd.train] warning: unknown override {k!r} (accepted, unused); known keys: "
                   f"{', '.join(sorted(DEFAULTS))}", file=sys.stderr)
-        cfg[k] = val
+        given.add(k)
+        if k not in ("dataset_path", "av2_mode"):
+            cfg[k] = val
+    root = cfg.get("dataset_path")
+    if root:
+        if "train_data" not in given:
+            cfg["train_data"] = os.path.join(root, "train")
+        if "val_data" not in given:
+            cfg["val_data"] = os.path.join(root, "val")
+    cfg["_given"] = sorted(given)
     if cfg["model"] not in ("deflow", "fastflow3d"):
         raise SystemExit(f"unknown model {cfg['model']!r}")
     if cfg["model"] == "fastflow3d":
         cfg["model.target.decoder_option"] = "linear"
     if cfg["loss_fn"] not in ("deflowLoss", "ff3dLoss", "zeroflowLoss"):
         raise SystemExit(f"unknown loss_fn {cfg['loss_fn']!r} (deflowLoss, ff3dLoss, zeroflowLoss)")
+    gfs = cfg.pop("_grid_feature_size", None)
+    if gfs is not None and list(gfs) != grid_from(cfg):
+        raise SystemExit(f"model.target.grid_feature_size={gfs} does not match voxel_size / point_cloud_range ({grid_from(cfg)})")
     return cfg
 
 
@@ -75,6 +117,7 @@ def build_model(cfg):
 def save_checkpoint(path: str, model, trainer, cfg, epoch: int, step: int):
     sd = {"model." + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
     opt = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in trainer.opt.state_dict().items()}
+    cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
     torch.save({"state_dict": sd, "hyper_parameters": {"cfg": cfg}, "epoch": epoch, "global_step": step,
                 "optimizer_states": [opt], "pytorch-lightning_version": "deflow_amd"}, path)
 

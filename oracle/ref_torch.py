@@ -346,9 +346,24 @@ class LinearDecoder(nn.Module):
 # ----------------------------------------------------------------------------------------
 
 
-def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor) -> torch.Tensor:
-    """inv(pose1) @ pose0 (UNPINNED; call site [REF deflow.py:67])."""
-    return torch.linalg.inv(pose1) @ pose0
+POSE_INVERSE = "rigid"   # "rigid" | "general": which restatement of the absent upstream helper cal_pose0to1 uses
+
+
+def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor, form: str = None) -> torch.Tensor:
+    """inv(pose1) @ pose0 (UNPINNED: the helper lives in the un-vendored OpenSceneFlow submodule; call site [REF deflow.py:18,67]).
+    Two restatements, because the last bit of T decides which 0.2 m cell a point on a cell edge falls into:
+      "rigid"   (default; what upstream is recalled to do): the closed-form inverse of a rigid transform,
+                inv = [R^T | (R^T * -t).sum(1)], then inv @ pose0 in inv's dtype;
+      "general" (rounds 1-2): torch.linalg.inv(pose1) @ pose0 (LU).
+    Both are exact for exactly orthonormal R; on fp32 poses they differ by ~1e-7."""
+    form = POSE_INVERSE if form is None else form
+    if form == "general":
+        return torch.linalg.inv(pose1) @ pose0
+    assert form == "rigid", form
+    inv = torch.eye(4, dtype=pose1.dtype, device=pose1.device)
+    inv[:3, :3] = pose1[:3, :3].T
+    inv[:3, 3] = (pose1[:3, :3].T * -pose1[:3, 3]).sum(axis=1)
+    return inv @ pose0.type(inv.dtype)
 
 
 class DeFlow(nn.Module):

@@ -7,6 +7,9 @@ ego-motion step and the voxel coordinates stay fp32, because they decide which c
 
     err(HIP, fp64)  <=  max(1e-4, 4 x err(oracle_fp32, fp64))
 
+in three norms (round 3): max-abs / max|ref| as before, rms-relative (||d||_2 / ||ref||_2: a tensor whose small entries are all
+wrong fails this one) and 1 - cosine (bound squared, since 1 - cos ~ rms^2 / 2).
+
 i.e. the HIP path must be within the north-star tolerance of the exact result, or -- for the few tensors where fp32 itself
 cannot do better (ill-conditioned sums) -- no worse than a small multiple of what the reference arithmetic achieves.
 Every comparison is appended to ``gpurun_out/parity_report.jsonl`` (pulled back by gpurun; also printed with ``-rA``).
@@ -38,13 +41,35 @@ def record(test: str, name: str, **kw):
         pass
 
 
+def rms_rel(got, want) -> float:
+    """||got - want||_2 / ||want||_2 -- the whole tensor's error, not its single worst element"""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-300))
+
+
+def one_minus_cos(got, want) -> float:
+    got, want = got.detach().double().cpu().reshape(-1), want.detach().double().cpu().reshape(-1)
+    den = float(got.norm() * want.norm())
+    return 0.0 if den == 0.0 else max(0.0, 1.0 - float(torch.dot(got, want)) / den)
+
+
 def three_way(test: str, name: str, got, ref32, ref64, floor: float = FLOOR, factor: float = FACTOR) -> float:
-    """assert err(got, fp64) <= max(floor, factor * err(oracle fp32, fp64)); returns err(got, fp64)"""
+    """assert err(got, fp64) <= max(floor, factor * err(oracle fp32, fp64)) in THREE norms; returns the max-norm err(got, fp64).
+      * max-abs error / max|reference|   (round 1-2's only figure: blind to small entries that are 100 % wrong)
+      * rms-relative  ||got - ref||_2 / ||ref||_2   with the same floor / factor
+      * 1 - cosine(got, ref) <= max(floor^2, factor^2 * (1 - cos(oracle fp32, ref)))   (direction of the whole tensor; 1 - cos ~ rms^2 / 2)"""
     e_hip, e_o32 = rel_err(got, ref64), rel_err(ref32, ref64)
-    bound = max(floor, factor * e_o32)
-    record(test, name, err_hip_vs_fp64=e_hip, err_oracle32_vs_fp64=e_o32, bound=bound, ok=e_hip <= bound)
-    print(f"[parity] {test} {name}: HIP vs fp64 {e_hip:.2e} | oracle fp32 vs fp64 {e_o32:.2e} | bound {bound:.1e}")
+    r_hip, r_o32 = rms_rel(got, ref64), rms_rel(ref32, ref64)
+    c_hip, c_o32 = one_minus_cos(got, ref64), one_minus_cos(ref32, ref64)
+    bound, rbound, cbound = max(floor, factor * e_o32), max(floor, factor * r_o32), max(floor * floor, factor * factor * c_o32)
+    ok = e_hip <= bound and r_hip <= rbound and c_hip <= cbound
+    record(test, name, err_hip_vs_fp64=e_hip, err_oracle32_vs_fp64=e_o32, bound=bound, rms_hip=r_hip, rms_oracle32=r_o32, rms_bound=rbound,
+           one_minus_cos_hip=c_hip, one_minus_cos_oracle32=c_o32, cos_bound=cbound, ok=ok)
+    print(f"[parity] {test} {name}: HIP vs fp64 max {e_hip:.2e} rms {r_hip:.2e} 1-cos {c_hip:.1e} | oracle fp32 vs fp64 max {e_o32:.2e} "
+          f"rms {r_o32:.2e} | bounds {bound:.1e} / {rbound:.1e} / {cbound:.1e}")
     assert e_hip <= bound, f"{test} {name}: err(HIP, fp64) = {e_hip:.3e} > {bound:.1e} (oracle fp32 vs fp64: {e_o32:.3e})"
+    assert r_hip <= rbound, f"{test} {name}: rms-rel(HIP, fp64) = {r_hip:.3e} > {rbound:.1e} (oracle fp32 vs fp64: {r_o32:.3e})"
+    assert c_hip <= cbound, f"{test} {name}: 1 - cos(HIP, fp64) = {c_hip:.3e} > {cbound:.1e} (oracle fp32 vs fp64: {c_o32:.3e})"
     return e_hip
 
 

@@ -483,6 +483,85 @@ def test_pillar_bands_equal_first_generation(dev, monkeypatch, S, N, grid, ext, 
         assert torch.equal(c2, c1)
 
 
+def _dense_cloud(S, N, seed, extent, rows_m):
+    """uniform in x over the whole grid, uniform in y over +-rows_m metres: most cells of the central bands are occupied"""
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.cat([(torch.rand(S, N, 1, generator=g) - 0.5) * 2.02 * extent, (torch.rand(S, N, 1, generator=g) - 0.5) * 2 * rows_m,
+                     torch.rand(S, N, 1, generator=g) * 6.6 - 3.3], 2)
+    pts[:, -N // 50:] = float("nan")
+    return pts
+
+
+BAND_ORACLE_CASES = [  # S, N, grid, extent, dense rows (m; 0 = gaussian cloud), DF_P2_MIN_WGS
+    (3, 700, 64, 6.4, 0, None), (2, 20000, 256, 25.6, 0, None), (2, 80000, 512, 51.2, 0, None), (1, 160000, 1024, 51.2, 0, None),
+    (5, 1023, 64, 6.4, 0, None), (1, 1025, 128, 12.8, 0, None),
+    # the WIDE band kernel (4 x 512 = 2048 cells per band, the form the B = 16 bench runs) with > 1024 occupied cells in a
+    # band: round 2's int-typed occupied-cell list overflowed its 1024-entry LDS array here (ADVICE r2, high)
+    (2, 100000, 512, 51.2, 10.0, "1"), (1, 200000, 1024, 51.2, 4.0, "1"),
+]
+
+
+@pytest.mark.parametrize("S,N,grid,ext,dense,min_wgs", BAND_ORACLE_CASES)
+@pytest.mark.parametrize("train", [False, True])
+def test_pillar_bands_vs_oracle(dev, monkeypatch, S, N, grid, ext, dense, min_wgs, train):
+    """the band pipeline (hist / scan / scatter / band) against the CPU oracle alone: compaction outputs, the (sample, cell)-
+    sorted arrays (= a stable sort of the valid points by cell key, input order inside a cell), the dense cell table, and the
+    canvas incl. its zeros (NaN-poisoned before the call)"""
+    from deflow_amd.encoder import DynamicEmbedder
+    from deflow_amd._lib import img
+    from oracle import ref_torch as O
+    if min_wgs is not None:
+        monkeypatch.setenv("DF_P2_MIN_WGS", min_wgs)
+    vs, rng, dims = [2 * ext / grid, 2 * ext / grid, 6], [-ext, -ext, -3, ext, ext, 3], [grid, grid]
+    pts = _dense_cloud(S, N, 77 + N, ext, dense) if dense else _cloud(S, N, 1000 + N, ext)
+    torch.manual_seed(5)
+    ref = O.DynamicEmbedder(vs, dims, rng, 32)
+    bn = ref.feature_net.pfn_layers[0][1]
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    mine = DynamicEmbedder(vs, dims, rng, 32)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).train(train)
+    ref.train(train)
+    with torch.no_grad():
+        want_img, want_infos = ref(pts)
+    canvas = torch.full((S, grid, grid, 32), float("nan"), device=dev)
+    with torch.no_grad():
+        st = mine.pillarize(pts.to(dev), img(canvas), train)
+    torch.cuda.synchronize()
+    counts = st.counts.cpu().tolist()
+    assert counts == [int(i["voxel_coords"].shape[0]) for i in want_infos]
+    keys, idxs, ptss = [], [], []
+    for b in range(S):
+        m = counts[b]
+        wi = want_infos[b]
+        assert torch.equal(st.coords_c[b, :m].cpu().long(), wi["voxel_coords"].long()), b
+        assert torch.equal(st.idx_c[b, :m].cpu(), wi["point_idxes"].long()), b
+        assert torch.equal(st.points_c[b, :m].cpu(), wi["points"]) and torch.equal(st.offs_c[b, :m].cpu(), wi["point_offsets"]), b
+        key = b * grid * grid + wi["voxel_coords"][:, 1].long() * grid + wi["voxel_coords"][:, 2].long()
+        order = torch.sort(key, stable=True).indices
+        keys.append(key[order]); idxs.append(b * N + wi["point_idxes"].long()[order]); ptss.append(wi["points"][order])
+    key_want, idx_want, pts_want = torch.cat(keys), torch.cat(idxs), torch.cat(ptss)
+    tot = sum(counts)
+    assert torch.equal(st.key_sorted[:tot].cpu().long(), key_want) and torch.equal(st.idx_sorted[:tot].cpu().long(), idx_want)
+    assert torch.equal(st.pts_sorted[:tot].cpu(), pts_want)
+    # dense [start, end) table: runs of equal keys; empty cells hold (0, 0)
+    uk, cnt = torch.unique_consecutive(key_want, return_counts=True)
+    end = torch.cumsum(cnt, 0)
+    rng_want = torch.zeros(S * grid * grid, 2, dtype=torch.int32)
+    rng_want[uk, 0], rng_want[uk, 1] = (end - cnt).int(), end.int()
+    assert torch.equal(st.cell_rng.cpu(), rng_want)
+    if dense:   # the case the test exists for: more than 1024 occupied cells inside one band of the wide kernel
+        R = 2048 // grid
+        occ_per_band = torch.bincount((uk % (grid * grid)) // (R * grid) + (uk // (grid * grid)) * (grid // R))
+        assert int(occ_per_band.max()) > 1024, int(occ_per_band.max())
+    assert torch.isfinite(canvas).all(), "every canvas byte must be written (zeros included)"
+    check(f"band canvas vs oracle train={train}", canvas.permute(0, 3, 1, 2), want_img, 2e-5)
+    if train:
+        check("band running_mean", mine._bn.running_mean, bn.running_mean, 1e-5)
+        check("band running_var", mine._bn.running_var, bn.running_var, 1e-5)
+
+
 @pytest.mark.parametrize("H,W,N", [(40, 72, 5000), (104, 24, 3000), (8, 1000, 4097)])
 def test_pillar_bands_rectangular_grids(dev, monkeypatch, H, W, N):
     """non-square grids whose height is not a multiple of the band height, a width that is not a power of two, a single-band

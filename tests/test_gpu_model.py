@@ -309,6 +309,46 @@ def test_g5_orchestration_golden(dev, golden_dir):
         check(f"g5 pose_flow b{b}", res["pose_flow"][b].cpu()[m], w[m], 1e-4)
 
 
+@pytest.mark.parametrize("form", ["rigid", "general"])
+def test_pose_inverse_forms_vs_oracle(dev, monkeypatch, form):
+    """both restatements of the UNPINNED upstream helper cal_pose0to1 (closed-form rigid inverse = default; torch.linalg.inv =
+    rounds 1-2) through the whole forward with NON-identity pose0 and pose1: pose_flow, the transformed points and the flow
+    against the oracle using the same form"""
+    from oracle import ref_torch as O
+    from deflow_amd import deflow as D
+    monkeypatch.setattr(O, "POSE_INVERSE", form)
+    monkeypatch.setattr(D, "POSE_INVERSE", form)
+    ref, mine = build_pair(dev, 3, decoder_option="gru", num_iters=2)
+    ref.eval(); mine.eval()
+    batch = make_batch(2, 1500, 4100)
+    g = torch.Generator().manual_seed(8)
+    world = []
+    for b in range(2):            # world poses: pose1 = W, pose0 = W @ T  ->  inv(pose1) @ pose0 = T up to rounding
+        yaw = float(torch.rand(1, generator=g)) * 6.28
+        W = torch.eye(4)
+        W[0, 0] = W[1, 1] = math.cos(yaw); W[0, 1] = -math.sin(yaw); W[1, 0] = math.sin(yaw)
+        W[:3, 3] = torch.randn(3, generator=g) * 3.0
+        world.append(W)
+    T = torch.stack([torch.linalg.inv(p) for p in batch["pose1"]])
+    batch["pose1"] = torch.stack(world)
+    batch["pose0"] = torch.stack([w @ t for w, t in zip(world, T)])
+    with torch.no_grad():
+        want = ref(batch)
+        got = mine(to_dev(batch, dev))
+    for b in range(2):
+        w = want["pose_flow"][b]
+        m = ~torch.isnan(w)
+        check(f"pose_flow[{b}] ({form})", got["pose_flow"][b].cpu()[m], w[m], 1e-5)
+        # a 4x4 product on the device vs on the host may differ in the last bit, which can move a point sitting on a cell
+        # edge: compare the points both sides kept
+        gi, wi = got["pc0_valid_point_idxes"][b].cpu(), want["pc0_valid_point_idxes"][b]
+        common = torch.isin(gi, wi)
+        assert common.float().mean() > 0.995 and abs(len(gi) - len(wi)) <= 3
+        sel_w = torch.isin(wi, gi)
+        tol = 1e-4 if (bool(common.all()) and len(gi) == len(wi)) else 5e-3   # a moved point changes its two pillars' features
+        check(f"flow[{b}] ({form})", got["flow"][b].cpu()[common], want["flow"][b][sel_w], tol)
+
+
 def test_full_size_properties(dev):
     """BASELINE config 2 shape (512x512, 80k points, 4 iterations): size-independent properties."""
     import deflow_amd
@@ -888,14 +928,40 @@ def test_config0_fastflow3d_ff3dloss_bs1_from_scene_files(dev, tmp_path, capsys)
     shutil.copy(os.path.join(root, "scene_a.h5"), one / "scene_a.h5")
     index = [e for e in pickle.load(open(os.path.join(root, "index_total.pkl"), "rb")) if e[0] == "scene_a"]
     pickle.dump(index, open(one / "index_total.pkl", "wb"))
+    # the reference's data root layout [REF 1_train.sh:12-14; 2_eval.sh:13]: <dataset_path>/train and <dataset_path>/val
+    sensor = tmp_path / "av2" / "sensor"
+    shutil.copytree(one, sensor / "train")
+    shutil.copytree(one, sensor / "val")
     ck = tmp_path / "ff3d.ckpt"
     T.main(["model=fastflow3d", "lr=4e-5", "epochs=1", "batch_size=1", "loss_fn=ff3dLoss", "voxel_size=[0.4, 0.4, 6]",
-            f"train_data={one}", f"val_data={one}", "num_workers=2", "log_every=4", f"save_checkpoint={ck}"])
+            f"dataset_path={sensor}", "num_workers=2", "log_every=4", f"save_checkpoint={ck}"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     steps = [l for l in lines if "trainer/loss" in l]
     assert len(steps) == len(index) // 4 and all(np.isfinite(l["trainer/loss"]) for l in steps)
+    val = [l for l in lines if "val" in l]
     m = E.main([f"checkpoint={ck}", "av2_mode=val", f"val_data={one}", "num_workers=2"])
     assert np.isfinite(m["EPE"]) and m["n"] > 0
+    # the reference's LITERAL evaluation command [REF assets/slurm/2_eval.sh:33-35]:
+    #   eval.py wandb_mode=online dataset_path=/scratch/local/av2/sensor av2_mode=val checkpoint=<ckpt>
+    # must read <dataset_path>/val (round 2 silently evaluated synthetic pairs here)
+    m2 = E.main(["wandb_mode=online", f"dataset_path={sensor}", "av2_mode=val", f"checkpoint={ck}"])
+    line = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert line["val_data"] == str(sensor / "val") and line["model"] == "fastflow3d"
+    assert m2["n"] == m["n"] and abs(m2["EPE"] - m["EPE"]) < 1e-6 and abs(m2["EPE"] - val[-1]["val"]["EPE"]) < 1e-3
+    with pytest.raises(Exception):      # a data key that leads nowhere must not fall back to synthetic pairs
+        E.main([f"dataset_path={tmp_path / 'nowhere'}", "av2_mode=val", f"checkpoint={ck}"])
+    # a checkpoint whose configuration is NESTED the way the reference's hydra / Lightning files are (model.name,
+    # model.target.*): the architecture must come back from it (was built as DeFlow and loaded with strict=False)
+    sd = torch.load(ck, map_location="cpu", weights_only=False)
+    sd["hyper_parameters"] = {"cfg": {"model": {"name": "fastflow3d", "target": {"_target_": "scripts.network.models.fastflow3d.FastFlow3D",
+                                                                                "voxel_size": [0.4, 0.4, 6], "num_iters": 4}},
+                                      "voxel_size": [0.4, 0.4, 6], "point_cloud_range": [-51.2, -51.2, -3, 51.2, 51.2, 3],
+                                      "batch_size": 1, "lr": 4e-5, "dataset_path": "/somewhere/else"}}
+    nested = tmp_path / "nested.ckpt"
+    torch.save(sd, nested)
+    m3 = E.main([f"dataset_path={sensor}", "av2_mode=val", f"checkpoint={nested}"])
+    cap = capsys.readouterr()
+    assert "mismatch" not in cap.err and abs(m3["EPE"] - m["EPE"]) < 1e-6
 
 
 def test_gradient_clipping_matches_clip_grad_norm(dev):

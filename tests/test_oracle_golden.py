@@ -233,3 +233,39 @@ def test_f64_twin_convwithnorms(golden_dir, tag):
     y.backward(_t(g["gy"]).double())
     _close(x.grad, g64["gx"], rtol=1e-10, atol=1e-13)
     _close(m.batchnorm.running_var, g64["running_var"], rtol=1e-12, atol=1e-14)
+
+
+def _rigid(seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    T = torch.eye(4, dtype=torch.float64)
+    T[:3, :3] = q
+    T[:3, 3] = torch.randn(3, generator=g, dtype=torch.float64) * 30
+    return T.to(dtype)
+
+
+def test_cal_pose0to1_forms():
+    """cal_pose0to1 is UNPINNED (its source is in the un-vendored OpenSceneFlow submodule; call site [REF deflow.py:18,67]).
+    Both restatements -- closed-form rigid inverse (default, what upstream is recalled to do) and torch.linalg.inv -- are kept:
+    they agree to fp32 rounding on rigid poses, the product's function equals the oracle's bit for bit in each form, and in
+    float64 each is an exact inverse (pose1 -> pose1 gives the identity)."""
+    import deflow_amd
+    from oracle import ref_torch as O
+    from deflow_amd import deflow as D
+    assert O.POSE_INVERSE == D.POSE_INVERSE == "rigid"
+    for seed in range(5):
+        p0, p1 = _rigid(seed), _rigid(100 + seed)
+        for form in ("rigid", "general"):
+            a, b = O.cal_pose0to1(p0, p1, form), deflow_amd.cal_pose0to1(p0, p1, form)
+            assert torch.equal(a, b), form
+        r, g = O.cal_pose0to1(p0, p1, "rigid"), O.cal_pose0to1(p0, p1, "general")
+        exact = torch.linalg.inv(p1.double()) @ p0.double()
+        assert float((r - g).abs().max()) < 2e-4 * float(exact.abs().max())          # translations are O(30 m) in fp32
+        assert float((r.double() - exact).abs().max()) < 1e-4 and float((g.double() - exact).abs().max()) < 1e-4
+        d0, d1 = _rigid(seed, torch.float64), _rigid(100 + seed, torch.float64)
+        for form in ("rigid", "general"):
+            assert float((O.cal_pose0to1(d1, d1, form) - torch.eye(4, dtype=torch.float64)).abs().max()) < 1e-12
+    with pytest.raises(ValueError):
+        deflow_amd.cal_pose0to1(p0, p1, "svd")

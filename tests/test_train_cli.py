@@ -18,6 +18,33 @@ def test_parse_overrides_reference_commands():
     assert parse_overrides(["loss_fn=zeroflowLoss"])["loss_fn"] == "zeroflowLoss"                       # [REF 1_train.sh:70]
     with pytest.raises(SystemExit):
         parse_overrides(["loss_fn=chamferLoss"])
+    # the 16-iteration ablation and the 0.4 m fastflow3d resolution [REF 1_train.sh:50,78]
+    assert parse_overrides(["model=deflow", "model.target.num_iters=16"])["model.target.num_iters"] == 16
+    c = parse_overrides(["model=fastflow3d", "voxel_size=[0.4, 0.4, 6]"])
+    assert grid_from(c) == [256, 256]
+
+
+def test_dataset_path_and_strict_keys():
+    """[REF 2_eval.sh:33-35; 1_train.sh:30]: dataset_path=<root> names <root>/train and <root>/val; keys that select the model
+    or the optimizer are never swallowed silently (`model.target.num_iter=8` trained with the default)"""
+    from deflow_amd.train import parse_overrides
+    c = parse_overrides(["wandb_mode=online", "dataset_path=/scratch/local/av2/sensor", "av2_mode=val", "checkpoint=/x/y.ckpt"])
+    assert c["val_data"] == "/scratch/local/av2/sensor/val" and c["train_data"] == "/scratch/local/av2/sensor/train"
+    c = parse_overrides(["dataset_path=/d", "val_data=/elsewhere/val"])
+    assert c["val_data"] == "/elsewhere/val" and c["train_data"] == "/d/train"
+    c = parse_overrides("slurm_id=1 wandb_mode=online train_data=/s/train val_data=/s/val num_workers=16 model=deflow lr=2e-6 "
+                        "epochs=50 batch_size=10 loss_fn=deflowLoss".split())                                # [REF 1_train.sh:28-30]
+    assert c["train_data"] == "/s/train" and c["num_workers"] == 16 and c["batch_size"] == 10
+    for bad in ("model.target.num_iter=8", "optimizer.learning_rate=1e-3", "model.target.decoder=gru", "optimizer.name=SGD"):
+        with pytest.raises(SystemExit):
+            parse_overrides([bad])
+    assert parse_overrides(["optimizer.lr=1e-3"])["lr"] == 1e-3 and parse_overrides(["optimizer.name=Adam"])["lr"] == 2e-4
+    assert parse_overrides(["model.name=fastflow3d"])["model.target.decoder_option"] == "linear"
+    assert parse_overrides(["model.target.grid_feature_size=[512, 512]"])["voxel_size"] == [0.2, 0.2, 6]
+    with pytest.raises(SystemExit):
+        parse_overrides(["model.target.grid_feature_size=[256, 256]"])
+    with pytest.raises(SystemExit):
+        parse_overrides(["av2_mode=train"])
 
 
 def test_checkpoint_roundtrip_lightning_layout(tmp_path):
