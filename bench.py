@@ -217,6 +217,7 @@ def main():
 
     exposed = None
     bf16_multi = None
+    graph_multi = None
     if world > 1 and not args.no_extras:
         # BASELINE configs[4] ("bf16 MFMA, 8xMI355X"): the same data-parallel step with dtype=bf16, collectives on, timed the same way
         trainer.mfma_bf16 = True
@@ -228,12 +229,49 @@ def main():
         dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
         bf16_multi = (float(tb_.item()), float(lossb_))
         # how much of the gradient all-reduce is NOT hidden behind the backward: the same steps without the collectives
-        # (replicas drift apart afterwards -- nothing is measured after this)
+        # (replicas drift apart afterwards -- only timings are taken after this)
         trainer.collective = trainer.sink.collective = False
         dt_nc, _, _ = timed_steps(args.steps)
         tn = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
         dist.all_reduce(tn, op=dist.ReduceOp.MAX)
         exposed = (dt - float(tn.item())) / args.steps * 1e3
+        trainer.collective = trainer.sink.collective = True
+        # the data-parallel bf16 step as a captured PROGRAM (HIP-graph segments split at the gradient buckets, the collectives
+        # between them: optim.SegmentedCapture) -- the host-free form of the step the 8-GPU deployment runs.  Last, and guarded:
+        # a failure here must not take the headline with it
+        try:
+            trainer.mfma_bf16 = True
+            trainer.capture(batch)
+            for _ in range(2):
+                trainer.step_captured()
+            barrier()
+            tg0 = time.perf_counter()
+            for _ in range(args.steps):
+                trainer.step_captured()
+            torch.cuda.synchronize()
+            tloc = time.perf_counter() - tg0
+            barrier()
+            tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            hosts = []
+            for _ in range(5):          # host cost of ONE replayed step with an empty queue (no back-pressure from the GPU)
+                barrier()
+                th = time.perf_counter()
+                if share_gpu:           # gloo's all_reduce blocks the host on the device: time the graph launches alone
+                    for o in trainer._program:
+                        if o[0] == "graph":
+                            o[1].replay()
+                else:
+                    trainer.step_captured()
+                hosts.append((time.perf_counter() - th) * 1e3)
+            torch.cuda.synchronize()
+            kinds = [o[0] for o in trainer._program]
+            graph_multi = {"workload": "the data-parallel bf16 step replayed as HIP-graph segments split at the gradient buckets, collectives between them",
+                           "ms_per_step": float(tg.item()) / args.steps * 1e3, "host_ms_per_step": statistics.median(hosts),
+                           "graph_segments": kinds.count("graph"), "allreduce_calls": sum(len(o[1]) for o in trainer._program if o[0] == "allreduce")}
+        except Exception as e:      # noqa: BLE001 -- reported in the line, never fatal
+            graph_multi = {"error": f"{type(e).__name__}: {e}"[:300]}
+        trainer.mfma_bf16 = False
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -260,6 +298,8 @@ def main():
                                             "master weights), gradient collectives on, MAX over ranks",
                                 "ms_per_step": bf16_multi[0] / args.steps * 1e3, "pairs_per_s": world * args.batch * args.steps / bf16_multi[0],
                                 "speedup_vs_fp32": dt / bf16_multi[0], "loss": bf16_multi[1]}
+    if graph_multi is not None:
+        out["hip_graph"] = graph_multi
     if prof is not None and os.environ.get("DF_BENCH_DUMP"):
         with open(os.environ["DF_BENCH_DUMP"], "w") as f:
             per = len(prof.records) // args.steps
@@ -343,9 +383,16 @@ def main():
             tg0 = time.perf_counter()
             for _ in range(args.steps):
                 trainer.step_captured()
-            host_ms = (time.perf_counter() - tg0) / args.steps * 1e3
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - tg0) / args.steps * 1e3
+            hosts = []
+            for _ in range(5):      # host cost of ONE replay with an empty queue: back-to-back replays block on the GPU's queue
+                torch.cuda.synchronize()   # depth (round 2's figure grew with --steps), which is GPU time, not host work
+                th = time.perf_counter()
+                trainer.step_captured()
+                hosts.append((time.perf_counter() - th) * 1e3)
+            torch.cuda.synchronize()
+            host_ms = statistics.median(hosts)
             trainer.mfma_bf16 = False
             out["hip_graph"] = {"workload": "the bf16 step above as one captured HIP graph (Trainer.capture / step_captured)",
                                 "ms_per_step": graph_ms, "host_ms_per_step": host_ms, "eager_ms_per_step": dtb / args.steps * 1e3}

@@ -77,66 +77,82 @@ class DeFlowFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dflow):
-        model, st = ctx.model, ctx.state
-        grads = GradDict()
-        bstar = st["bstar"]
-        if ops.SIDE is None and os.environ.get("DF_SIDE_STREAM") == "1":
-            ops.SIDE = ops.SideStream(bstar.device)
-        sink = getattr(model, "_grad_sink", None)
-        # phase callback: hand finished gradients to the arena / the overlapped all-reduce (not while weight gradients
-        # are still in flight on the side stream)
-        phase = (lambda params: sink.deliver(params, grads)) if (sink is not None and ops.SIDE is None) else (lambda params: None)
-        B, H, W, _ = bstar.shape
-        dev = bstar.device
-        dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
-        dv = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
-        # d(bstar) is only read at occupied pillars (pillar feature net backward): the UNet's two data gradients into it
-        # -- skip conv and first encoder conv -- are evaluated there only (df_pillar_input_grad) instead of densely for
-        # all H*W cells.  DF_DENSE_CANVAS_GRAD=1 keeps the dense kernels (A/B, tests).
-        sparse = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(model.backbone, FastFlow3DUNet)
-        if sparse:
-            # decoder: its gather backward writes d(before) = d(bstar) and d(after) = dv densely (a cheap stream)
-            model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
-                                    before=img(bstar), after=img(st["v"]))
-            st["sv"] = None
-            phase(model.head.parameters())
-            dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True,
-                                                           dv_cells=st["p0"])
-            st["tape"] = None
-            bb = model.backbone
-            w1 = ops.ohwi(bb.encoder_step_1[0].conv.weight)
-            w3 = ops.ohwi(bb.decoder_step3.u3.weight)
-            nb = max(1, 256 // B)
-            dw1 = torch.empty_like(w1)   # [64,3,3,32] memory
-            for cloud, pst in ((0, st["p0"]), (1, st["p1"])):
-                N = pst.pts.shape[1]
-                ws1 = torch.empty(nb * B, 64 * 9 * 32, dtype=torch.float32, device=dev)
-                call("df_sparse_in_wgrad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1),
-                     img(bstar, 32, 32 * cloud), ptr(ws1), nb, stream())
-                call("df_conv2d_wgrad_reduce", ptr(ws1), nb * B, 64, 9, 32, ptr(dw1), 9 * 32, cloud, stream())
-                call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
-                     img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, nb, stream())  # one 16-wave workgroup per CU
-            grads[bb.encoder_step_1[0].conv.weight] = dw1.permute(0, 3, 1, 2)
-        else:
-            # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
-            model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
-                                    before=img(bstar), after=img(st["v"]))
-            st["sv"] = None
-            phase(model.head.parameters())
-            # UNet: accumulates its own d(bstar) into the same buffer
-            model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads, phase)
-            st["tape"] = None
-        # pillar feature net of both clouds (shared weights -> accumulate)
-        emb = model.embedder
-        g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)
-        g = emb.pillarize_bwd(st["p1"], img(dbstar, 32, 32), g)
-        grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
-        if ops.SIDE is not None:
-            ops.SIDE.join()
-        if sink is not None:
-            sink.deliver(ctx.params, grads)   # the pillar feature net, and everything else if phases were off
+        sink = getattr(ctx.model, "_grad_sink", None)
+        grads = deflow_backward(ctx.model, ctx.state, dflow, ctx.params, sink)
         ctx.state = None
         return (None, None, None) + _grads_for(ctx.params, grads, sink)
+
+
+def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Tensor], sink=None) -> "GradDict":
+    """The hand-sequenced backward of the whole hot path (decoder -> UNet -> pillar feature net) on the state `_run(save=True)`
+    left: every launch is a HIP kernel through the C ABI.  Called by DeFlowFn.backward (autograd users) and DIRECTLY by
+    optim.Trainer.step (no autograd engine, no worker thread: the launch sequence stays on the caller's thread, which is what
+    lets the data-parallel step be captured as HIP-graph segments split at the gradient buckets).
+    Gradients leave through `sink` phase by phase (optim.GradSink); what the sink did not take is in the returned dict."""
+    grads = GradDict()
+    bstar = st["bstar"]
+    if ops.SIDE is None and os.environ.get("DF_SIDE_STREAM") == "1":
+        ops.SIDE = ops.SideStream(bstar.device)
+    # phase callback: hand finished gradients to the arena / the overlapped all-reduce.  With weight gradients in flight on
+    # the side stream a phase first joins it -- only worth it when a collective is waiting for the bucket (data-parallel
+    # ranks); on one rank everything is delivered once at the end
+    if sink is None or (ops.SIDE is not None and not sink.collective):
+        phase = lambda ps: None
+    elif ops.SIDE is not None:
+        def phase(ps):
+            ops.SIDE.join()
+            sink.deliver(ps, grads)
+    else:
+        phase = lambda ps: sink.deliver(ps, grads)
+    B, H, W, _ = bstar.shape
+    dev = bstar.device
+    dbstar = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+    dv = torch.empty(B, H, W, 64, dtype=torch.float32, device=dev)
+    # d(bstar) is only read at occupied pillars (pillar feature net backward): the UNet's two data gradients into it
+    # -- skip conv and first encoder conv -- are evaluated there only (df_pillar_input_grad) instead of densely for
+    # all H*W cells.  DF_DENSE_CANVAS_GRAD=1 keeps the dense kernels (A/B, tests).
+    sparse = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(model.backbone, FastFlow3DUNet)
+    if sparse:
+        # decoder: its gather backward writes d(before) = d(bstar) and d(after) = dv densely (a cheap stream)
+        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                before=img(bstar), after=img(st["v"]))
+        st["sv"] = None
+        phase(list(model.head.parameters()))
+        dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True,
+                                                       dv_cells=st["p0"])
+        st["tape"] = None
+        bb = model.backbone
+        w1 = ops.ohwi(bb.encoder_step_1[0].conv.weight)
+        w3 = ops.ohwi(bb.decoder_step3.u3.weight)
+        nb = max(1, 256 // B)
+        dw1 = torch.empty_like(w1)   # [64,3,3,32] memory
+        for cloud, pst in ((0, st["p0"]), (1, st["p1"])):
+            ws1 = torch.empty(nb * B, 64 * 9 * 32, dtype=torch.float32, device=dev)
+            call("df_sparse_in_wgrad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1),
+                 img(bstar, 32, 32 * cloud), ptr(ws1), nb, stream())
+            call("df_conv2d_wgrad_reduce", ptr(ws1), nb * B, 64, 9, 32, ptr(dw1), 9 * 32, cloud, stream())
+            call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
+                 img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, nb, stream())  # one 16-wave workgroup per CU
+        grads[bb.encoder_step_1[0].conv.weight] = dw1.permute(0, 3, 1, 2)
+    else:
+        # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
+        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                before=img(bstar), after=img(st["v"]))
+        st["sv"] = None
+        phase(list(model.head.parameters()))
+        # UNet: accumulates its own d(bstar) into the same buffer
+        model.backbone.run_backward(bstar, st["tape"], dv, dbstar, grads, phase)
+        st["tape"] = None
+    # pillar feature net of both clouds (shared weights -> accumulate)
+    emb = model.embedder
+    g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)
+    g = emb.pillarize_bwd(st["p1"], img(dbstar, 32, 32), g)
+    grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
+    if ops.SIDE is not None:
+        ops.SIDE.join()
+    if sink is not None:
+        sink.deliver(params, grads)   # the pillar feature net, and everything else if phases were off
+    return grads
 
 
 class DeflowLossFn(torch.autograd.Function):

@@ -107,9 +107,11 @@ class DeFlow(nn.Module):
         self.timer[3].stop()
         return flow, {"bstar": bstar, "v": v, "p0": p0, "p1": p1, "ps": ps, "tape": tape, "sv": sv}
 
-    def forward_padded(self, batch: Dict[str, torch.Tensor]) -> dict:
+    def forward_padded(self, batch: Dict[str, torch.Tensor], engine_tape: bool = False) -> dict:
         """Sync-free forward: returns (and stores in ``last_state``) padded device tensors -- flow [B,N,3],
-        pose_flow [B,N,3], counts0/counts1 [B] i32, idx_c0 [B,N] i64 ... -- without reading anything back to the host."""
+        pose_flow [B,N,3], counts0/counts1 [B] i32, idx_c0 [B,N] i64 ... -- without reading anything back to the host.
+        engine_tape: keep the engine's own tape in ``last_state["engine"]`` instead of building an autograd node (the caller --
+        optim.Trainer -- runs autograd.deflow_backward on it directly; call under torch.no_grad())."""
         self.timer[0].start("Data Preprocess")
         pc0 = batch["pc0"].contiguous().float()
         pc1s = batch["pc1"].contiguous().float()
@@ -133,7 +135,9 @@ class DeFlow(nn.Module):
         params = [p for p in self.parameters()]
         # differentiable whenever autograd is recording, in training AND in eval mode (frozen BatchNorm), as the reference
         # nn.Module is; inference callers wrap the call in torch.no_grad() (eval.py, bench.py do) and get the tape-less path
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if engine_tape:
+            flow, state = self._run(pc0s, pc1s, train=train, save=True)
+        elif torch.is_grad_enabled() and any(p.requires_grad for p in params):
             flow = DeFlowFn.apply(self, pc0s, pc1s, *params)
             state = self._state_tmp
             self._state_tmp = None
@@ -143,6 +147,8 @@ class DeFlow(nn.Module):
         p0, p1 = state["p0"], state["p1"]
         self.last_state = {"flow": flow, "pose_flow": pose_flow, "counts0": p0.counts, "counts1": p1.counts,
                            "idx_c0": p0.idx_c, "pc0s": pc0s, "p0": p0, "p1": p1}
+        if engine_tape:
+            self.last_state["engine"] = state
         return self.last_state
 
     def forward(self, batch: Dict[str, torch.Tensor]):

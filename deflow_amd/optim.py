@@ -92,6 +92,7 @@ class GradSink:
         self.slot_of = {p.data_ptr(): flat.slots[n] for n, p in flat.named}
         self.delivered = set()
         self.works: list = []
+        self.cap: Optional["SegmentedCapture"] = None   # set while Trainer.capture records the step
 
     def begin(self):
         self.delivered.clear()
@@ -115,6 +116,8 @@ class GradSink:
         if not dsts:
             return
         torch._foreach_copy_(dsts, srcs)
+        if self.cap is not None:
+            self.cap.touch()
         if self.collective:
             slots.sort()
             lo, hi = slots[0][0], slots[0][0] + slots[0][1]
@@ -126,16 +129,75 @@ class GradSink:
                     runs.append((lo, hi))
                     lo, hi = off, off + n
             runs.append((lo, hi))
-            for lo, hi in runs:
-                self.works.append(self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
+            self.all_reduce_runs(runs)
+
+    def all_reduce_runs(self, runs):
+        """asynchronous sum all-reduce of arena ranges [lo, hi) -- or, while a step is being captured, a split of the HIP graph
+        at this point with the collectives recorded between the two segments (SegmentedCapture)"""
+        if self.cap is not None:
+            self.cap.emit(("allreduce", list(runs)))
+            return
+        for lo, hi in runs:
+            self.works.append(self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
 
     def was_delivered(self, p) -> bool:
         return p.data_ptr() in self.delivered
 
     def finish(self):
+        if self.cap is not None:
+            self.cap.emit(("wait",))
+            return
         for w in self.works:
             w.wait()
         self.works.clear()
+
+
+class SegmentedCapture:
+    """The training step recorded as a PROGRAM: HIP-graph segments with the data-parallel collectives between them,
+
+        [graph 0: forward, loss, decoder backward] [all-reduce head bucket] [graph 1: UNet decoder backward] [all-reduce ...]
+        ... [graph 5: pillar feature net backward] [all-reduce] [wait] [graph 6: Adam]
+
+    so that replaying a data-parallel step costs the host a handful of graph launches and `all_reduce` calls instead of ~410
+    Python-issued kernel launches, while RCCL keeps overlapping every bucket with the rest of the backward exactly as in the
+    eager step (the collective is enqueued right after the segment that produced its bucket; the next segment does not wait
+    for it).  The collectives themselves stay OUTSIDE the graphs: they run on the process group's own stream / threads
+    (RCCL, or gloo in the tests) and need no capture support from the backend.  All segments share one allocator pool and are
+    replayed in capture order, so tensors that live across a split (the tape, the gradient buffers) stay valid.
+    `fresh` = nothing has been launched into the open segment yet: an op emitted then needs no split (no empty graphs)."""
+
+    def __init__(self):
+        self.ops: list = []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.g: Optional[torch.cuda.CUDAGraph] = None
+        self.fresh = True
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog / worker threads keep calling into HIP while this thread captures
+        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.fresh = True
+
+    def touch(self):
+        self.fresh = False
+
+    def end(self):
+        self.g.capture_end()
+        if not self.fresh:
+            self.ops.append(("graph", self.g))
+        self.g = None
+
+    def emit(self, op):
+        if self.fresh:                 # nothing launched since the last split: the op simply follows the previous one
+            self.ops.append(op)
+            return
+        self.end()
+        self.ops.append(op)
+        self.begin()
+
+    @property
+    def n_graphs(self) -> int:
+        return sum(1 for o in self.ops if o[0] == "graph")
 
 
 class FlatAdam:
@@ -230,14 +292,13 @@ class Trainer:
         """Sum the gradient arena over the data-parallel ranks (ONE collective over 27.6 MB); returns the scale that
         turns the sum into DDP's mean (folded into the Adam kernel instead of a separate divide pass)."""
         if self.collective:
-            if self.sink.delivered:   # bucketed, already in flight: wait; then whatever did not go through the sink
-                self.sink.finish()
-                rest = [p for p in self.flat.params if not self.sink.was_delivered(p)]
+            if self.sink.delivered:   # bucketed, already in flight; then whatever did not go through the sink
+                rest = sorted(self.sink.slot_of[p.data_ptr()] for p in self.flat.params if not self.sink.was_delivered(p))
                 if rest:
-                    for p in rest:
-                        self.dist.all_reduce(p.grad if p.grad.is_contiguous() else p.grad.permute(0, 2, 3, 1), group=self.pg)
+                    self.sink.all_reduce_runs([(off, off + n) for off, n in rest])
             else:
-                self.dist.all_reduce(self.flat.grad, group=self.pg)
+                self.sink.all_reduce_runs([(0, self.flat.numel)])
+            self.sink.finish()
         return 1.0 / self.world
 
     def sync_buffers(self):
@@ -266,32 +327,56 @@ class Trainer:
         """frame pairs are sharded by global sample index: rank r owns samples [r*b, (r+1)*b)"""
         return base_seed + rank * per_rank_batch
 
-    # ---- the whole step as ONE captured HIP graph ----------------------------------------------------------------
+    # ---- the whole step as captured HIP graph(s) -------------------------------------------------------------------
     def capture(self, batch) -> None:
-        """Capture `step(batch)` -- forward, loss, hand-sequenced backward, Adam: ~410 launches -- as one HIP graph on the
-        shapes of `batch` (whose tensors become the graph's static inputs; `step_captured(new_batch)` copies into them).  The
-        step is sync-free and every host-side quantity the kernels take is constant across steps except Adam's step number,
-        which moves to device memory (df_adam_step_dev).  Replaying costs the host 0.1-1 ms instead of the ~44 ms it takes
-        Python to enqueue the step; the GPU time is about the same (fp32: equal; bf16, where the step runs on two streams:
-        50.6 ms replayed vs 48.9 eager) -- the point is a host-free step, not a faster one.  One rank only: the RCCL buckets issued from inside the backward are not
-        captured."""
-        if self.collective:
-            raise RuntimeError("Trainer.capture: graph capture of the data-parallel step (RCCL inside the backward) is not supported")
+        """Capture `step(batch)` -- forward, loss, hand-sequenced backward, Adam: ~410 launches -- as HIP graph(s) on the shapes
+        of `batch` (whose tensors become the static inputs; `step_captured(new_batch)` copies into them).  The step is sync-free
+        and every host-side quantity the kernels take is constant across steps except Adam's step number, which moves to device
+        memory (df_adam_step_dev).  Replaying costs the host ~1 ms instead of the ~44 ms Python needs to enqueue the step; the
+        GPU time is about the same -- the point is a host-free step, not a faster one.
+        One rank: ONE graph.  Data-parallel ranks: the graph is SPLIT at every gradient bucket and the collectives are issued
+        between the segments (SegmentedCapture), still overlapped with the rest of the backward.
+        The two warm-up steps capture needs are NOT training steps: parameters, Adam state, BatchNorm buffers and the step
+        counters are restored afterwards, so the first `step_captured()` is exactly the step an eager trainer would take."""
         dev = self.flat.param.device
+        if ops.SYNC is not None:
+            raise RuntimeError("Trainer.capture: sync_bn issues blocking collectives inside the forward and cannot be captured")
         self.opt.step_dev = torch.full((1,), self.opt.step_count, dtype=torch.int32, device=dev)
         self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):        # warm-up on a side stream, as torch's capture rules ask; these ARE training steps
+        bufs = list(self.model.buffers())
+        snap = (self.flat.param.clone(), self.opt.exp_avg.clone(), self.opt.exp_avg_sq.clone(), self.opt.step_count,
+                [b.clone() for b in bufs])
+        cap_stream = torch.cuda.Stream(device=dev)
+        cap_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap_stream):   # warm-up on a side stream, as torch's capture rules ask
             for _ in range(2):
                 self.step(self._static)
-        torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_loss = self.step(self._static)
-        # the captured launch sequence was RECORDED, not executed; the two warm-up steps and the capture call advanced the host
-        # counter by 3, the device counter by 2
-        self.opt.step_count -= 1
+            with torch.no_grad():
+                self.flat.param.copy_(snap[0]); self.opt.exp_avg.copy_(snap[1]); self.opt.exp_avg_sq.copy_(snap[2])
+                for b, v in zip(bufs, snap[4]):
+                    b.copy_(v)
+                self.opt.step_count = snap[3]
+                self.opt.step_dev.fill_(snap[3])
+            torch.cuda.synchronize()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            cap = SegmentedCapture()
+            self.sink.cap = cap
+            try:
+                cap.begin()
+                cap.touch()
+                self._graph_loss = self.step(self._static)
+                cap.end()
+            finally:
+                self.sink.cap = None
+        torch.cuda.current_stream().wait_stream(cap_stream)
+        self._program = cap.ops
+        self._cap = cap      # keeps the pool handle alive
+        self._graph = cap    # (truthy marker older callers test for)
+        # the captured launch sequence was RECORDED, not executed: undo the host-side counter
+        self.opt.step_count = snap[3]
+        ops.PARAM_GEN[0] += 1
 
     def step_captured(self, batch=None) -> torch.Tensor:
         """Replay the captured step (optionally on a new batch of the captured shapes).  -> loss tensor of the replay"""
@@ -301,29 +386,89 @@ class Trainer:
                     if v.shape != self._static[k].shape:
                         raise ValueError(f"step_captured: {k} has shape {tuple(v.shape)}, the graph was captured on {tuple(self._static[k].shape)}")
                     self._static[k].copy_(v, non_blocking=True)
-        self._graph.replay()
+        works = []
+        for op in self._program:
+            kind = op[0]
+            if kind == "graph":
+                op[1].replay()
+            elif kind == "allreduce":
+                for lo, hi in op[1]:
+                    works.append(self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
+            else:   # "wait": the optimizer segment follows
+                for w in works:
+                    w.wait()
+                works.clear()
         self.opt.step_count += 1
         ops.PARAM_GEN[0] += 1
         return self._graph_loss
 
     def _side_on(self) -> Optional[bool]:
-        """weight-gradient GEMMs on a second stream?  DF_SIDE_STREAM=0/1 decides if set; otherwise on in bf16 mode on one GPU
-        (with data-parallel ranks the phase-by-phase gradient delivery -- the overlapped all-reduce -- needs them in order)."""
+        """weight-gradient GEMMs on a second stream?  DF_SIDE_STREAM=0/1 decides if set; otherwise on in bf16 mode (with
+        data-parallel ranks each gradient phase joins the side stream before its bucket goes out: autograd.deflow_backward)."""
         env = os.environ.get("DF_SIDE_STREAM")
         if env is not None:
             return None if env == "1" else False   # "1": autograd creates the stream itself (every caller, not only Trainer)
-        return bool(self.mfma_bf16 and not self.collective)
+        return bool(self.mfma_bf16)
+
+    def _forward_backward(self, batch) -> torch.Tensor:
+        """forward -> loss -> backward WITHOUT the autograd engine when the model is the hand-sequenced DeFlow engine: the
+        forward keeps its own tape, the loss kernels produce d(flow) directly and autograd.deflow_backward runs on this thread
+        (the autograd path -- DeFlowFn / loss.backward(), which every non-Trainer caller uses -- computes the same launches
+        from a worker thread; tests/test_gpu_model.py::test_direct_step_equals_autograd_step)."""
+        model = self.model
+        if not hasattr(model, "forward_padded") or os.environ.get("DF_TRAINER_AUTOGRAD") == "1":
+            model.forward_padded(batch)
+            loss = self.loss_on_last_forward(batch)
+            loss.backward()
+            return loss.detach()
+        from .autograd import deflow_backward
+        with torch.no_grad():
+            st = model.forward_padded(batch, engine_tape=True)
+            flow = st["flow"]
+            B, N, _ = flow.shape
+            dev = flow.device
+            gt = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+            gtf = batch["flow"].contiguous().float()
+            call("df_gather_gt", ptr(gtf), ptr(st["pose_flow"]), ptr(st["idx_c0"]), ptr(st["counts0"]), B, N, ptr(gt), 64, stream())
+            if self.loss_fn == "deflowLoss":
+                nblk = max(1, min(32, (N + 255) // 256))
+                partial = torch.empty(B, nblk, 6, dtype=torch.float32, device=dev)
+                call("df_deflow_loss_fwd", ptr(flow), ptr(gt), ptr(st["counts0"]), B, N, ptr(partial), nblk, stream())
+                bins = torch.empty(B, 6, dtype=torch.float32, device=dev)
+                loss = torch.empty(1, dtype=torch.float32, device=dev)
+                call("df_deflow_loss_finalize", ptr(partial), B, nblk, ptr(bins), ptr(loss), stream())
+                dflow = torch.empty_like(flow)
+                if not hasattr(self, "_one") or self._one.device != dev:
+                    self._one = torch.ones(1, dtype=torch.float32, device=dev)
+                call("df_deflow_loss_bwd", ptr(flow), ptr(gt), ptr(st["counts0"]), B, N, ptr(bins), ptr(self._one), 1.0, ptr(dflow),
+                     nblk, stream())
+                loss = loss[0]
+            else:   # the ablation losses are a few torch ops on [B,N,3] tensors: autograd for them alone
+                from . import losses
+                leaf = flow.detach().requires_grad_(True)
+                with torch.enable_grad():
+                    if self.loss_fn == "zeroflowLoss":
+                        loss = losses.zeroflow_loss(leaf, gt, st["counts0"])
+                    else:
+                        cls = batch.get("flow_category_indices")
+                        if cls is not None:
+                            cls = torch.gather(cls.long(), 1, st["idx_c0"].clamp(0, cls.shape[1] - 1))
+                        loss = losses.ff3d_loss(leaf, gt, st["counts0"], cls)
+                    dflow, = torch.autograd.grad(loss, leaf)
+                loss = loss.detach()
+            deflow_backward(model, st.pop("engine"), dflow.contiguous(), self.flat.params, self.sink)
+        return loss
 
     def step(self, batch) -> torch.Tensor:
         self.flat.zero_grad()
         self.sink.begin()
         with ops.mfma_bf16(self.mfma_bf16), ops.side_stream(self._side_on(), self.flat.grad.device):
-            self.model.forward_padded(batch)
-            loss = self.loss_on_last_forward(batch)
-            loss.backward()
+            loss = self._forward_backward(batch)
         scale = self.reduce_gradients()
         if self.gradient_clip_val > 0:       # two launches on the 27.6 MB arena, no host sync
             total_norm = torch.linalg.vector_norm(self.flat.grad) * scale
             self.flat.grad.mul_(torch.clamp(self.gradient_clip_val / (total_norm + 1e-6), max=1.0))
+        if self.sink.cap is not None:
+            self.sink.cap.touch()
         self.opt.step(grad_scale=scale)
         return loss.detach()

@@ -183,15 +183,21 @@ def main(argv=None):
         train_loader, train_sampler = scene_loader(str(cfg["train_data"]), shuffle=True)
     if cfg["val_data"] != "synthetic":
         val_loader, _ = scene_loader(str(cfg["val_data"]), shuffle=False)
-    use_graph = str(cfg["graph"]).lower() in ("1", "true") and world == 1 and float(cfg["gradient_clip_val"]) == 0.0
+    use_graph = str(cfg["graph"]).lower() in ("1", "true")
+    if use_graph and str(cfg["sync_bn"]).lower() in ("1", "true") and world > 1:
+        use_graph = False     # SyncBatchNorm's collectives sit inside the forward and block the host
+        if rank == 0:
+            print("[deflow_amd.train] note: graph=true is ignored with sync_bn=true (running eager steps)", file=sys.stderr)
     gstep, log_step, log_t = gstep0, gstep0, time.perf_counter()
     for epoch in range(start_epoch, int(cfg["epochs"])):
         if train_loader is not None:
             train_sampler.set_epoch(epoch)
         for batch in (train_loader if train_loader is not None else synthetic_epoch(epoch)):
             if use_graph:
-                # graph=true: the step is captured once as a HIP graph (on the first batch, which thereby also serves as the two
-                # warm-up steps capture needs) and replayed for every batch of the same shapes; other shapes run eagerly
+                # graph=true: the step is captured once as HIP graph(s) on the first batch (capture restores parameters, Adam
+                # state and BatchNorm buffers after its warm-up launches: the replay below IS the first training step) and
+                # replayed for every batch of the same shapes; other shapes run eagerly.  Data-parallel ranks replay graph
+                # segments split at the gradient buckets (optim.SegmentedCapture)
                 if getattr(trainer, "_graph", None) is None:
                     trainer.capture(batch)
                     loss = trainer.step_captured()      # (capture records the launches, it does not run them)

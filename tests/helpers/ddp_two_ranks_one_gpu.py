@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     out, sync_bn = sys.argv[1], len(sys.argv) > 2 and sys.argv[2] == "sync_bn"
+    graph = len(sys.argv) > 2 and sys.argv[2].startswith("graph")          # "graph" | "graph_bf16"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,6 +28,8 @@ def main():
     tr = Trainer(model, lr=2e-4, sync_bn=sync_bn)
     assert tr.collective and tr.world == 2
     batch = to_dev(make_batch(2, 1500, 7000 + 50 * rank), dev)                         # rank-specific shard
+    if graph:
+        return graph_mode(out, rank, dev, model, batch, "bf16" if sys.argv[2].endswith("bf16") else "fp32")
     losses, works = [], 0
     for _ in range(2):
         tr.flat.zero_grad(); tr.sink.begin()
@@ -41,6 +44,44 @@ def main():
     dist.all_gather_object(gathered, {"losses": losses, "works": works, "param_sum": float(tr.flat.param.double().sum())})
     if rank == 0:
         torch.save({"state": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "ranks": gathered}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def graph_mode(out, rank, dev, model, batch, dtype):
+    """the data-parallel step captured as HIP-graph SEGMENTS split at the gradient buckets (optim.SegmentedCapture), replayed
+    on changing batches, against the eager data-parallel step from the same start: same losses, bit-identical parameters,
+    Adam moments and BatchNorm buffers on both ranks (gloo's two-rank sum is order-independent); plus the host time of a replay"""
+    import copy
+    import time
+    from test_gpu_model import make_batch, to_dev
+    from deflow_amd.optim import Trainer
+    m2 = copy.deepcopy(model)
+    t1, t2 = Trainer(model, lr=1e-3, dtype=dtype), Trainer(m2, lr=1e-3, dtype=dtype)
+    seq = [batch, to_dev(make_batch(2, 1500, 9000 + 50 * rank), dev), batch]
+    want = [float(t1.step(b)) for b in seq]
+    t2.capture(seq[0])
+    got = [float(t2.step_captured(b)) for b in seq]
+    torch.cuda.synchronize()
+    kinds = [o[0] for o in t2._program]
+    n_graph, n_ar = kinds.count("graph"), sum(len(o[1]) for o in t2._program if o[0] == "allreduce")
+    same = bool(torch.equal(t1.flat.param, t2.flat.param) and torch.equal(t1.opt.exp_avg_sq, t2.opt.exp_avg_sq)
+                and all(torch.equal(a, b) for a, b in zip(model.buffers(), m2.buffers())))
+    # host cost of one replayed data-parallel step (gloo's all_reduce blocks the host on the device, so time the graph
+    # launches alone: the collectives are a handful of calls either way)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for o in t2._program:
+        if o[0] == "graph":
+            o[1].replay()
+    host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    res = {"want": want, "got": got, "same": same, "n_graph": n_graph, "n_allreduce": n_ar, "kinds": kinds, "host_ms": host_ms,
+           "steps": (t1.opt.step_count, t2.opt.step_count, int(t2.opt.step_dev)), "param_sum": float(t2.flat.param.double().sum())}
+    gathered = [None, None]
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save({"ranks": gathered}, out)
     dist.barrier()
     dist.destroy_process_group()
 

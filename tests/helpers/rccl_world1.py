@@ -36,6 +36,21 @@ def run(force: bool):
         issued += len(tr.sink.works)
         tr.opt.step(grad_scale=tr.reduce_gradients())
     torch.cuda.synchronize()
+    if force:
+        # the same two steps as a captured PROGRAM over RCCL: graph segments split at the buckets, real (1-rank) all-reduces
+        # on the process group's stream between them, the stream-level wait before the Adam segment (optim.SegmentedCapture)
+        torch.manual_seed(0)
+        m2 = deflow_amd.DeFlow(grid_feature_size=[128, 128], point_cloud_range=[-12.8, -12.8, -3, 12.8, 12.8, 3],
+                               num_iters=2).to(dev).train()
+        t2 = Trainer(m2, lr=2e-4)
+        t2.capture(batch)
+        for _ in range(2):
+            lg = t2.step_captured()
+        torch.cuda.synchronize()
+        kinds = [o[0] for o in t2._program]
+        assert kinds.count("graph") >= 6 and kinds[-2:] == ["wait", "graph"], kinds
+        assert torch.equal(t2.flat.param, tr.flat.param) and float(lg) == float(loss.detach()), "captured RCCL program != eager"
+        print(f"RCCL_WORLD1_GRAPH_OK segments={kinds.count('graph')}")
     return tr.flat.param.clone(), tr.flat.grad.clone(), float(loss.detach()), issued
 
 
