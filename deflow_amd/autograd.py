@@ -83,6 +83,9 @@ class DeFlowFn(torch.autograd.Function):
         return (None, None, None) + _grads_for(ctx.params, grads, sink)
 
 
+TAP = None   # debugging / tests: callable(stage_name, **tensors) called at the hand-over points of the backward
+
+
 def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Tensor], sink=None) -> "GradDict":
     """The hand-sequenced backward of the whole hot path (decoder -> UNet -> pillar feature net) on the state `_run(save=True)`
     left: every launch is a HIP kernel through the C ABI.  Called by DeFlowFn.backward (autograd users) and DIRECTLY by
@@ -114,8 +117,11 @@ def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Ten
     sparse = os.environ.get("DF_DENSE_CANVAS_GRAD") != "1" and isinstance(model.backbone, FastFlow3DUNet)
     if sparse:
         # decoder: its gather backward writes d(before) = d(bstar) and d(after) = dv densely (a cheap stream)
-        model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
-                                before=img(bstar), after=img(st["v"]))
+        dh0 = model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
+                                      before=img(bstar), after=img(st["v"]))
+        if TAP is not None:
+            TAP("head", dh0=dh0, dbstar=dbstar, dv=dv)
+        del dh0
         st["sv"] = None
         phase(list(model.head.parameters()))
         dy1, (dcat, lat) = model.backbone.run_backward(bstar, st["tape"], dv, None, grads, phase, sparse_input_grad=True,
@@ -134,6 +140,8 @@ def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Ten
             call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
                  img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, nb, stream())  # one 16-wave workgroup per CU
         grads[bb.encoder_step_1[0].conv.weight] = dw1.permute(0, 3, 1, 2)
+        if TAP is not None:
+            TAP("canvas_grad", dy1=dy1, dskip=dcat[..., lat:], dbstar=dbstar)
     else:
         # decoder: writes d(before)=d(bstar) and d(after)=dv completely (zeros where no point looked)
         model.head.run_backward(dflow, st["ps"], st["sv"], img(dbstar), img(dv), False, False, grads,
@@ -148,6 +156,9 @@ def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Ten
     g = emb.pillarize_bwd(st["p0"], img(dbstar, 32, 0), None)
     g = emb.pillarize_bwd(st["p1"], img(dbstar, 32, 32), g)
     grads[emb._lin.weight], grads[emb._bn.weight], grads[emb._bn.bias] = g
+    if TAP is not None:
+        TAP("pfn", dW=g[0], dgamma=g[1], dbeta=g[2], dbstar=dbstar, **{f"{k}{i}": getattr(st[f"p{i}"], k) for i in (0, 1)
+                                                                      for k in ("bn_ss", "pts_sorted", "key_sorted", "cell_rng", "counts")})
     if ops.SIDE is not None:
         ops.SIDE.join()
     if sink is not None:

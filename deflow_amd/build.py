@@ -16,6 +16,14 @@ LIB = os.path.join(HERE, "libdeflow_amd.so")
 SOURCES = ["conv.hip", "conv_bf16.hip", "elementwise.hip", "pillarize.hip", "pillar_bands.hip", "decoder.hip", "decoder3.hip", "decoder_bf16.hip", "decoder3_bwd.hip", "decoder_wgrad.hip", "decoder_bwd.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
+# Per-file extras.  pillarize.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 instructions (v_pk_fma_f32 ...):
+# round 3 found (tools/pfn_bwd_stress.py next to tools/grad_repro_probe.py bf16 as a second PROCESS on the same GPU) that the
+# pillar feature net's backward kernels return wrong sums -- up to 7e-2 relative, ~4 % of the launches -- while another process
+# runs bf16-MFMA kernels on the GPU, and stop doing so once their v_pk_*_f32 instructions are gone.  PyTorch's own kernels
+# are not affected, an fp32-MFMA neighbour does not trigger it, and inside ONE process (any size, two streams) every step is
+# bit-reproducible -- so the deployment (one process per GPU) never sees it; the two-ranks-on-one-GPU tests did.  These
+# kernels are launch-latency-bound: the flag costs nothing measurable.
+EXTRA_FLAGS = {"pillarize.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps_mtime() -> float:
@@ -29,7 +37,7 @@ def _compile(src: str, verbose: bool) -> str:
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

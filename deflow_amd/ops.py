@@ -172,7 +172,8 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    w16 = MFMA_BF16 and ks == 3 and stride == 1 and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1
+    w16 = (MFMA_BF16 and ks == 3 and stride == 1 and os.environ.get("DF_CONV_W16", "1") != "0"
+           and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1)
     if w16:
         # bf16 tiles in LDS (conv_halo_w16_kernel): the weights are cast once per call (they change every optimizer step and
         # each conv uses them once per direction), the activations stay fp32 in memory
