@@ -9,14 +9,15 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeflow_amd.so")
+LIB_PATH = os.environ.get("DF_LIB") or os.path.join(_HERE, "libdeflow_amd.so")   # DF_LIB: an alternate build for A/B runs (tools/)
 
 _ERR = {-1: "DF_E_SHAPE", -2: "DF_E_ALIGN", -3: "DF_E_ARG", -4: "DF_E_WORKSPACE"}
 
 
 class DfImg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
-                ("ld", C.c_int32), ("grp_size", C.c_int32), ("img_stride", C.c_int64), ("grp_off", C.c_int64)]
+                ("ld", C.c_int32), ("grp_size", C.c_int32), ("img_stride", C.c_int64), ("grp_off", C.c_int64),
+                ("elt", C.c_int32), ("reserved", C.c_int32)]   # elt: 0 = float32, 1 = bfloat16 (bf16-storage training)
 
 
 class DfGeom(C.Structure):
@@ -75,6 +76,10 @@ _SIGS = {
     "df_upsample2x_bf16": [DfImg, DfImg, I, P],
     "df_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, I, P],
     "df_bn_gelu_apply": [P, P, I, DfImg, P],
+    "df_bn_gelu_apply_t": [P, I, P, I, DfImg, P],
+    "df_bn_gelu_bwd_reduce_t": [DfImg, P, I, P, I, P, I, P],
+    "df_bn_gelu_bwd_apply_t": [DfImg, P, I, P, P, I, P, I, P, I, P],
+    "df_conv2d_wgrad_bf16": [DfImg, DfImg, I, I, I, P, I, P, P],
     "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],
     "df_bn_bwd_finalize": [P, I, I, I, L, P, P, P, P],
     "df_bn_gelu_bwd_apply": [DfImg, P, P, P, I, P, P, I, P],
@@ -150,12 +155,21 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _elt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError(f"df_img: unsupported dtype {t.dtype}")
+
+
 def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
-    """Descriptor of an NHWC-shaped tensor [N,H,W,C'] (stride(3) == 1); optional channel slice [c_off, c_off+c)."""
+    """Descriptor of an NHWC-shaped tensor [N,H,W,C'] (stride(3) == 1); optional channel slice [c_off, c_off+c).
+    float32 or bfloat16 (the element type travels in the descriptor; only the bf16-storage entry points accept bfloat16)."""
     assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2), (t.shape, t.stride())
     n, h, w, cc = t.shape
     c = cc - c_off if c is None else c
-    return DfImg(t.data_ptr() + 4 * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0)
+    return DfImg(t.data_ptr() + t.element_size() * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, _elt(t), 0)
 
 
 def img_pair(t: torch.Tensor, c: int) -> DfImg:
@@ -163,4 +177,4 @@ def img_pair(t: torch.Tensor, c: int) -> DfImg:
     This is how the shared encoder reads/writes torch.cat((pc0_x, pc1_x), dim=1) without a copy."""
     assert t.dim() == 4 and t.shape[3] == 2 * c and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
     n, h, w, _ = t.shape
-    return DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c)
+    return DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c, _elt(t), 0)

@@ -47,6 +47,32 @@ def _compile(src: str, verbose: bool) -> str:
     return obj
 
 
+def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
+    """an alternate library deflow_amd/_build/<name>/lib<name>.so with extra hipcc flags on every file (A/B experiments:
+    DF_LIB=<path> python ...)"""
+    out = os.path.join(BUILD, name)
+    os.makedirs(out, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(out, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not (os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _deps_mtime())):
+            r = subprocess.run([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_flags, "-c", srcp, "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed on {src}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, SOURCES))
+    lib = os.path.join(out, f"lib{name}.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link failed")
+    return lib
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(BUILD, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -16,6 +16,7 @@
 // workgroups per CU.  k is permuted inside each group of 8: MFMA step s of group g uses k = 8g + s on lanes 0-31
 // and k = 8g + 4 + s on lanes 32-63 for BOTH operands, so one b128 read feeds four MFMA steps.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -111,53 +112,72 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // instead of a branch per element.  With the branch the compiler had to re-wait for the bias / scale loads inside every
     // element block -- s_waitcnt vmcnt(0), which also waits for the PREVIOUS element's store: 16 TM serialised write
     // round trips per wave.
+    // Y16 (p.y.elt == 1, bf16-storage training): the value is rounded to bf16 (RNE) and stored as 2 bytes; the BatchNorm
+    // statistics are taken from the ROUNDED values, i.e. of the tensor the normalisation pass will actually read.
     constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
+    auto body = [&](auto y16_tag) {
+      constexpr bool Y16 = decltype(y16_tag)::value;
+      constexpr int ESZ = Y16 ? 2 : 4;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co = n0 + (wn * TN + j) * 32 + li;
-      const float bia = p.bias ? p.bias[co] : 0.f;
-      float sc = 1.f, sh = 0.f;
-      if (p.epi == DF_EPI_BN_GELU) {
-        sc = p.scale[co];
-        sh = p.shift[co];
-      }
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        unsigned ob[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-          ob[e] = off >= 0 ? (unsigned)((off + co) * 4) : ROW_BAD;
+      for (int j = 0; j < TN; ++j) {
+        const int co = n0 + (wn * TN + j) * 32 + li;
+        const float bia = p.bias ? p.bias[co] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (p.epi == DF_EPI_BN_GELU) {
+          sc = p.scale[co];
+          sh = p.shift[co];
         }
-        float old[16];
-        if (p.accumulate) {
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
+        for (int i = 0; i < TM; ++i) {
+          unsigned ob[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+            ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
+          }
+          float old[16];
+          if (p.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              if constexpr (Y16)
+                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], 0, 0) << 16);
+              else
+                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bia;
+            if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+            if (p.accumulate) v += old[e];
+            if constexpr (Y16) {
+              const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
+              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], 0, 0);
+              v = __builtin_bit_cast(float, (unsigned)h << 16);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
+            }
+            if (ob[e] != ROW_BAD) {
+              s1 += v;
+              s2 += v * v;
+            }
+          }
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] + bia;
-          if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-          if (p.accumulate) v += old[e];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
-          if (ob[e] != ROW_BAD) {
-            s1 += v;
-            s2 += v * v;
+        if (p.epi == DF_EPI_STATS) {
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (kh == 0) {
+            const int cl = (wn * TN + j) * 32 + li;
+            red[(wm * BN + cl) * 2 + 0] = s1;
+            red[(wm * BN + cl) * 2 + 1] = s2;
           }
         }
       }
-      if (p.epi == DF_EPI_STATS) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (kh == 0) {
-          const int cl = (wn * TN + j) * 32 + li;
-          red[(wm * BN + cl) * 2 + 0] = s1;
-          red[(wm * BN + cl) * 2 + 1] = s2;
-        }
-      }
-    }
+    };
+    if (p.y.elt) body(std::true_type{});
+    else body(std::false_type{});
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -743,7 +763,8 @@ constexpr int LDH = 16;   // floats per bf16 tile row
 // SEG = 1: the tile's 128 output pixels are one run of an image row (W % 128 == 0), halo = 130 pixels.  SEG = 2: W == 64, the
 // tile is two whole image rows, halo = 2 x 66 pixels (halo row 66 s + c + tx feeds output pixel (oy + s, c)); 32-row MFMA
 // blocks never straddle the two rows.
-template <int BN, int WM, int WN, int SEG = 1>
+// X16: the activations are bfloat16 in memory (bf16-storage training): an item is ONE 16-byte load and goes to LDS as it is.
+template <int BN, int WM, int WN, int SEG = 1, bool X16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, HR = 132;                 // halo rows: 130 (SEG = 1) / 132 (SEG = 2) used
@@ -752,6 +773,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
   constexpr int NW = WM * WN, NT = 64 * NW;         // waves, threads (8 waves: wave tile 64 x 32 at BN = 128; 4 waves: 64 x 64)
   constexpr int RB = (BN + 16 * NW - 1) / (16 * NW);   // weight DMA passes (a wave moves 16 rows of 64 B per instruction)
   constexpr int NIT = (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte LDS slot each) per thread
+  constexpr int XES = X16 ? 2 : 4;                     // bytes per activation element in memory
   static_assert(NW == 8 || NW == 4, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                      // [2][HR][LDH]
@@ -790,22 +812,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
     aseg[e] = sg;
     const int sl = aslot ^ ((j >> 2) & 3);
     aoff[e] = (aon[e] && ix >= 0 && ix < wx)
-                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * XES + p.dshift) : DMA_BAD;
   }
   const int brow = wave * 16 + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);   // (row >> 2) & 3 = (lane >> 4) & 3
   unsigned boff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + brow + 16 * NW * i) * 9 * p.K + bslot * 8) * 2);
 
+  // Scalar-light group addressing (profiles/r02_pmc_conv_bf16.txt: 994 k SALU vs 745 k VALU instructions per launch; the
+  // scalar unit is shared by the CU's 16 waves and 12 MFMAs per wave and group are only ~400 cycles): the per-group scalar
+  // offsets are CARRIED and advanced by adds -- no multiplies, no forward / data-gradient tap selects inside the loop.
+  //   sa  = byte offset of group (ty, kc)'s halo row / k chunk in x:  += BK * 4 per chunk, += row pitch - K * 4 per tap row
+  //   swb = byte offset of tap (ty, tx = 0), chunk kc in the bf16 weights; tap tx sits tx * dtap further (dtap < 0 for the
+  //         data gradient, whose taps run backwards: 8 - 3 ty - tx)
+  const unsigned a_row_step = (unsigned)(wx * ldx * XES - KC * BK * XES);
+  const int dtap = fwd ? p.K * 2 : -p.K * 2;
+  const int w_row_step = 3 * dtap - KC * BK * 2;
+  unsigned sa_next = 0;                               // offsets of the NEXT group to fetch (group 0 first)
+  int swb_next = fwd ? 0 : 8 * p.K * 2;
+  int ty_next = 0;
   f32x4 ra[NIT][2];
-  auto fetch_a = [&](int ty, int kc) {              // group (ty, kc)'s halo -> registers
-    const unsigned soff = (unsigned)((ty * wx * ldx + kc * BK) * 4);
+  auto fetch_a = [&]() {                            // the next group's halo -> registers
+    const unsigned soff = sa_next;
+    const int ty = ty_next;
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
       if (e + 1 < NIT || aon[e]) {
         const unsigned v = (unsigned)(oy + aseg[e] - 1 + ty) < (unsigned)hx ? aoff[e] : DMA_BAD;
         ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, soff, 0));
-        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, soff, 0));
+        if constexpr (!X16) ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, soff, 0));
       }
     }
   };
@@ -813,13 +848,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
     float* a = As + abuf * HR * LDH;
 #pragma unroll
     for (int e = 0; e < NIT; ++e)
-      if (e + 1 < NIT || aon[e]) *reinterpret_cast<bf16x8_t*>(a + (tid + e * NT) * 4) = pack_bf16(ra[e][0], ra[e][1]);
+      if (e + 1 < NIT || aon[e]) {
+        if constexpr (X16) *reinterpret_cast<f32x4*>(a + (tid + e * NT) * 4) = ra[e][0];
+        else *reinterpret_cast<bf16x8_t*>(a + (tid + e * NT) * 4) = pack_bf16(ra[e][0], ra[e][1]);
+      }
   };
-  auto load_b = [&](int ty, int kc, int bbuf) {     // the three horizontal taps' weight tiles of group (ty, kc)
+  auto load_b = [&](int bbuf) {                     // the three horizontal taps' weight tiles of the next group
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
-      const int wtap = fwd ? ty * 3 + tx : (2 - ty) * 3 + (2 - tx);
-      const unsigned soff = (unsigned)((wtap * p.K + kc * BK) * 2);
+      const unsigned soff = (unsigned)(swb_next + tx * dtap);
       float* b = Bs + (bbuf * 3 + tx) * BN * LDH + wave * 16 * LDH;
 #pragma unroll
       for (int i = 0; i < RB; ++i)
@@ -839,20 +876,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
   // One stage = one (vertical tap, k chunk) group = three taps x two k-steps (12 MFMAs per wave at 128 x 128): a third of the
   // barriers of the per-tap pipeline, and the next group's operands have a whole group of MFMAs to arrive.
   const int ngroups = 3 * KC;
-  fetch_a(0, 0);
-  load_b(0, 0, 0);
+  int kc_next = 0;
+  auto advance = [&]() {                            // (ty, kc) of the next group to fetch and its carried offsets
+    if (++kc_next == KC) {
+      kc_next = 0;
+      ++ty_next;
+      sa_next += a_row_step + BK * XES;
+      swb_next += w_row_step + BK * 2;
+    } else {
+      sa_next += BK * XES;
+      swb_next += BK * 2;
+    }
+  };
+  fetch_a();
+  load_b(0);
+  advance();
   stash_a(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int ty1 = 0, kc1 = 0;   // group g + 1 = (ty1, kc1), counted without divisions
+  const float* a_cur = As + (wm * TM * 32 + li) * LDH;      // this group's tiles; the two ring slots alternate
+  const float* b_cur = Bs + (wn * TN * 32 + li) * LDH;
+  int a_flip = HR * LDH, b_flip = 3 * BN * LDH;
   for (int g = 0; g < ngroups; ++g) {
-    if (++kc1 == KC) { kc1 = 0; ++ty1; }
     if (g + 1 < ngroups) {
-      load_b(ty1, kc1, (g + 1) & 1);
-      fetch_a(ty1, kc1);
+      load_b((g + 1) & 1);
+      fetch_a();
+      advance();
     }
-    const float* a0 = As + (g & 1) * HR * LDH + (wm * TM * 32 + li) * LDH;
-    const float* b0 = Bs + (g & 1) * 3 * BN * LDH + (wn * TN * 32 + li) * LDH;
+    const float* a0 = a_cur;
+    const float* b0 = b_cur;
+    a_cur += a_flip; a_flip = -a_flip;
+    b_cur += b_flip; b_flip = -b_flip;
     const int sb = (li >> 2) & 3;
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
@@ -885,13 +939,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
 #endif
 }
 
-template <int BN, int WM, int WN, int SEG = 1>
+template <int BN, int WM, int WN, int SEG = 1, bool X16 = false>
 static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
   const size_t tiles = (size_t)2 * (132 + 3 * BN) * LDH * sizeof(float);
   const size_t epi = (size_t)(2 * 128 + WM * BN * 2) * sizeof(float);   // conv_epilogue: rowoff[BM] (int64) + red[WM][BN][2]
   const size_t lds_bytes = tiles > epi ? tiles : epi;
-  DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN, SEG>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN, SEG>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_SET_LDS_ONCE((conv_halo_w16_kernel<BN, WM, WN, SEG, X16>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_w16_kernel<BN, WM, WN, SEG, X16>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -1548,6 +1602,221 @@ __global__ __launch_bounds__(768) void wgrad3_ring_kernel(WgradParams p) {
 #endif
 }
 
+// ---- 3x3 stride-1 weight gradient of the bf16-STORAGE training mode: x and dy are bfloat16 in memory -------------------
+// The 12-wave ring kernel above moves fp32 tiles through LDS and rounds the fragments after k-strided 32-bit reads (18 reads
+// + 16 conversions per 3 MFMAs: 24 % matrix-pipe time, profiles/r02_pmc_conv_bf16.txt).  Here
+//   * both tensors arrive as bf16 by LDS-DMA: half the bytes per stage (17 KB instead of 35), so the ring is FOUR stages
+//     deep at the same two workgroups per CU -- three stages of prefetch against the ~2 us loaded round trip that bounded
+//     the two-deep ring;
+//   * the k index of this GEMM is the PIXEL, the slow index of both NHWC tiles: the fragments are read with gfx950's
+//     transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block and every lane gets
+//     its channel's 4 consecutive pixels) -- 2 reads per 8-deep operand, no conversion, no packing: 8 LDS instructions per
+//     3 MFMAs instead of 18 + 16 VALU;
+//   * the LDS image is built for that read: each tile is split in two 32-channel halves with 64-byte pixel rows,
+//     [half][pixel][32 ch], so the 32 lanes of a service group (rows P..P+3 x 64 B) cover all 64 banks exactly once,
+//     whatever the tap shift.  The DMA builds it for free: slot s of an op takes the 16-byte source chunk (pixel, 8 channels)
+//     the image wants there (lane-linear destination, per-lane source address).
+// Wave = (32 co x 32 ci quadrant) x kernel row ky as in the ring kernel; same accumulator layout and split-K partials.
+template <int D>
+__global__ __launch_bounds__(768) void wgrad3_tr_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 32, XW = P + 2, LC = 64;
+  constexpr int YB = 2 * P * 64;                        // dY tile bytes: [2 halves][32 px][64 B]          = 4096
+  constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows x 34 px][64 B]              = 6528
+  constexpr int NYO = YB / 1024, NXO = (2 * XH + 1023) / 1024;   // 1-KB DMA ops: 4 + 13
+  constexpr int XB = NXO * 1024, STG = YB + XB;         // stage bytes (17408)
+  constexpr int NOPS = NYO + NXO;                       // 17 ops per stage over 12 waves: op j = wave (+ 12)
+  static_assert(NYO <= 12 && NOPS > 12 && NOPS <= 24, "op 0: dY or X, op 1: X");
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int quad = wave & 3, ky = wave >> 2;
+  const int wci = quad & 1, wco = quad >> 1;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {   // all (ci, co) tiles of a split on one XCD: they read the same x / dy tiles (see wgrad3_ring_kernel)
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * LC, co0 = by * LC;
+  const bool do_bias = p.bias_ws && bx == 0;
+  float bsum = 0.f;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+
+  // DMA ops: lane-constant source parts (bytes), wave-uniform cursor for the rest (no divisions in the loop)
+  const bool op0_y = wave < NYO, op1_on = wave + 12 < NOPS;
+  unsigned loff[2];
+  int lpx[2], lqy[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave + 12 * i;
+    if (j < NYO) {
+      const int s = j * 64 + lane;                       // 16-byte slot of the dY image
+      const int h = s >> 7, px = (s & 127) >> 2, q = s & 3;
+      lpx[i] = px;
+      lqy[i] = 0;
+      loff[i] = (unsigned)((px * p.dy.ld + co0 + 32 * h + 8 * q) * 2);
+    } else {
+      const int s = (j - NYO) * 64 + lane;               // slot of the X image: [half][row qy][xi][4 slots]
+      const int h = s / (3 * XW * 4), r = (s - h * 3 * XW * 4) >> 2, q = s & 3;
+      const int qy = r / XW, xi = r - qy * XW;
+      const bool on = h < 2 && j < NOPS && (ci0 + 32 * h + 8 * q) < p.K;
+      lpx[i] = xi - 1;
+      lqy[i] = on ? qy - 1 : (1 << 28);
+      loff[i] = (unsigned)((((qy - 1) * wx + xi - 1) * p.x.ld + ci0 + 32 * h + 8 * q) * 2);
+    }
+  }
+  const int ldst0 = op0_y ? wave * 1024 : YB + (wave - NYO) * 1024;
+  const int ldst1 = YB + (wave + 12 - NYO) * 1024;
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 2);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wx * p.x.ld) * 2);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 2), xrow_step = (unsigned)(wx * p.x.ld * 2);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 2), xseg_step = (unsigned)(P * p.x.ld * 2);
+  auto issue = [&](int buf) {   // loads the cursor's chunk into ring slot `buf`, then advances the cursor
+    char* slot = ldsb + buf * STG;
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+    if (op0_y) {
+      const bool ok = ox0 + lpx[0] < wy;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(slot + ldst0), 16, ok ? ybase + loff[0] : DMA_BAD, 0, 0, 0);
+    } else {
+      const bool ok = (unsigned)(cur_oy + lqy[0]) < (unsigned)hx && (unsigned)(ox0 + lpx[0]) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst0), 16, ok ? xbase + loff[0] : DMA_BAD, 0, 0, 0);
+    }
+    if (op1_on) {
+      const bool ok = (unsigned)(cur_oy + lqy[1]) < (unsigned)hx && (unsigned)(ox0 + lpx[1]) < (unsigned)wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst1), 16, ok ? xbase + loff[1] : DMA_BAD, 0, 0, 0);
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {   // next image: its base need not follow the previous one
+        cur_oy = 0;
+        ++cur_n;
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 2);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 2);
+      }
+    }
+  };
+
+  // transposing reads: lane (group g = lane >> 4: channel block cb = g & 1, k half kh = g >> 1; i = lane & 15) supplies the
+  // address of pixel row (i >> 2), 8-byte column chunk (i & 3) of its 16-channel block and receives channel (cb * 16 + i)'s
+  // 4 consecutive pixels.  Issued as inline assembly: through the builtin the compiler treats every read as possibly aliasing
+  // the LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of the first one -- the whole prefetched ring drained per stage.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+  const int tr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // bytes inside a half
+  const unsigned a_base = lds0 + wco * (P * 64) + (8 * kh) * 64 + tr_lane;                   // dY half wco, pixel 8 kh
+  const unsigned b_base = lds0 + YB + wci * XH + (ky * XW + 8 * kh) * 64 + tr_lane;          // X half wci, row ky, pixel 8 kh
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto op8 = [](u32x2_t lo, u32x2_t hi) -> bf16x8_t {
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  static_assert(D >= 2 && D <= 4, "ring depth");
+  const int my_ops = op1_on ? 2 : 1;
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < nst) issue(d);
+  for (int i = 0; i < nst; ++i) {
+    // this wave's DMA share of stage i has landed (the ops of up to D - 2 later stages may still be in flight) ...
+    switch (min(D - 2, nst - 1 - i) * my_ops) {
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D.  A RAW barrier: __syncthreads() carries a
+    // fence for which the compiler drains vmcnt to 0 -- i.e. waits for the whole prefetched ring -- in front of it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + D - 1 < nst) issue((i + D - 1) % D);
+    const char* st = ldsb + (i % D) * STG;
+    const unsigned so = (unsigned)((i % D) * STG);
+#pragma unroll
+    for (int ks = 0; ks < P / 16; ++ks) {
+      // the 16-pixel step's operands: dY pixels +0..3 / +4..7, and the same for the three horizontal taps of x (one pixel
+      // = 64 bytes further per tap)
+      u32x2_t al, ah, b0l, b0h, b1l, b1h, b2l, b2h;
+      const unsigned aa = a_base + so + ks * 16 * 64, ba = b_base + so + ks * 16 * 64;
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\t"
+          "ds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\t"
+          "ds_read_b64_tr_b16 %3, %9 offset:256\n\t"
+          "ds_read_b64_tr_b16 %4, %9 offset:64\n\t"
+          "ds_read_b64_tr_b16 %5, %9 offset:320\n\t"
+          "ds_read_b64_tr_b16 %6, %9 offset:128\n\t"
+          "ds_read_b64_tr_b16 %7, %9 offset:384\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(al), "=&v"(ah), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l), "=&v"(b2h)
+          : "v"(aa), "v"(ba)
+          : "memory");
+      const bf16x8_t a8 = op8(al, ah);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, op8(b0l, b0h), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, op8(b1l, b1h), acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, op8(b2l, b2h), acc[2], 0, 0, 0);
+    }
+    if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6 (8 groups of 4 pixels; combined after the loop)
+      const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(st);
+      const int c = tid & 63;
+#pragma unroll
+      for (int j = 0; j < P / 8; ++j)
+        bsum += __builtin_bit_cast(float, (unsigned)dy16[(c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31)] << 16);
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (tid < 512) red[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[64 * w + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t;
+    }
+  }
+  if ((ci0 + wci * 32) < p.K) {
+    float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = acc[kx][e];
+      }
+  }
+#endif
+}
+
 template <int CIT>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1687,9 +1956,11 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   wt[i] = w[((int64_t)co * taps + t) * cin + ci];
 }
 
-bool img_ok(const df_img& d) {
-  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.grp_size > 0 &&
-         (d.n % d.grp_size) == 0 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 && (d.grp_off % 4) == 0;
+// any16: the caller accepts bfloat16 elements too (then 16-byte alignment is 8 elements)
+bool img_ok(const df_img& d, bool any16 = false) {
+  const int a = d.elt == 1 ? 8 : 4;
+  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.grp_size > 0 && (d.elt == 0 || (any16 && d.elt == 1)) &&
+         (d.n % d.grp_size) == 0 && (d.ld % a) == 0 && (d.img_stride % a) == 0 && (d.grp_off % a) == 0;
 }
 
 }  // namespace
@@ -1763,7 +2034,10 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream) {
-  DF_REQUIRE(img_ok(x) && img_ok(y) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
+  // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
+  // kernel with the branch-free epilogue
+  DF_REQUIRE(img_ok(x, w16 != nullptr) && img_ok(y, true) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
+  const int xes = x.elt ? 2 : 4, yes = y.elt ? 2 : 4;
   DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
   DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
   DF_REQUIRE(mode == DF_CONV_FWD || mode == DF_CONV_DGRAD, DF_E_ARG);
@@ -1807,8 +2081,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   {
     static const int no_dma = getenv("DF_CONV_NO_DMA") ? atoi(getenv("DF_CONV_NO_DMA")) : 0;
     const int64_t groups = x.n / x.grp_size;
-    const int64_t ext = ((int64_t)(x.grp_size - 1) * x.img_stride + (groups - 1) * x.grp_off + (int64_t)x.h * x.w * x.ld) * 4;
-    const int64_t dsh = (p.cls_tiles > 0) ? 0 : (int64_t)pad * ((int64_t)x.w + 1) * x.ld * 4;
+    const int64_t ext = ((int64_t)(x.grp_size - 1) * x.img_stride + (groups - 1) * x.grp_off + (int64_t)x.h * x.w * x.ld) * xes;
+    const int64_t dsh = (p.cls_tiles > 0) ? 0 : (int64_t)pad * ((int64_t)x.w + 1) * x.ld * xes;
     const int64_t wb = (int64_t)p.N * ksize * ksize * p.K * 4;
     const bool geom_ok = !(mode == DF_CONV_DGRAD && stride == 2 && p.cls_tiles == 0);  // generic s2 dgrad: register path
     if (!no_dma && geom_ok && x.img_stride >= 0 && x.grp_off >= 0 && ext + dsh < (int64_t)DMA_BAD - (16 << 20) && wb < (1ll << 31) &&
@@ -1821,8 +2095,9 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   {
     static const int wide_epi = getenv("DF_CONV_WIDE_EPI") ? atoi(getenv("DF_CONV_WIDE_EPI")) : 0;
     const int64_t ygroups = y.n / y.grp_size;
-    const int64_t yext = ((int64_t)(y.grp_size - 1) * y.img_stride + (ygroups - 1) * y.grp_off + (int64_t)y.h * y.w * y.ld) * 4;
-    p.y_bytes = (!wide_epi && y.img_stride >= 0 && y.grp_off >= 0 && yext < (int64_t)0xFFFFFFFFll - (16 << 20)) ? (unsigned)yext : 0u;
+    const int64_t yext = ((int64_t)(y.grp_size - 1) * y.img_stride + (ygroups - 1) * y.grp_off + (int64_t)y.h * y.w * y.ld) * yes;
+    p.y_bytes = ((!wide_epi || y.elt) && y.img_stride >= 0 && y.grp_off >= 0 && yext < (int64_t)0xFFFFFFFFll - (16 << 20)) ? (unsigned)yext : 0u;
+    if (y.elt) DF_REQUIRE(p.y_bytes != 0 && p.x_bytes != 0, DF_E_SHAPE);   // bf16 output: only the DMA kernels' straight-line epilogue
   }
   if (!query) g_last_dma = p.x_bytes != 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1840,6 +2115,10 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     p.w_bytes = p.w_bytes / 2;
     p.bf16 = 1;
     static const int w4 = getenv("DF_W16_WAVES4") ? atoi(getenv("DF_W16_WAVES4")) : 0;   // bit 0: 128-wide, bit 1: 64-wide tiles on 4 waves
+    if (x.elt) {   // bf16 activations in memory: 8-wave forms only
+      if (halo_ok) return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 1, true>(p, s) : launch_conv_halo_w16<64, 4, 2, 1, true>(p, s);
+      return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 2, true>(p, s) : launch_conv_halo_w16<64, 4, 2, 2, true>(p, s);
+    }
     if (halo_ok) {
       if (var == 128128) return (w4 & 1) ? launch_conv_halo_w16<128, 2, 2>(p, s) : launch_conv_halo_w16<128, 2, 4>(p, s);
       return (w4 & 2) ? launch_conv_halo_w16<64, 2, 2>(p, s) : launch_conv_halo_w16<64, 4, 2>(p, s);
@@ -1847,6 +2126,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     if (var == 128128) return (w4 & 1) ? launch_conv_halo_w16<128, 2, 2, 2>(p, s) : launch_conv_halo_w16<128, 2, 4, 2>(p, s);
     return (w4 & 2) ? launch_conv_halo_w16<64, 2, 2, 2>(p, s) : launch_conv_halo_w16<64, 4, 2, 2>(p, s);
   }
+  DF_REQUIRE(x.elt == 0, DF_E_ARG);
   switch (var) {
     case 128032: return launch_conv<128, 32, 4, 1>(p, s);
     case 64064: return launch_conv<64, 64, 2, 2>(p, s);
@@ -2000,6 +2280,40 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
   }
   DF_CHECK_LAUNCH();
   return DF_OK;
+}
+
+// bf16-STORAGE training: 3x3 stride-1 weight gradient of bfloat16 x and dy (wgrad3_tr_kernel); splits / workspace / reduce as
+// df_conv2d_wgrad_mp (df_conv2d_wgrad_splits with the same shapes).
+extern "C" int df_conv2d_wgrad_bf16(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws,
+                                    void* stream) {
+  DF_REQUIRE(img_ok(x, true) && img_ok(dy, true) && x.elt == 1 && dy.elt == 1 && ws && df_aligned16(ws), DF_E_ALIGN);
+  DF_REQUIRE(ksize == 3 && stride == 1 && pad == 1, DF_E_SHAPE);
+  DF_REQUIRE(x.n == dy.n && x.h == dy.h && x.w == dy.w && x.c % 32 == 0 && dy.c % 64 == 0 && (dy.w % 32) == 0, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 1;
+  p.stride = 1; p.pad = 1; p.K = x.c; p.N = dy.c;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 2;
+  };
+  const int64_t ex = extent(x), ey = extent(dy);
+  DF_REQUIRE(x.img_stride >= 0 && dy.img_stride >= 0 && x.grp_off >= 0 && dy.grp_off >= 0 && ex < (int64_t)DMA_BAD && ey < (int64_t)DMA_BAD,
+             DF_E_SHAPE);
+  p.x_bytes = (unsigned)ex;
+  p.dy_bytes = (unsigned)ey;
+  p.chunks_per_row = dy.w / 32;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static const int depth = getenv("DF_WGRAD_TR_DEPTH") ? atoi(getenv("DF_WGRAD_TR_DEPTH")) : 4;
+  const size_t stage = 4096 + 13 * 1024;
+  if (depth == 2) return launch_wgrad_dma(wgrad3_tr_kernel<2>, grid, 2 * stage, s, p, 768);
+  if (depth == 3) return launch_wgrad_dma(wgrad3_tr_kernel<3>, grid, 3 * stage, s, p, 768);
+  return launch_wgrad_dma(wgrad3_tr_kernel<4>, grid, 4 * stage, s, p, 768);
 }
 
 extern "C" int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw,

@@ -7,6 +7,38 @@
 
 namespace {
 
+// ---- element-typed 4-wide access (E = df_img.elt: 0 = float32, 1 = bfloat16; idx in ELEMENTS) -- bf16-storage training:
+// the BatchNorm / GELU passes are pure HBM streams, half the bytes is half the time
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int E>
+__device__ __forceinline__ f32x4 ldx4(const void* base, int64_t idx) {
+  if constexpr (E == 0) {
+    return ld4(reinterpret_cast<const float*>(base) + idx);
+  } else {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, v[0] << 16);
+    r[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, v[1] << 16);
+    r[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+    return r;
+  }
+}
+template <int E>
+__device__ __forceinline__ void stx4(void* base, int64_t idx, f32x4 v) {
+  if constexpr (E == 0) {
+    st4(reinterpret_cast<float*>(base) + idx, v);
+  } else {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 a, b;
+    a[0] = (__bf16)v[0]; a[1] = (__bf16)v[1]; b[0] = (__bf16)v[2]; b[1] = (__bf16)v[3];   // RNE (v_cvt_pk_bf16_f32)
+    u32x2 w;
+    w[0] = __builtin_bit_cast(unsigned, a);
+    w[1] = __builtin_bit_cast(unsigned, b);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = w;
+  }
+}
+
 // ------------------------------------------------------------------ BN finalize ---------
 // Stage A (large layers): block (channel block, group, split) sums its range of per-tile partials in double and
 // leaves [sum, sum of squares] per channel in scratch[g][split][2][C] -- the biggest layer has 32768 tiles per group,
@@ -95,21 +127,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const void* __restric
 }
 
 // ------------------------------------------------------------------ BN+GELU apply -------
-__global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const float* __restrict__ y, const float* __restrict__ bn_ss,
+template <int YE = 0, int ZE = 0>
+__global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restrict__ y, const float* __restrict__ bn_ss,
                                                             int imgs_per_group, df_img z, int64_t total4) {
   const int C4 = z.c >> 2;
   const int hw = z.h * z.w;
-  float* __restrict__ zp = reinterpret_cast<float*>(z.ptr);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / C4;
     const int c = (int)(i - m * C4) * 4;
     const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
     const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
-    const f32x4 v = ld4(y + m * z.c + c), sc = ld4(ss + c), sh = ld4(ss + z.c + c);
+    const f32x4 v = ldx4<YE>(y, m * z.c + c), sc = ld4(ss + c), sh = ld4(ss + z.c + c);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = df_gelu(v[k] * sc[k] + sh[k]);
-    st4(zp + df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
+    stx4<ZE>(z.ptr, df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
   }
 }
 
@@ -144,14 +176,15 @@ __device__ __forceinline__ void block_reduce_rows(f32x4 (&acc)[NV], const RowPar
 
 // ------------------------------------------------------------------ BN+GELU backward ----
 // pass 1: partial[blk][c][2] = sum over the block's rows of (dyh, dyh * xhat)
-__global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, const float* __restrict__ y,
+template <int GE = 0, int YE = 0>
+__global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, const void* __restrict__ y,
                                                                  const float* __restrict__ bn_ss, int imgs_per_group,
                                                                  float* __restrict__ partial, int64_t rows,
                                                                  int64_t rows_per_blk) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 2];
   const int C = dz.c, hw = dz.h * dz.w;
   const RowPart rp = row_part(C);
-  const float* __restrict__ dzp = reinterpret_cast<const float*>(dz.ptr);
+  const void* __restrict__ dzp = dz.ptr;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r_end = min(r_begin + rows_per_blk, rows);
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -161,8 +194,8 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
     const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
     for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
       const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
-      const f32x4 g4 = ld4(dzp + df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
-      const f32x4 yv = ld4(y + m * C + rp.c);
+      const f32x4 g4 = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
+      const f32x4 yv = ldx4<YE>(y, m * C + rp.c);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float yh = yv[k] * sc[k] + sh[k];
@@ -220,15 +253,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // pass 2: dy = scale * (dyh - c1 - xhat * c2); dbias partial = column sums of dy
-__global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const float* __restrict__ y,
+// DE = element type of dy: with bf16 the bias-gradient column sums are taken from the ROUNDED values (what the weight-gradient
+// and data-gradient kernels will read)
+template <int GE = 0, int YE = 0, int DE = 0>
+__global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const void* __restrict__ y,
                                                                 const float* __restrict__ bn_ss,
                                                                 const float* __restrict__ coef, int imgs_per_group,
-                                                                float* __restrict__ dy, float* __restrict__ dbias_partial,
+                                                                void* __restrict__ dy, float* __restrict__ dbias_partial,
                                                                 int64_t rows, int64_t rows_per_blk) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4];
   const int C = dz.c, hw = dz.h * dz.w;
   const RowPart rp = row_part(C);
-  const float* __restrict__ dzp = reinterpret_cast<const float*>(dz.ptr);
+  const void* __restrict__ dzp = dz.ptr;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r_end = min(r_begin + rows_per_blk, rows);
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
@@ -239,8 +275,8 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
     const f32x4 c1 = ld4(coef + ((int64_t)g * 2 + 0) * C + rp.c), c2 = ld4(coef + ((int64_t)g * 2 + 1) * C + rp.c);
     for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
       const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
-      const f32x4 g4 = ld4(dzp + df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
-      const f32x4 yv = ld4(y + m * C + rp.c);
+      const f32x4 g4 = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
+      const f32x4 yv = ldx4<YE>(y, m * C + rp.c);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -248,9 +284,10 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
         const float d = g4[k] * df_gelu_grad(yh);
         const float xh = (yv[k] - mu[k]) * is[k];
         o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
+        if constexpr (DE == 1) o[k] = (float)(__bf16)o[k];
         acc[0][k] += o[k];
       }
-      st4(dy + m * C + rp.c, o);
+      stx4<DE>(dy, m * C + rp.c, o);
     }
   }
   if (dbias_partial) {
@@ -409,8 +446,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(df_img dy, df_img d
   }
 }
 
-bool img_ok(const df_img& d) {
+// any16: the entry point has a bfloat16 form (bf16 rows are accessed 8 bytes = 4 elements at a time)
+bool img_ok(const df_img& d, bool any16 = false) {
   return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && (d.c % 4) == 0 && d.grp_size > 0 &&
+         (d.elt == 0 || (any16 && d.elt == 1)) &&
          (d.n % d.grp_size) == 0 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 && (d.grp_off % 4) == 0;
 }
 bool rowpart_ok(int C) { return C >= 4 && C <= 1024 && (C % 4) == 0 && (256 % (C / 4)) == 0; }
@@ -443,27 +482,45 @@ extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int gro
   return DF_OK;
 }
 
-extern "C" int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
-  DF_REQUIRE(y && bn_ss && img_ok(z) && df_aligned16(y) && imgs_per_group > 0, DF_E_ARG);
+extern "C" int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
+  DF_REQUIRE(y && bn_ss && img_ok(z, true) && df_aligned16(y) && imgs_per_group > 0 && (y_elt == 0 || y_elt == 1), DF_E_ARG);
   const int64_t total4 = (int64_t)z.n * z.h * z.w * (z.c / 4);
-  hipLaunchKernelGGL(bn_gelu_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     y, bn_ss, imgs_per_group, z, total4);
+  const dim3 grid(grid_for(total4));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
+  else if (y_elt == 1 && z.elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
+  else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
+  else hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
+  DF_REQUIRE(z.elt == 0, DF_E_ARG);
+  return df_bn_gelu_apply_t(y, 0, bn_ss, imgs_per_group, z, stream);
+}
+
+extern "C" int df_bn_gelu_bwd_reduce_t(df_img dz, const void* y, int y_elt, const float* bn_ss, int imgs_per_group, float* partial,
+                                       int nblk, void* stream) {
+  DF_REQUIRE(img_ok(dz, true) && y && bn_ss && partial && nblk > 0 && rowpart_ok(dz.c) && (y_elt == 0 || y_elt == 1), DF_E_ARG);
+  const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
+  const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
+  DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
+  const int64_t rpb = rows / nblk;
+  DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);  // a block never straddles two stat groups
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dz.elt == 0 && y_elt == 0) hipLaunchKernelGGL((bn_gelu_bwd_reduce_kernel<0, 0>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, imgs_per_group, partial, rows, rpb);
+  else if (dz.elt == 1 && y_elt == 1) hipLaunchKernelGGL((bn_gelu_bwd_reduce_kernel<1, 1>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, imgs_per_group, partial, rows, rpb);
+  else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_bwd_reduce_kernel<0, 1>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, imgs_per_group, partial, rows, rpb);
+  else hipLaunchKernelGGL((bn_gelu_bwd_reduce_kernel<1, 0>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, imgs_per_group, partial, rows, rpb);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
 
 extern "C" int df_bn_gelu_bwd_reduce(df_img dz, const float* y, const float* bn_ss, int imgs_per_group, float* partial,
                                      int nblk, void* stream) {
-  DF_REQUIRE(img_ok(dz) && y && bn_ss && partial && nblk > 0 && rowpart_ok(dz.c), DF_E_ARG);
-  const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
-  const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
-  DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
-  const int64_t rpb = rows / nblk;
-  DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);  // a block never straddles two stat groups
-  hipLaunchKernelGGL(bn_gelu_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz, y,
-                     bn_ss, imgs_per_group, partial, rows, rpb);
-  DF_CHECK_LAUNCH();
-  return DF_OK;
+  DF_REQUIRE(dz.elt == 0, DF_E_ARG);
+  return df_bn_gelu_bwd_reduce_t(dz, y, 0, bn_ss, imgs_per_group, partial, nblk, stream);
 }
 
 extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
@@ -475,18 +532,38 @@ extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int 
   return DF_OK;
 }
 
-extern "C" int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef,
-                                    int imgs_per_group, float* dy, float* dbias_partial, int nblk, void* stream) {
-  DF_REQUIRE(img_ok(dz) && y && bn_ss && coef && dy && nblk > 0 && rowpart_ok(dz.c), DF_E_ARG);
+extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const float* bn_ss, const float* coef,
+                                      int imgs_per_group, void* dy, int dy_elt, float* dbias_partial, int nblk, void* stream) {
+  DF_REQUIRE(img_ok(dz, true) && y && bn_ss && coef && dy && nblk > 0 && rowpart_ok(dz.c) && (y_elt == 0 || y_elt == 1) &&
+                 (dy_elt == 0 || dy_elt == 1), DF_E_ARG);
   const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
   const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
   DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
   const int64_t rpb = rows / nblk;
   DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);
-  hipLaunchKernelGGL(bn_gelu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz, y,
-                     bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DF_BWD_APPLY(G, Y, D) \
+  hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<G, Y, D>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb)
+  const int key = dz.elt * 4 + y_elt * 2 + dy_elt;
+  switch (key) {
+    case 0: DF_BWD_APPLY(0, 0, 0); break;
+    case 1: DF_BWD_APPLY(0, 0, 1); break;
+    case 2: DF_BWD_APPLY(0, 1, 0); break;
+    case 3: DF_BWD_APPLY(0, 1, 1); break;
+    case 4: DF_BWD_APPLY(1, 0, 0); break;
+    case 5: DF_BWD_APPLY(1, 0, 1); break;
+    case 6: DF_BWD_APPLY(1, 1, 0); break;
+    default: DF_BWD_APPLY(1, 1, 1); break;
+  }
+#undef DF_BWD_APPLY
   DF_CHECK_LAUNCH();
   return DF_OK;
+}
+
+extern "C" int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef,
+                                    int imgs_per_group, float* dy, float* dbias_partial, int nblk, void* stream) {
+  DF_REQUIRE(dz.elt == 0, DF_E_ARG);
+  return df_bn_gelu_bwd_apply_t(dz, y, 0, bn_ss, coef, imgs_per_group, dy, 0, dbias_partial, nblk, stream);
 }
 
 extern "C" int df_colsum_partial(df_img x, float* partial, int nblk, void* stream) {

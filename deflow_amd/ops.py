@@ -50,20 +50,30 @@ PROFILER: Optional[KernelProfiler] = None
 MFMA_BF16 = False
 
 
-class mfma_bf16:
-    """with ops.mfma_bf16(True): ...  -- scoped form of the switch above"""
+# bf16 STORAGE on top of the bf16-operand mode (round 3; on with Trainer(dtype="bf16") unless DF_BF16_STORE=0): inside the UNet
+# encoder the conv outputs y, the activations z, and the gradients dz / dy of every 3x3 stride-1 ConvWithNorms layer live in
+# HBM as bfloat16 (BatchNorm statistics from the fp32 accumulators' rounded values, normalisation / GELU / their backward in
+# fp32 registers) -- the BatchNorm + GELU passes and the conv I/O move half the bytes, and the weight gradient reads bf16 tiles
+# with transposing LDS reads (csrc/conv.hip wgrad3_tr_kernel).  Stage inputs / outputs (the skip tensors) stay fp32.
+BF16_STORE = False
 
-    def __init__(self, on: bool):
-        self.on = bool(on)
+
+class mfma_bf16:
+    """with ops.mfma_bf16(True[, store=True]): ...  -- scoped form of the switches above"""
+
+    def __init__(self, on: bool, store: bool = False):
+        self.on, self.store = bool(on), bool(on) and bool(store)
 
     def __enter__(self):
-        global MFMA_BF16
+        global MFMA_BF16, BF16_STORE
         self.prev, MFMA_BF16 = MFMA_BF16, self.on
+        self.prev_store, BF16_STORE = BF16_STORE, self.store
         return self
 
     def __exit__(self, *exc):
-        global MFMA_BF16
+        global MFMA_BF16, BF16_STORE
         MFMA_BF16 = self.prev
+        BF16_STORE = self.prev_store
         return False
 
 
@@ -262,9 +272,13 @@ def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, mo
          ptr(rmean), ptr(rvar), ptr(bn_ss), ptr(scratch), splits, stream())
 
 
+def _elt(t: torch.Tensor) -> int:
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
 def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):
-    with timed("bn_gelu_apply", bytes=8.0 * y.numel()):          # read y, write z
-        call("df_bn_gelu_apply", ptr(y), ptr(bn_ss), imgs_per_group, z, stream())
+    with timed("bn_gelu_apply", bytes=(y.element_size() + (2.0 if z.elt else 4.0)) * y.numel()):          # read y, write z
+        call("df_bn_gelu_apply_t", ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, z, stream())
 
 
 def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
@@ -276,8 +290,8 @@ def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
 
 
 def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True,
-                frozen: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """-> dy [n,h,w,C], dgamma [C], dbeta [C], dbias [C].
+                frozen: bool = False, dy_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> dy [n,h,w,C] (dy_dtype: float32, or bfloat16 in the bf16-storage mode), dgamma [C], dbeta [C], dbias [C].
     frozen: eval-mode BatchNorm (running statistics are constants): the batch-statistic terms of the data gradient
     vanish (coef = 0), dgamma / dbeta keep their form, and the conv bias gradient is no longer cancelled."""
     dev = y.device
@@ -286,8 +300,9 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
     nbg = _pow2_blocks(rows_per_group)
     nblk = nbg * groups
     partial = _f32(nblk, C, 2, device=dev)
-    with timed("bn_gelu_bwd_reduce", bytes=8.0 * y.numel()):     # read dz, y
-        call("df_bn_gelu_bwd_reduce", dz, ptr(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
+    gb = 2.0 if dz.elt else 4.0
+    with timed("bn_gelu_bwd_reduce", bytes=(gb + y.element_size()) * y.numel()):     # read dz, y
+        call("df_bn_gelu_bwd_reduce_t", dz, ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
     if SYNC is not None and not frozen:
         red = partial.view(groups, nbg, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
         dbeta, dgamma = red[:, :, 0].sum(0).float(), red[:, :, 1].sum(0).float()
@@ -299,10 +314,11 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
         call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
         if frozen:
             coef.zero_()
-    dy = torch.empty_like(y)
+    dy = torch.empty(y.shape, dtype=dy_dtype, device=dev)
     dbp = _f32(nblk, C, device=dev)
-    with timed("bn_gelu_bwd_apply", bytes=12.0 * y.numel()):     # read dz, y; write dy
-        call("df_bn_gelu_bwd_apply", dz, ptr(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), ptr(dbp), nblk, stream())
+    with timed("bn_gelu_bwd_apply", bytes=(gb + y.element_size() + dy.element_size()) * y.numel()):     # read dz, y; write dy
+        call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), _elt(dy), ptr(dbp), nblk,
+             stream())
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
     return dy, dgamma, dbeta, dbias
@@ -347,11 +363,15 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
-    call("df_conv2d_wgrad_mp", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
-         int(MFMA_BF16), stream())
+    t16 = bool(x.elt and dy.elt)
+    if t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
+        call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
+    else:
+        call("df_conv2d_wgrad_mp", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
+             int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = (f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_tr_kernel<4>" if t16 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"

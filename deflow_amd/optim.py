@@ -248,6 +248,8 @@ class Trainer:
         # accumulation; master weights, Adam state, activations, BatchNorm statistics, GRU state and gates, and the loss stay
         # fp32 (no loss scaling needed: bf16 has fp32's exponent range)
         self.mfma_bf16 = dtype == "bf16"
+        # bf16 STORAGE inside the UNet encoder (ops.BF16_STORE) goes with the mode; DF_BF16_STORE=0 keeps fp32 tensors (A/B, tests)
+        self.bf16_store = os.environ.get("DF_BF16_STORE", "1") != "0"
         self.loss_fn = loss_fn
         # Lightning's gradient_clip_val (norm clipping of the synchronised gradient, torch.nn.utils.clip_grad_norm_); 0 = off
         self.gradient_clip_val = float(gradient_clip_val)
@@ -466,7 +468,7 @@ class Trainer:
     def step(self, batch) -> torch.Tensor:
         self.flat.zero_grad()
         self.sink.begin()
-        with ops.mfma_bf16(self.mfma_bf16), ops.side_stream(self._side_on(), self.flat.grad.device):
+        with ops.mfma_bf16(self.mfma_bf16, self.bf16_store), ops.side_stream(self._side_on(), self.flat.grad.device):
             loss = self._forward_backward(batch)
         scale = self.reduce_gradients()
         if self.gradient_clip_val > 0:       # two launches on the 27.6 MB arena, no host sync

@@ -57,8 +57,10 @@ class UpsampleSkip(nn.Module):
                                    nn.Conv2d(out_channels, out_channels, 3, 1, 1))
 
 
-def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int, train: bool, tape: Optional[list]):
-    """z = gelu(bn(conv(x))).  train: batch statistics per group (+ running update); else running stats, fused."""
+def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int, train: bool, tape: Optional[list],
+                 store16: bool = False):
+    """z = gelu(bn(conv(x))).  train: batch statistics per group (+ running update); else running stats, fused.
+    store16 (training, bf16-storage mode): the conv output y is kept as bfloat16 (z's type is the caller's: its descriptor)."""
     dev = m.conv.weight.device
     w, b, bn = ops.ohwi(m.conv.weight), m.conv.bias.detach(), m.batchnorm
     C = m.conv.out_channels
@@ -81,7 +83,7 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     tile_m = ops.conv_tile_m(rows_pg, C)
     assert rows_pg % tile_m == 0, "BatchNorm statistic groups must be a multiple of the row tile"
     tiles_pg = rows_pg // tile_m
-    y = torch.empty(n_imgs, z.h, z.w, C, dtype=torch.float32, device=dev)
+    y = torch.empty(n_imgs, z.h, z.w, C, dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
     partial = torch.empty(tiles_pg * groups, C, 2, dtype=torch.float32, device=dev)
     yi = img(y)
     yi.grp_size = ipg  # stat groups are image groups: tile -> group by its first row
@@ -94,6 +96,17 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     ops.bn_gelu_apply(y, bn_ss, ipg, z)
     if tape is not None:
         tape.append(("cwn", m, x, y, bn_ss, ipg, groups, False))
+
+
+def _stage_store16_ok(n: int, h: int, w: int, c: int, dev) -> bool:
+    """do the bf16-tile kernels (df_conv2d_w16 with bfloat16 tensors, df_conv2d_wgrad_bf16) exist for an [n,h,w,c] -> [n,h,w,c]
+    3x3 stride-1 layer?  (asks the library with descriptors of that shape; nothing is launched)"""
+    if os.environ.get("DF_BF16_STORE") == "0" or w % 32 or c % 64:
+        return False
+    probe = torch.empty(16, dtype=torch.bfloat16, device=dev)
+    d = DfImg(probe.data_ptr(), n, h, w, c, c, n, h * w * c, 0, 1, 0)
+    return (call("df_conv2d_w16_ok", d, d, 3, 1, ops.CONV_FWD, ops.EPI_STATS) == 1
+            and call("df_conv2d_w16_ok", d, d, 3, 1, ops.CONV_DGRAD, ops.EPI_BIAS) == 1)
 
 
 class FastFlow3DUNet(nn.Module):
@@ -130,6 +143,10 @@ class FastFlow3DUNet(nn.Module):
             for i, m in enumerate(stage):
                 if i == 0:
                     h, w = h // 2, w // 2
+                    # bf16-storage mode (ops.BF16_STORE, training with a tape): inside a stage whose 3x3 stride-1 layers have
+                    # the bf16-tile kernels (W % 128 == 0, or W == 64) every y / z / dz / dy is bfloat16; the stage's input
+                    # and its last activation (the skip tensor) stay fp32
+                    store16 = bool(train and tape is not None and ops.BF16_STORE and ops.MFMA_BF16 and _stage_store16_ok(2 * B, h, w, m.conv.out_channels, dev))
                 C = m.conv.out_channels
                 if i == len(stage) - 1:
                     cat = torch.empty(B, h, w, 2 * C, **f32)
@@ -137,9 +154,9 @@ class FastFlow3DUNet(nn.Module):
                     z = img_pair(cat, C)
                     keep = cat
                 else:
-                    keep = torch.empty(2 * B, h, w, C, **f32)
+                    keep = torch.empty(2 * B, h, w, C, dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
                     z = img(keep)
-                _cwn_forward(m, x, z, 2 * B, 2, train, tape)
+                _cwn_forward(m, x, z, 2 * B, 2, train, tape, store16)
                 alive.append(keep)  # without this a no-tape run would free x's tensor before the next conv reads it
                 if tape is not None:
                     tape.append(("keep", keep))
@@ -400,11 +417,15 @@ class FastFlow3DUNet(nn.Module):
             for i in reversed(range(len(stage))):
                 pop("keep")
                 _, m, x, y, bn_ss, ipg, groups, frozen = pop("cwn")
-                dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups, frozen=frozen)
+                # bf16-storage stage (y is bfloat16): dy of its stride-1 layers is bfloat16 too, and so is the dx they hand to
+                # the layer in front; the stage's first (stride-2) layer keeps an fp32 dy for the fp32 kernels that consume it
+                s16 = y.dtype == torch.bfloat16 and i > 0
+                dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups, frozen=frozen,
+                                                           dy_dtype=torch.bfloat16 if s16 else torch.float32)
                 hold(dy)
                 grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
                 if i > 0:
-                    dxt = torch.empty(2 * B, x.h, x.w, x.c, **f32)
+                    dxt = torch.empty(2 * B, x.h, x.w, x.c, dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
                     dx, acc = img(dxt), False
                 elif sidx == 1 and sparse_input_grad:
                     dx, acc = None, False

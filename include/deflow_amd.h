@@ -35,6 +35,10 @@ typedef struct df_img {
   int32_t grp_size;   /* images per group */
   int64_t img_stride; /* elements between images inside a group */
   int64_t grp_off;    /* element offset of group g */
+  int32_t elt;        /* element type: 0 = float32 (every entry point), 1 = bfloat16 (bf16-STORAGE training, round 3: only the
+                         entry points that say so accept it -- df_conv2d_w16 x / y, df_conv2d_mp y, df_bn_gelu_*_t,
+                         df_conv2d_wgrad_bf16; all others return DF_E_ARG).  ld / img_stride / grp_off stay in ELEMENTS */
+  int32_t reserved;   /* 0 */
 } df_img;
 
 int df_version(void);
@@ -219,6 +223,15 @@ int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int
 int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef, int imgs_per_group,
                          float* dy, float* dbias_partial, int nblk, void* stream);
 /* generic column sums: out[c] = sum over partial rows (used for conv bias grads etc.) */
+/* bf16-STORAGE training (round 3): the same three passes with typed tensors.  *_elt / df_img.elt: 0 = float32, 1 = bfloat16;
+ * arithmetic in fp32 registers either way.  df_bn_gelu_bwd_apply_t with dy_elt = 1 takes the bias-gradient column sums from
+ * the ROUNDED dy (what the weight- and data-gradient kernels read).  Replaces the BatchNorm2d + GELU of ConvWithNorms and its
+ * backward [REF decoder.py:202-220] when activations are kept in bfloat16 (Lightning precision="bf16-mixed" keeps them so). */
+int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, void* stream);
+int df_bn_gelu_bwd_reduce_t(df_img dz, const void* y, int y_elt, const float* bn_ss, int imgs_per_group, float* partial, int nblk,
+                            void* stream);
+int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const float* bn_ss, const float* coef, int imgs_per_group, void* dy,
+                           int dy_elt, float* dbias_partial, int nblk, void* stream);
 int df_colsum_partial(df_img x, float* partial, int nblk, void* stream);
 int df_colsum_finalize(const float* partial, int nblk, int C, int nvals, float* out, int accumulate, void* stream);
 /* first stage for very many partial rows: out[g][total] = sum of row group g (rows split evenly into `groups`);
@@ -239,6 +252,11 @@ int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, int pad, floa
                        const int32_t* row_counts, int rows_per_seg, float* bias_ws, int mfma_bf16, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
+/* bf16-STORAGE training (round 3): the 3x3 stride-1 weight gradient of BFLOAT16 x and dy (df_img.elt = 1 on both; W % 32 == 0):
+ * bf16 tiles by LDS-DMA into a four-deep ring, fragments by transposing LDS reads (ds_read_b64_tr_b16), fp32 accumulation and
+ * fp32 split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce exactly as df_conv2d_wgrad_mp.  Replaces the weight
+ * gradient autograd takes for the Conv2d of ConvWithNorms [REF decoder.py:205,213] under bf16 autocast. */
+int df_conv2d_wgrad_bf16(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws, void* stream);
 /* bf16 inference convolution (BASELINE configs[4], "bf16 MFMA"): x, w bf16 (NHWC / [Cout,kh,kw,Cin]), fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, epilogue DF_EPI_BIAS or DF_EPI_BN_GELU in fp32, output bf16 (out_f32 = 0) or fp32.
  * df_img element counts (c, ld, strides) are in elements of the respective type; Cin, Cout multiples of 64.

@@ -37,7 +37,7 @@ def test_binding_table_matches_header(lib_path):
 
 def test_struct_layouts():
     from deflow_amd import _lib
-    assert ctypes.sizeof(_lib.DfImg) == 48 and _lib.DfImg.img_stride.offset == 32
+    assert ctypes.sizeof(_lib.DfImg) == 56 and _lib.DfImg.img_stride.offset == 32 and _lib.DfImg.elt.offset == 48   # + elt (round 3)
     assert ctypes.sizeof(_lib.DfGeom) == 48
     assert ctypes.sizeof(_lib.DfGruWeights) == 80 and ctypes.sizeof(_lib.DfGruWeightsT) == 24
 
@@ -99,7 +99,8 @@ def test_counted_vmcnt_kernels_do_not_spill():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "deflow_amd", "csrc")
-    for fname, kernels in (("conv_bf16.hip", ["conv64_roll_bf16_kernel"]), ("decoder_wgrad.hip", ["gru_wgrad_kernel"])):
+    for fname, kernels in (("conv_bf16.hip", ["conv64_roll_bf16_kernel"]), ("decoder_wgrad.hip", ["gru_wgrad_kernel"]),
+                           ("conv.hip", ["wgrad3_tr_kernel"])):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result", "-c",
                             os.path.join(src, fname), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
                            capture_output=True, text=True, timeout=600)

@@ -845,3 +845,124 @@ torch.save(y.float().cpu(), sys.argv[1])
         ref = F.gelu(ref * sc + sh)
     err = float((outs["roll"].to(dev) - ref).abs().max() / ref.abs().max())
     assert err < (2e-5 if out_f32 else 5e-3), err
+
+
+# ------------------------------------------------------------------------ bf16-STORAGE training kernels (round 3) ----
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 128), (128, 128, 2, 6, 128), (256, 256, 2, 4, 64), (64, 64, 1, 4, 256)])
+@pytest.mark.parametrize("mode", ["fwd_stats", "dgrad", "dgrad_acc"])
+def test_conv_w16_bf16_storage(dev, cin, cout, n, h, w, mode):
+    """df_conv2d_w16 with BFLOAT16 tensors in memory (bf16-storage training): x bf16 -> y bf16, fp32 accumulation.  bf16 x bf16
+    products are exact in fp32, so the result must equal F.conv2d on the same bf16 values up to the final rounding of y
+    (half an ulp of bf16 = 2^-9 relative) -- checked against the fp32 result rounded to bf16: equal, or one bf16 ulp apart where
+    the fp32 sums differ in the last bits.  Statistics epilogue: sums of the ROUNDED outputs."""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call, ptr, stream
+    g = torch.Generator().manual_seed(cin + h)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    bias = torch.randn(cout, generator=g) * 0.1
+    w16 = _bf(wt)
+    w_ohwi = ops.ohwi(wt.to(dev).contiguous(memory_format=torch.channels_last))      # [cout,3,3,cin]
+    if mode == "fwd_stats":
+        x = _bf(torch.randn(n, h, w, cin, generator=g)).to(dev)
+        want = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w16.float(), _bf(bias).float() * 0 + bias, padding=1).permute(0, 2, 3, 1)
+        wk, bk, conv_mode, epi = w_ohwi, bias.to(dev), ops.CONV_FWD, ops.EPI_STATS
+    else:   # data gradient: x plays dy [n,h,w,cout]; dx = conv_transpose2d(dy, w)
+        x = _bf(torch.randn(n, h, w, cout, generator=g)).to(dev)
+        want = F.conv_transpose2d(x.float().cpu().permute(0, 3, 1, 2), w16.float(), padding=1).permute(0, 2, 3, 1)
+        wk, bk, conv_mode, epi = ops.weight_transpose(w_ohwi), None, ops.CONV_DGRAD, ops.EPI_BIAS
+    oc = want.shape[3]
+    y = torch.zeros(n, h, w, oc, dtype=torch.bfloat16, device=dev)
+    base = None
+    if mode == "dgrad_acc":
+        base = _bf(torch.randn(n, h, w, oc, generator=g)).to(dev)
+        y.copy_(base)
+    rows = n * h * w
+    tile_m = ops.conv_tile_m(rows, oc)
+    partial = torch.zeros(rows // tile_m, oc, 2, device=dev) if epi == ops.EPI_STATS else None
+    wb = torch.empty(wk.numel(), dtype=torch.bfloat16, device=dev)
+    kin = x.shape[3]
+    call("df_cast_bf16", ptr(wk), ptr(wb), wk.numel() // kin, kin, kin, kin, stream())
+    assert call("df_conv2d_w16_ok", img(x), img(y), 3, 1, conv_mode, epi) == 1
+    call("df_conv2d_w16", img(x), ptr(wb), ptr(bk), img(y), 3, 1, 1, conv_mode, epi, None, None, ptr(partial), int(mode == "dgrad_acc"), stream())
+    torch.cuda.synchronize()
+    ref = want + (base.float().cpu() if base is not None else 0.0)
+    got = y.float().cpu()
+    ref16 = _bf(ref).float()
+    ulp = ref.abs().clamp_min(1e-6) * 2.0 ** -7           # one bf16 ulp is <= 2^-7 relative
+    bad = (got - ref16).abs() > ulp
+    assert not bad.any(), (int(bad.sum()), float((got - ref16).abs().max()))
+    assert (got == ref16).float().mean() > 0.98
+    if partial is not None:
+        s = partial.sum(0).cpu()
+        check("w16 bf16 stats sum", s[:, 0], got.reshape(-1, oc).sum(0), 2e-5)
+        check("w16 bf16 stats sumsq", s[:, 1], (got.reshape(-1, oc) ** 2).sum(0), 2e-5)
+
+
+@pytest.mark.parametrize("C,n,h,w", [(64, 4, 8, 32), (256, 2, 4, 16)])
+def test_bn_gelu_passes_typed(dev, C, n, h, w):
+    """df_bn_gelu_{apply,bwd_reduce,bwd_apply}_t in every float32 / bfloat16 combination the bf16-storage mode uses against
+    the same formulas in torch on the SAME (bf16-valued) inputs: outputs within half a bf16 ulp, sums tight."""
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(C)
+    y32 = torch.randn(n, h, w, C, generator=g)
+    dz32 = torch.randn(n, h, w, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    for ye, ge, de in ((torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32, torch.bfloat16),
+                       (torch.bfloat16, torch.bfloat16, torch.float32), (torch.float32, torch.float32, torch.float32)):
+        y, dz = y32.to(ye).to(dev), dz32.to(ge).to(dev)
+        yv, gv = y.float().cpu().double(), dz.float().cpu().double()
+        mean, var = yv.mean((0, 1, 2)), yv.var((0, 1, 2), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale, shift = gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd
+        bn_ss = torch.stack([scale, shift, mean, invstd]).float().view(1, 4, C).contiguous().to(dev)
+        ss = bn_ss.cpu().double()[0]
+        # forward
+        z = torch.empty(n, h, w, C, dtype=ye, device=dev)
+        ops.bn_gelu_apply(y, bn_ss, n, img(z))
+        yh = yv * ss[0] + ss[1]
+        want_z = 0.5 * yh * (1 + torch.erf(yh / 2 ** 0.5))
+        tol = 2.0 ** -8 if ye == torch.bfloat16 else 1e-6
+        assert float(((z.float().cpu().double() - want_z).abs() / want_z.abs().clamp_min(1e-2)).max()) < tol
+        # backward
+        dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(dz), y, bn_ss, n, 1, dy_dtype=de)
+        torch.cuda.synchronize()
+        cdf = 0.5 * (1 + torch.erf(yh / 2 ** 0.5))
+        d = gv * (cdf + yh * torch.exp(-0.5 * yh * yh) / (2 * torch.pi) ** 0.5)
+        xh = (yv - ss[2]) * ss[3]
+        c1, c2 = d.mean((0, 1, 2)), (d * xh).mean((0, 1, 2))
+        want_dy = ss[0] * (d - c1 - xh * c2)
+        check(f"typed bn dbeta {ye}/{ge}", dbeta, d.sum((0, 1, 2)).float(), 1e-5)
+        check(f"typed bn dgamma {ye}/{ge}", dgamma, (d * xh).sum((0, 1, 2)).float(), 1e-5)
+        tol = 2.0 ** -8 if de == torch.bfloat16 else 2e-5
+        e = float((dy.float().cpu().double() - want_dy).abs().max() / want_dy.abs().max())
+        assert e < tol, (ye, ge, de, e)
+        check(f"typed bn dbias {de}", dbias, dy.float().cpu().sum((0, 1, 2)), 1e-5)    # sums of the stored (rounded) dy
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256)])
+def test_wgrad_bf16_tr_kernel(dev, cin, cout, n, h, w):
+    """df_conv2d_wgrad_bf16 (bf16 tiles by LDS-DMA, transposing LDS reads, four-deep ring) against the exact weight gradient
+    of the same bf16 values (products exact in fp32): dW to fp32 summation-order accuracy, bias sums likewise.  Shapes with
+    several chunks per row, rows at the image border, more than one image and more stages than ring slots."""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin * 7 + w)
+    x = _bf(torch.randn(n, h, w, cin, generator=g)).to(dev)
+    dy = _bf(torch.randn(n, h, w, cout, generator=g)).to(dev)
+    dw = torch.empty(cout, 3, 3, cin, device=dev)
+    db = ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw, want_bias=True)
+    torch.cuda.synchronize()
+    xf = x.float().cpu().permute(0, 3, 1, 2).double().requires_grad_(False)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(xf, wref, padding=1)
+    out.backward(dy.float().cpu().permute(0, 3, 1, 2).double())
+    want = wref.grad.permute(0, 2, 3, 1)
+    check("tr wgrad dW", dw, want.float(), 2e-5)
+    check("tr wgrad bias", db, dy.float().cpu().sum((0, 1, 2)), 2e-5)
