@@ -892,7 +892,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
   load_b(0);
   advance();
   stash_a(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as a builtin: visible to the compiler's wait-count bookkeeping
   __syncthreads();
   const float* a_cur = As + (wm * TM * 32 + li) * LDH;      // this group's tiles; the two ring slots alternate
   const float* b_cur = Bs + (wn * TN * 32 + li) * LDH;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_w16_kernel(ConvParams 
     }
     // the next group's halo: its ring slot was last read in group g - 1 (behind the previous barrier)
     if (g + 1 < ngroups) stash_a((g + 1) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as a builtin: visible to the compiler's wait-count bookkeeping
     __syncthreads();
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);

@@ -852,7 +852,7 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 128), (128, 128, 2, 6, 128), (256, 256, 2, 4, 64), (64, 64, 1, 4, 256)])
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 40, 128), (128, 128, 2, 36, 128), (256, 256, 4, 36, 64), (64, 64, 1, 36, 256)])
 @pytest.mark.parametrize("mode", ["fwd_stats", "dgrad", "dgrad_acc"])
 def test_conv_w16_bf16_storage(dev, cin, cout, n, h, w, mode):
     """df_conv2d_w16 with BFLOAT16 tensors in memory (bf16-storage training): x bf16 -> y bf16, fp32 accumulation.  bf16 x bf16
@@ -893,7 +893,9 @@ def test_conv_w16_bf16_storage(dev, cin, cout, n, h, w, mode):
     ref = want + (base.float().cpu() if base is not None else 0.0)
     got = y.float().cpu()
     ref16 = _bf(ref).float()
-    ulp = ref.abs().clamp_min(1e-6) * 2.0 ** -7           # one bf16 ulp is <= 2^-7 relative
+    # one bf16 ulp is <= 2^-7 relative: two ulps (rounding ties of the fp32 sums); near zero the sums are cancellations whose
+    # fp32 summation-order noise is not small against the result itself: absolute floor
+    ulp = ref.abs().clamp_min(0.02) * 2.0 ** -6
     bad = (got - ref16).abs() > ulp
     assert not bad.any(), (int(bad.sum()), float((got - ref16).abs().max()))
     assert (got == ref16).float().mean() > 0.98
@@ -942,7 +944,9 @@ def test_bn_gelu_passes_typed(dev, C, n, h, w):
         tol = 2.0 ** -8 if de == torch.bfloat16 else 2e-5
         e = float((dy.float().cpu().double() - want_dy).abs().max() / want_dy.abs().max())
         assert e < tol, (ye, ge, de, e)
-        check(f"typed bn dbias {de}", dbias, dy.float().cpu().sum((0, 1, 2)), 1e-5)    # sums of the stored (rounded) dy
+        # sums of the stored (rounded) dy; the exact value is ~0 (BatchNorm cancels a conv bias), so measure against sum|dy|
+        dyc = dy.float().cpu().double()
+        assert float((dbias.cpu().double() - dyc.sum((0, 1, 2))).abs().max()) <= 2e-5 * float(dyc.abs().sum((0, 1, 2)).max())
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256)])
