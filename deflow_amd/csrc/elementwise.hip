@@ -358,10 +358,11 @@ __device__ __forceinline__ Lerp lerp_src(int dst, int in, int out, int align_cor
   return r;
 }
 
+// YE = 1: bfloat16 output (bf16-storage training: the upsampled half of an UpsampleSkip concatenation); the input stays fp32
+template <int YE = 0>
 __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int align_corners, int64_t total4) {
   const int C4 = y.c >> 2;
   const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
-  float* __restrict__ yp = reinterpret_cast<float*>(y.ptr);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t m = i / C4;
     const int c = (int)(i - m * C4) * 4;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
     const f32x4 v00 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld), v01 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld);
     const f32x4 v10 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i0) * x.ld), v11 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i1) * x.ld);
     const f32x4 o = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
-    st4(yp + df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o);
+    stx4<YE>(y.ptr, df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o);
   }
 }
 
@@ -595,11 +596,13 @@ extern "C" int df_colsum_stage(const float* partial, int nblk, int total, int gr
 }
 
 extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream) {
-  DF_REQUIRE(img_ok(x) && img_ok(y), DF_E_ARG);
+  DF_REQUIRE(img_ok(x) && img_ok(y, true), DF_E_ARG);     // y may be bfloat16 (bf16-storage training)
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     y, align_corners, total4);
+  if (y.elt) hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                                y, align_corners, total4);
+  else hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                          y, align_corners, total4);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -162,9 +162,9 @@ class FastFlow3DUNet(nn.Module):
                     tape.append(("keep", keep))
                 x = z
         fstar, lstar, rstar = cats
-        s = self._upsample_skip(self.decoder_step1, rstar, lstar, tape)
-        t = self._upsample_skip(self.decoder_step2, s, fstar, tape)
-        u = self._upsample_skip(self.decoder_step3, t, bstar, tape)
+        s = self._upsample_skip(self.decoder_step1, rstar, lstar, tape, train)
+        t = self._upsample_skip(self.decoder_step2, s, fstar, tape, train)
+        u = self._upsample_skip(self.decoder_step3, t, bstar, tape, train)
         v = torch.empty(B, H, W, 64, **f32)
         if out_cells is None:
             self._conv(self.decoder_step4, u, img(v), 3, tape)
@@ -181,18 +181,24 @@ class FastFlow3DUNet(nn.Module):
         if tape is not None:
             tape.append(("conv", m, x, ks))
 
-    def _upsample_skip(self, m: UpsampleSkip, a: torch.Tensor, b: torch.Tensor, tape: Optional[list]) -> torch.Tensor:
+    def _upsample_skip(self, m: UpsampleSkip, a: torch.Tensor, b: torch.Tensor, tape: Optional[list], train: bool = False) -> torch.Tensor:
         B, h, w, _ = a.shape
         lat, outc = m.u3.out_channels, m.u4_u5[1].out_channels
-        f32 = dict(dtype=torch.float32, device=a.device)
+        dev = a.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        # bf16-storage mode: the concatenation and the first 3x3 conv's output are bfloat16 (their consumers are the bf16-tile
+        # 3x3 kernels); the block's output stays fp32 for the 1x1 conv / sparse kernels that read it
+        s16 = bool(train and tape is not None and ops.BF16_STORE and ops.MFMA_BF16
+                   and _stage_store16_ok(B, 2 * h, 2 * w, outc, dev) and _stage_store16_ok(B, 2 * h, 2 * w, 2 * lat, dev))
+        mid = dict(dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
         t = torch.empty(B, h, w, lat, **f32)
         self._conv(m.u1_u2[0], a, img(t), 1, tape)
-        cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **f32)
+        cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **mid)
         ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
         if tape is not None:
             tape.append(("up", h, w, lat))
         self._conv(m.u3, b, img(cat, lat, lat), 1, tape)
-        u4 = torch.empty(B, 2 * h, 2 * w, outc, **f32)
+        u4 = torch.empty(B, 2 * h, 2 * w, outc, **mid)
         self._conv(m.u4_u5[0], cat, img(u4), 3, tape)
         u5 = torch.empty(B, 2 * h, 2 * w, outc, **f32)
         self._conv(m.u4_u5[1], u4, img(u5), 3, tape)
@@ -353,11 +359,13 @@ class FastFlow3DUNet(nn.Module):
 
         def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: Optional[DfImg], acc_b: bool):
             # reverse of: u1(a)->t ; up(t)->cat[:lat] ; u3(b)->cat[lat:] ; u4(cat) ; u5(u4)
+            # (bf16-storage mode: u4 and cat were bfloat16 -> du4 is bfloat16 as well, so both 3x3 weight gradients see bf16
+            #  x and dy; dcat stays fp32 for the 1x1 / upsample kernels behind it)
             _, m5, x5, _ = tape[-1]
             du4 = hold(torch.empty_like(x5))
             plain_conv_bwd(dout, img(du4), False)
             _, m4, x4, _ = tape[-1]
-            dcat = hold(torch.empty_like(x4))
+            dcat = hold(torch.empty(x4.shape, **f32))
             plain_conv_bwd(du4, img(dcat), False)
             lat = dcat.shape[3] // 2
             # u3
@@ -371,9 +379,14 @@ class FastFlow3DUNet(nn.Module):
             _, m1, xa, ks = pop("conv")
             self._conv_bwd(m1, img(xa), img(dt), 1, 1, da, acc_a, grads)
 
+        # the gradient a block receives at its output (du, dT, dS) is bfloat16 when that block kept its u4 in bfloat16 (bf16-
+        # storage mode): its two consumers are then the bf16-tile data- and weight-gradient kernels of the block's second conv
+        def dout_dtype(k):      # k-th "conv" entry from the end of the tape: (.., x, ks) with x = that conv's input
+            convs = [e for e in tape if e[0] == "conv"]
+            return convs[-k][2].dtype
         # decoder_step4
         _, m, xu, _ = tape[-1]
-        du = hold(torch.empty_like(xu))
+        du = hold(torch.empty(xu.shape, dtype=dout_dtype(2), device=dev))    # conv entries from the end: step4, step3.u5 (x = u4)
         if dv_cells is None:
             plain_conv_bwd(dv, img(du), False)
         else:
@@ -399,10 +412,11 @@ class FastFlow3DUNet(nn.Module):
             acc_b = False
         else:
             acc_b = True
-        dT = hold(torch.empty(B, H // 2, W // 2, 128, **f32))
+        # conv entries of a block in tape order: u1, u3, u4, u5 -> from the end: u5 (x = u4), u4, u3, u1
+        dT = hold(torch.empty(B, H // 2, W // 2, 128, dtype=dout_dtype(5), device=dev))      # step4, step3 (4 entries), step2.u5
         upsample_skip_bwd(du, img(dT), False, None if sparse_input_grad else img(dbstar), acc_b)
         dF = hold(torch.empty(B, H // 2, W // 2, 128, **f32))   # d(fstar)
-        dS = hold(torch.empty(B, H // 4, W // 4, 256, **f32))
+        dS = hold(torch.empty(B, H // 4, W // 4, 256, dtype=dout_dtype(5), device=dev))      # (tape shrank by one block) step1.u5
         upsample_skip_bwd(dT, img(dS), False, img(dF), False)
         dL = hold(torch.empty(B, H // 4, W // 4, 256, **f32))   # d(lstar)
         dR = hold(torch.empty(B, H // 8, W // 8, 512, **f32))   # d(rstar)

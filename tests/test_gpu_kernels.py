@@ -929,8 +929,9 @@ def test_bn_gelu_passes_typed(dev, C, n, h, w):
         ops.bn_gelu_apply(y, bn_ss, n, img(z))
         yh = yv * ss[0] + ss[1]
         want_z = 0.5 * yh * (1 + torch.erf(yh / 2 ** 0.5))
-        tol = 2.0 ** -8 if ye == torch.bfloat16 else 1e-6
-        assert float(((z.float().cpu().double() - want_z).abs() / want_z.abs().clamp_min(1e-2)).max()) < tol
+        # bf16 out: half an ulp (2^-9 relative, 2^-8 asserted) on top of the fp32 GELU (A&S erf: <= 5e-7 absolute)
+        tol = 2.0 ** -8 if ye == torch.bfloat16 else 2e-6
+        assert float(((z.float().cpu().double() - want_z).abs() / want_z.abs().clamp_min(1.0 if ye == torch.float32 else 1e-2)).max()) < tol
         # backward
         dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(img(dz), y, bn_ss, n, 1, dy_dtype=de)
         torch.cuda.synchronize()
