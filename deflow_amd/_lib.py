@@ -69,6 +69,9 @@ _SIGS = {
     "df_conv2d_tile_m": [L, I],
     "df_conv2d_w16": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_w16_ok": [DfImg, DfImg, I, I, I, I],
+    "df_conv2d_x3": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
+    "df_conv2d_x3_ok": [DfImg, DfImg, I, I, I, I],
+    "df_split_bf16x3": [P, P, L, P],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],
@@ -113,7 +116,7 @@ _SIGS = {
     "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
 _RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
-_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

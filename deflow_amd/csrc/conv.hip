@@ -951,6 +951,281 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 }
 
 
+// ---- fp32-ACCURATE 3x3 stride-1 convolution on the bf16 matrix pipe ("bf16x3", df_conv2d_x3) ---------------------------
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) moves 2 k per 64 cycles; v_mfma_f32_32x32x16_bf16 moves 16 k per 32: sixteen times the
+// k throughput.  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits: hi = bf16(x), mid = bf16(x -
+// hi), lo = bf16(x - hi - mid)), and a bf16 x bf16 product is exact in the fp32 accumulator, so
+//     x w  =  xh wh + xh wm + xm wh + xm wm + xh wl + xl wh  + (terms of relative size <= 2^-24: dropped)
+// -- six bf16 MFMAs reproduce the fp32 product to fp32 rounding (the same accumulation as before), at 16 / 6 = 2.7x the fp32
+// MFMA rate.  Round 2 tried the split on the FRAGMENTS inside conv_halo_kernel (7 VALU instructions per MFMA: no gain).  Here
+// the split happens ONCE per tile element: weights are pre-split into three bf16 planes per optimizer step (df_split_bf16x3),
+// the activation halo is split in the global -> register -> LDS staging of the bf16-tile kernel (once per workgroup and (ty, kc)
+// group, ~10 VALU per element against 4608 MFMA flops it feeds), and the loop is ds_read_b128 + MFMA only: 18 fragment reads
+// per 24 MFMAs and wave.  Six times the matrix work per byte also takes the kernel off the latency bound of the bf16-tile
+// form (12 MFMAs per wave between barriers, shorter than its own prefetch): a stage here is one TAP -- 24 MFMAs, ~770 matrix
+// cycles per wave -- and the weight tiles run through a DB-deep LDS ring with COUNTED vmcnt (DB - 1 stages = ~2 us of
+// prefetch), the halo is fetched a whole group (three stages) ahead.  LDS: A [2][3 planes][132][64 B] = 50 KB + B
+// [DB][3][BN][64 B] = 96 KB: one 8-wave workgroup per CU.
+template <int BN, int WM, int WN, int DB>
+__global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, HR = 132, SW = BM + 2;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int NIT = (SW * 4 + NT - 1) / NT;          // A staging items (one 16-byte bf16 slot = 8 floats) per thread
+  constexpr int AP = HR * LDH, AB = 3 * AP;            // A plane / buffer (floats)
+  constexpr int BP = BN * LDH, BSL = 3 * BP;           // B plane / ring slot (floats)
+  constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
+  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][3][HR][LDH]
+  float* Bs = lds + 2 * AB;             // [DB][3][BN][LDH]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int swz = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
+  const int KC = p.K / BK;
+  const bool fwd = p.mode == DF_CONV_FWD;
+  RowDecode dec;
+  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = 0; dec.py = dec.px = 0; dec.hh = dec.wh = 0;
+  int n, oy, ox0;
+  dec(m0, n, oy, ox0);
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // A staging (as conv_halo_w16_kernel): item e = LDS slot (tid + e NT): halo row j = slot >> 2, physical 16-byte slot tid & 3
+  // holding k = 8 (s ^ ((j >> 2) & 3)) .. + 7 of the chunk.  EVERY thread issues every item's two loads (out-of-range items read
+  // zeros from an out-of-range offset): the counted vmcnt waits below need the same number of operations in every wave.
+  const int aslot = tid & 3;
+  unsigned aoff[NIT];
+  bool aon[NIT];
+#pragma unroll
+  for (int e = 0; e < NIT; ++e) {
+    const int j = (tid + e * NT) >> 2;
+    const int ix = ox0 - 1 + j;
+    aon[e] = j < SW;
+    const int sl = aslot ^ ((j >> 2) & 3);
+    aoff[e] = (aon[e] && ix >= 0 && ix < wx)
+                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+  }
+  // weight DMA: a wave moves 16 rows x 64 B of one plane per instruction; plane pl sits pl * N * 9 * K elements further.
+  // BN = 64: waves 4 .. 7 repeat the rows of waves 0 .. 3 (same data to the same place) so that EVERY wave issues exactly three
+  // operations per weight stage -- the counted waits below are then compile-time constants, which the compiler's own
+  // wait-count bookkeeping can follow (run-time counts made it drain vmcnt to 0 at every halo fetch)
+  const int brow = ((wave * 16) % BN) + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned boff = (unsigned)(((int64_t)(n0 + brow) * 9 * p.K + bslot * 8) * 2);
+  const unsigned plane_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2);
+  constexpr int NBW = 3, NFA = 2 * NIT;               // VMEM operations per wave: per weight stage / per halo fetch
+
+  // carried scalar offsets (see conv_halo_w16_kernel): halo row / chunk of the NEXT group to fetch, tap (ty, tx, kc) of the next
+  // weight stage to issue
+  const unsigned a_row_step = (unsigned)(wx * ldx * 4 - KC * BK * 4);
+  const int dtap = fwd ? p.K * 2 : -p.K * 2;
+  unsigned sa_next = 0;
+  int ty_next = 0, kc_next = 0;
+  int swb_next = fwd ? 0 : 8 * p.K * 2;                // byte offset of tap (ty, tx = 0), chunk kc of the next weight GROUP
+  int btx = 0, bkc = 0;                                // next weight stage: its tap inside the group, the group's k chunk
+  const int NG = 3 * KC, NS = 3 * NG;
+
+  f32x4 ra[NIT][2];
+  auto fetch_a = [&]() {                              // the next group's halo -> registers, then advance the group cursor
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      const unsigned v = (unsigned)(oy - 1 + ty_next) < (unsigned)hx ? aoff[e] : DMA_BAD;
+      ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, sa_next, 0));
+      ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, sa_next, 0));
+    }
+    if (++kc_next == KC) {
+      kc_next = 0;
+      ++ty_next;
+      sa_next += a_row_step + BK * 4;
+    } else {
+      sa_next += BK * 4;
+    }
+  };
+  auto stash_a = [&](int abuf) {                      // registers -> three bf16 planes -> LDS
+    float* a = As + abuf * AB;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      if (e + 1 < NIT || aon[e]) {
+        float v[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        bf16x8_t hi, mi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { hi[k] = (__bf16)v[k]; r[k] = v[k] - (float)hi[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mi[k] = (__bf16)r[k]; r[k] = r[k] - (float)mi[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo[k] = (__bf16)r[k];
+        float* d = a + (tid + e * NT) * 4;
+        *reinterpret_cast<bf16x8_t*>(d) = hi;
+        *reinterpret_cast<bf16x8_t*>(d + AP) = mi;
+        *reinterpret_cast<bf16x8_t*>(d + 2 * AP) = lo;
+      }
+    }
+  };
+  // the next weight stage (tap btx of the group at swb_next): three plane tiles into the next ring slot
+  int bslot_ring = 0;
+  auto issue_b = [&]() {
+    float* b = Bs + bslot_ring * BSL + ((wave * 16) % BN) * LDH;
+    const unsigned soff = (unsigned)(swb_next + btx * dtap);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + pl * BP), 16, boff, soff + pl * plane_bytes, 0, 0);
+    if (++bslot_ring == DB) bslot_ring = 0;
+    if (++btx == 3) {                                 // next weight group: next k chunk, or the next tap row's first
+      btx = 0;
+      if (++bkc == KC) {
+        bkc = 0;
+        swb_next += 3 * dtap - KC * BK * 2 + BK * 2;
+      } else {
+        swb_next += BK * 2;
+      }
+    }
+  };
+#define DF_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int cur_slot = 0;
+  // one tap stage: issue (MAIN: the next group's halo at tx == 0, weight stage s + PD), 2 k-steps x 6 products, the waits
+  auto stage = [&](auto tx_c, auto main_c, int g, int s) {
+    constexpr int tx = decltype(tx_c)::value;
+    constexpr bool MAIN = decltype(main_c)::value;
+    const float* a0 = As + (g & 1) * AB + (wm * TM * 32 + li) * LDH;
+    if constexpr (MAIN) {
+      if (tx == 0) fetch_a();
+      issue_b();
+    } else {
+      if (tx == 0 && g + 1 < NG) fetch_a();
+      if (s + PD < NS) issue_b();
+    }
+    const float* b0 = Bs + cur_slot * BSL + (wn * TN * 32 + li) * LDH;
+    if (++cur_slot == DB) cur_slot = 0;
+    const float* a = a0 + tx * LDH;
+    const int sa = ((li + tx) >> 2) & 3, sb = (li >> 2) & 3;
+#pragma unroll
+    for (int q = 0; q < BK / 16; ++q) {
+      bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float* ap = a + i * 32 * LDH + (((2 * q + kh) ^ sa) * 4);
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(ap);
+        am[i] = *reinterpret_cast<const bf16x8_t*>(ap + AP);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(ap + 2 * AP);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* bp = b0 + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4);
+        bh[j] = *reinterpret_cast<const bf16x8_t*>(bp);
+        bm[j] = *reinterpret_cast<const bf16x8_t*>(bp + BP);
+        bl[j] = *reinterpret_cast<const bf16x8_t*>(bp + 2 * BP);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);   // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    // ---- end of the stage: (last stage of a group) the next group's halo -> LDS; then weight stage s + 1 must have landed.
+    // MAIN (every issue above happened): operations issued after the halo fetch = the 3 weight stages of this group; after
+    // weight stage s + 1's = PD - 1 weight stages + the halo fetches of the PD - 1 stages behind it.
+    if constexpr (MAIN) {
+      if (tx == 2) {
+        DF_VMCNT(3 * NBW);
+        stash_a((g + 1) & 1);
+      }
+      // halo fetches among stages s - (PD - 2) .. s: taps tx, tx - 1, ... (mod 3) -- count the zeros
+      constexpr int FA_IN = ((PD - 1) / 3) + (((PD - 1) % 3) > tx ? 1 : 0);
+      DF_VMCNT((PD - 1) * NBW + FA_IN * NFA);
+    } else {
+      DF_VMCNT(0);
+      if (tx == 2 && g + 1 < NG) stash_a((g + 1) & 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // prologue: halo of group 0, weight stages 0 .. PD - 1 (NS = 27 KC >= PD)
+  fetch_a();
+#pragma unroll
+  for (int d = 0; d < PD; ++d) issue_b();
+  DF_VMCNT(PD * NBW);                                  // the halo loads were issued first
+  stash_a(0);
+  DF_VMCNT((PD - 1) * NBW);                            // weight stage 0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // main groups: every stage s of the group has s + PD < NS, a next group to fetch, and (PD > 3) a full window of PD - 1
+  // earlier stages behind it; the first group of a deep ring and the last groups take the conservative form
+  const int g_main = max(min((NS - PD) / 3, NG - 1), 0);
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  int g = 0, s = 0;
+  if (PD > 3) {
+    stage(T0{}, std::false_type{}, g, s);
+    stage(T1{}, std::false_type{}, g, s + 1);
+    stage(T2{}, std::false_type{}, g, s + 2);
+    ++g; s += 3;
+  }
+  for (; g < g_main; ++g, s += 3) {
+    stage(T0{}, std::true_type{}, g, s);
+    stage(T1{}, std::true_type{}, g, s + 1);
+    stage(T2{}, std::true_type{}, g, s + 2);
+  }
+  for (; g < NG; ++g, s += 3) {                        // tail: run-time issue conditions, vmcnt(0) waits
+    stage(T0{}, std::false_type{}, g, s);
+    stage(T1{}, std::false_type{}, g, s + 1);
+    stage(T2{}, std::false_type{}, g, s + 2);
+  }
+#undef DF_VMCNT
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
+#endif
+}
+
+template <int BN, int WM, int WN, int DB>
+static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)(2 * 3 * 132 + DB * 3 * BN) * LDH * sizeof(float);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BN, WM, WN, DB>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BN, WM, WN, DB>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// w [n] fp32 -> three bf16 planes out3[3][n]: hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)  (w == hi + mid + lo)
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ out3, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const float r2 = r1 - (float)mi;
+    out3[i] = hi;
+    out3[n + i] = mi;
+    out3[2 * n + i] = (__bf16)r2;
+  }
+}
+
 // 8-wave forms (512 threads; wave tile 64 x 32 resp. 32 x 32, 32 / 16 accumulator registers): the same LDS footprint
 // and DMA traffic as the 4-wave kernels but twice the waves per SIMD to cover each other's barrier and DMA waits
 // (measured +2..4 % on the 128 x 128 tile).  DMA path only.
@@ -2005,7 +2280,7 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
 // exists for this call" without launching anything
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
-                       int accumulate, int mfma_bf16, bool query, void* stream);
+                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -2022,6 +2297,35 @@ extern "C" int df_conv2d_w16(df_img x, const void* w16, const float* bias, df_im
                      stream);
 }
 
+// fp32-accurate convolution through three bf16 planes per operand (conv_halo_x3_kernel): w3 = df_split_bf16x3 of the
+// [Cout, 3, 3, Cin] weights (data gradient: of the transposed weights).  Same arguments and epilogues as df_conv2d.
+extern "C" int df_conv2d_x3(df_img x, const void* w3, const float* bias, df_img y, int ksize, int stride, int pad,
+                            int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                            int accumulate, void* stream) {
+  DF_REQUIRE(w3 && df_aligned16(w3), DF_E_ALIGN);
+  return conv2d_impl(x, nullptr, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false,
+                     stream, w3);
+}
+
+extern "C" int df_conv2d_x3_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi) {
+  static const int on = getenv("DF_CONV_X3") ? atoi(getenv("DF_CONV_X3")) : 1;
+  if (!on || ksize != 3 || stride != 1) return 0;
+  const float* any = reinterpret_cast<const float*>(x.ptr);
+  const int r = conv2d_impl(x, nullptr, nullptr, nullptr, y, ksize, stride, 1, mode, epi, any, any, const_cast<float*>(any), 0, 0, true,
+                            nullptr, x.ptr);
+  return r == 1 ? 1 : 0;
+}
+
+extern "C" int df_split_bf16x3(const float* w, void* out3, int64_t n, void* stream) {
+  DF_REQUIRE(w && out3 && n > 0 && df_aligned16(out3), DF_E_ARG);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     reinterpret_cast<__bf16*>(out3), n);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi) {
   static const int on = getenv("DF_CONV_W16") ? atoi(getenv("DF_CONV_W16")) : 1;
   if (!on || (ksize != 1 && ksize != 3)) return 0;
@@ -2033,7 +2337,8 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
-                       int accumulate, int mfma_bf16, bool query, void* stream) {
+                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3) {
+  if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
   DF_REQUIRE(img_ok(x, w16 != nullptr) && img_ok(y, true) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
@@ -2105,6 +2410,16 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
   const bool halo_ok = use_halo && p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && (y.w % 128) == 0 &&
                        x.w == y.w && x.h == y.h && (var == 128128 || var == 128064);
+  if (w3) {    // df_conv2d_x3: fp32-accurate product from three bf16 planes per operand (W % 128 == 0 forms only)
+    const bool ok = halo_ok && (p.K % BK) == 0 && x.elt == 0 && y.elt == 0;
+    if (query) return ok ? 1 : 0;
+    DF_REQUIRE(ok, DF_E_SHAPE);
+    p.w = reinterpret_cast<const float*>(w3);
+    p.w_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2 * 3);
+    p.bf16 = 0;
+    if (var == 128128) return launch_conv_halo_x3<128, 2, 4, 4>(p, s);
+    return launch_conv_halo_x3<64, 4, 2, 8>(p, s);
+  }
   if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed forms exist (W % 128 == 0, or W == 64 as row pairs)
     const bool two = p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && y.w == 64 && (y.h % 2) == 0 && x.w == y.w &&
                      x.h == y.h && (var == 128128 || var == 128064);

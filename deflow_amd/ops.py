@@ -184,7 +184,16 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e0.record()
     w16 = (MFMA_BF16 and ks == 3 and stride == 1 and os.environ.get("DF_CONV_W16", "1") != "0"
            and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1)
-    if w16:
+    x3 = (not MFMA_BF16 and not w16 and ks == 3 and stride == 1 and x.elt == 0 and y.elt == 0
+          and call("df_conv2d_x3_ok", x, y, ks, stride, mode, epi) == 1)
+    if x3:
+        # fp32-accurate product from three bf16 planes per operand (conv_halo_x3_kernel): the weights are split once per call
+        # (they change every optimizer step), the activations in the kernel's staging
+        w3 = torch.empty(3 * w_ohwi.numel(), dtype=torch.bfloat16, device=w_ohwi.device)
+        call("df_split_bf16x3", ptr(w_ohwi), ptr(w3), w_ohwi.numel(), stream())
+        call("df_conv2d_x3", x, ptr(w3), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+             int(accumulate), stream())
+    elif w16:
         # bf16 tiles in LDS (conv_halo_w16_kernel): the weights are cast once per call (they change every optimizer step and
         # each conv uses them once per direction), the activations stay fp32 in memory
         wb = torch.empty(w_ohwi.numel(), dtype=torch.bfloat16, device=w_ohwi.device)
@@ -200,6 +209,9 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
         name = _conv_variant(x, y, ks, stride, mode, epi)
+        if x3:
+            bn = 128 if y.c % 128 == 0 else 64
+            name = f"conv_halo_x3_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2}>"
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"

@@ -200,6 +200,16 @@ int df_conv2d_tile_m(int64_t rows_per_stat_group, int cout); /* row-tile the lau
  * [REF decoder.py:202-220 under torch.autocast(bfloat16)] */
 int df_conv2d_w16(df_img x, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
                   const float* scale, const float* shift, float* stats_partial, int accumulate, void* stream);
+/* fp32-ACCURATE 3x3 stride-1 convolution on the bf16 matrix pipe (round 3, "bf16x3"): every fp32 operand is the exact sum of
+ * three bf16 values, six of the nine bf16 x bf16 products (exact in the fp32 accumulator) reproduce the fp32 product to
+ * <= 2^-23 relative -- the same accuracy class as v_mfma_f32_32x32x2_f32 at 16 / 6 of its rate.  w3 = df_split_bf16x3 of
+ * the [Cout,3,3,Cin] weights (3 * Cout * 9 * Cin bf16); x, y fp32; arguments / epilogues as df_conv2d.  Replaces the fp32
+ * Conv2d of ConvWithNorms / UpsampleSkip [REF decoder.py:205,213] forward and data gradient.  df_conv2d_x3_ok: 1 if the form
+ * exists for the call (3x3, stride 1, W % 128 == 0, full 128-row tiles, DMA-addressable tensors; DF_CONV_X3=0 disables). */
+int df_conv2d_x3(df_img x, const void* w3, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
+                 const float* scale, const float* shift, float* stats_partial, int accumulate, void* stream);
+int df_conv2d_x3_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
+int df_split_bf16x3(const float* w, void* out3, int64_t n, void* stream);
 int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);

@@ -971,3 +971,55 @@ def test_wgrad_bf16_tr_kernel(dev, cin, cout, n, h, w):
     want = wref.grad.permute(0, 2, 3, 1)
     check("tr wgrad dW", dw, want.float(), 2e-5)
     check("tr wgrad bias", db, dy.float().cpu().sum((0, 1, 2)), 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 2, 40, 128), (128, 128, 1, 72, 128), (256, 256, 1, 66, 128), (64, 64, 1, 36, 256),
+                                            (128, 64, 2, 33, 128)])
+@pytest.mark.parametrize("mode", ["fwd_bias", "fwd_stats", "dgrad", "dgrad_acc"])
+def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
+    """df_conv2d_x3 (conv_halo_x3_kernel): the fp32 3x3 convolution computed on the bf16 matrix pipe from three bf16 planes per
+    operand must be an FP32-accurate convolution: against F.conv2d in float64 on the same fp32 inputs, error <= 2e-6 of the
+    largest output (the fp32-MFMA kernel measures ~5e-7 on these shapes; both are printed) -- forward with bias / with the
+    BatchNorm statistics epilogue, data gradient with and without accumulation; odd heights, several k chunks, image borders."""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call
+    g = torch.Generator().manual_seed(cin * 3 + h)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    w_ohwi = ops.ohwi(wt.to(dev).contiguous(memory_format=torch.channels_last))
+    if mode.startswith("fwd"):
+        x = torch.randn(n, h, w, cin, generator=g)
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+        wk, bk, conv_mode = w_ohwi, bias.to(dev), ops.CONV_FWD
+        epi = ops.EPI_STATS if mode == "fwd_stats" else ops.EPI_BIAS
+    else:
+        x = torch.randn(n, h, w, cout, generator=g)
+        want = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), padding=1).permute(0, 2, 3, 1)
+        wk, bk, conv_mode, epi = ops.weight_transpose(w_ohwi), None, ops.CONV_DGRAD, ops.EPI_BIAS
+    oc = want.shape[3]
+    xd = x.to(dev)
+    outs = {}
+    for form in ("x3", "fp32"):
+        monkeypatch.setenv("DF_CONV_X3_TEST", form)
+        y = torch.zeros(n, h, w, oc, device=dev)
+        base = None
+        if mode == "dgrad_acc":
+            base = torch.randn(n, h, w, oc, generator=torch.Generator().manual_seed(5))
+            y.copy_(base.to(dev))
+        rows = n * h * w
+        partial = torch.zeros(rows // ops.conv_tile_m(rows, oc), oc, 2, device=dev) if epi == ops.EPI_STATS else None
+        if form == "x3":
+            assert call("df_conv2d_x3_ok", img(xd), img(y), 3, 1, conv_mode, epi) == 1
+            ops.conv2d(img(xd), wk, bk, img(y), 3, 1, mode=conv_mode, epi=epi, stats=partial, accumulate=mode == "dgrad_acc")
+        else:
+            call("df_conv2d", img(xd), ops.ptr(wk), ops.ptr(bk), img(y), 3, 1, 1, conv_mode, epi, None, None, ops.ptr(partial),
+                 int(mode == "dgrad_acc"), ops.stream())
+        torch.cuda.synchronize()
+        ref = want + (base.double() if base is not None else 0.0)
+        outs[form] = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        if partial is not None and form == "x3":
+            check("x3 stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
+            check("x3 stats sumsq", partial.sum(0).cpu()[:, 1], (ref.reshape(-1, oc) ** 2).sum(0).float(), 2e-5)
+    print(f"[parity] conv x3 {mode} {cin}->{cout} @{h}x{w}x{n}: bf16x3 err {outs['x3']:.2e} | fp32-MFMA err {outs['fp32']:.2e} (vs float64)")
+    assert outs["x3"] <= 2e-6, outs
