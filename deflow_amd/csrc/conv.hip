@@ -2092,6 +2092,245 @@ __global__ __launch_bounds__(768) void wgrad3_tr_kernel(WgradParams p) {
 #endif
 }
 
+// ---- fp32-ACCURATE 3x3 stride-1 weight gradient on the bf16 matrix pipe (bf16x3, df_conv2d_wgrad_x3) ---------------------
+// The weight-gradient twin of conv_halo_x3_kernel: x and dy are fp32 in memory; every staged element is split once into three
+// bf16 planes (hi + mid + lo == the fp32 value) on its way global -> registers -> LDS, the planes are laid out as the
+// transposing-read image of wgrad3_tr_kernel ([plane][half][pixel][32 ch], 64-byte pixel rows), and each 8-deep operand pair
+// is multiplied as six exact bf16 products -- 36 MFMAs per wave and 32-pixel stage, dW to fp32 rounding at 16 / 6 of the fp32
+// MFMA rate.  12 waves = (32 co x 32 ci quadrant) x kernel row; two LDS stages of 3 x 17 KB (one workgroup per CU); the next
+// stage's elements are fetched into registers while the current stage is multiplied.
+__global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 32, XW = P + 2, LC = 64;
+  constexpr int YB = 2 * P * 64;                        // dY image bytes of one plane: [2 halves][32 px][64 B]
+  constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows x 34 px][64 B]
+  constexpr int PLB = YB + 2 * XH;                      // one plane of a stage (17152 B)
+  constexpr int STG = 3 * PLB;                          // stage bytes (51456)
+  constexpr int NYS = YB / 16, NXS = 2 * XH / 16;       // 16-byte slots: 256 + 816
+  constexpr int NIT = (NYS + NXS + 767) / 768;          // items per thread (2)
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int quad = wave & 3, ky = wave >> 2;
+  const int wci = quad & 1, wco = quad >> 1;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {   // all (ci, co) tiles of a split on one XCD: they read the same x / dy tiles (see wgrad3_ring_kernel)
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * LC, co0 = by * LC;
+  const bool do_bias = p.bias_ws && bx == 0;
+  float bsum = 0.f;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+
+  // staging items: item e of a thread = 16-byte slot (tid + 768 e) of a plane image: slots 0 .. 255 = dY ([half][px][4]), the
+  // rest = X ([half][row][xi][4]); the source is 8 consecutive fp32 channels (two 16-byte loads)
+  unsigned loff[NIT];     // lane-constant source byte offset relative to the stage's row / segment base
+  int lpx[NIT], lqy[NIT]; // dY: pixel (lqy = -100); X: column offset xi - 1, row offset qy - 1 (off: never in range)
+  int ldst[NIT];          // destination byte inside a plane
+#pragma unroll
+  for (int e = 0; e < NIT; ++e) {
+    const int t = tid + 768 * e;
+    if (t < NYS) {
+      const int h = t >> 7, px = (t & 127) >> 2, q = t & 3;
+      lpx[e] = px;
+      lqy[e] = -100;
+      loff[e] = (unsigned)((px * p.dy.ld + co0 + 32 * h + 8 * q) * 4);
+      ldst[e] = 16 * t;
+    } else {
+      const int sx = t - NYS;
+      const int h = sx / (3 * XW * 4), r = (sx - h * 3 * XW * 4) >> 2, q = sx & 3;
+      const int qy = r / XW, xi = r - qy * XW;
+      const bool on = sx < NXS && (ci0 + 32 * h + 8 * q) < p.K;
+      lpx[e] = xi - 1;
+      lqy[e] = on ? qy - 1 : (1 << 28);
+      loff[e] = (unsigned)((((qy - 1) * wx + xi - 1) * p.x.ld + ci0 + 32 * h + 8 * q) * 4);
+      ldst[e] = sx < NXS ? YB + 16 * sx : -1;
+    }
+  }
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wx * p.x.ld) * 4);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 4), xrow_step = (unsigned)(wx * p.x.ld * 4);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 4), xseg_step = (unsigned)(P * p.x.ld * 4);
+  f32x4 ra[NIT][2];
+  auto fetch = [&]() {          // the cursor's chunk -> registers, then advance the cursor
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      unsigned v;
+      if (lqy[e] == -100) {
+        v = (ox0 + lpx[e] < wy) ? ybase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v + 16, 0, 0));
+      } else {
+        const bool ok = (unsigned)(cur_oy + lqy[e]) < (unsigned)hx && (unsigned)(ox0 + lpx[e]) < (unsigned)wx;
+        v = ok ? xbase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, 0, 0));
+      }
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {
+        cur_oy = 0;
+        ++cur_n;
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
+      }
+    }
+  };
+  auto stash = [&](int buf) {   // registers -> hi / mid / lo planes -> LDS
+    char* st = ldsb + buf * STG;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      if (ldst[e] >= 0) {
+        float v[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        bf16x8_t hi, mi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { hi[k] = (__bf16)v[k]; r[k] = v[k] - (float)hi[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mi[k] = (__bf16)r[k]; r[k] = r[k] - (float)mi[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo[k] = (__bf16)r[k];
+        char* d = st + ldst[e];
+        *reinterpret_cast<bf16x8_t*>(d) = hi;
+        *reinterpret_cast<bf16x8_t*>(d + PLB) = mi;
+        *reinterpret_cast<bf16x8_t*>(d + 2 * PLB) = lo;
+      }
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+  const int tr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // (see wgrad3_tr_kernel)
+  const unsigned a_base = lds0 + wco * (P * 64) + (8 * kh) * 64 + tr_lane;
+  const unsigned b_base = lds0 + YB + wci * XH + (ky * XW + 8 * kh) * 64 + tr_lane;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto op8 = [](u32x2_t lo, u32x2_t hi) -> bf16x8_t {
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  if (nst > 0) {
+    fetch();
+    stash(0);
+  }
+  __syncthreads();
+  for (int i = 0; i < nst; ++i) {
+    if (i + 1 < nst) fetch();
+    const unsigned so = (unsigned)((i & 1) * STG);
+#pragma unroll
+    for (int ks = 0; ks < P / 16; ++ks) {
+      const unsigned aa = a_base + so + ks * 16 * 64, ba = b_base + so + ks * 16 * 64;
+      // dY operand: three planes x (pixels +0..3, +4..7); plane stride PLB = 17152 bytes (immediate offsets)
+      u32x2_t ahl, ahh, aml, amh, all_, alh;
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %6\n\t"
+          "ds_read_b64_tr_b16 %1, %6 offset:256\n\t"
+          "ds_read_b64_tr_b16 %2, %6 offset:17152\n\t"
+          "ds_read_b64_tr_b16 %3, %6 offset:17408\n\t"
+          "ds_read_b64_tr_b16 %4, %6 offset:34304\n\t"
+          "ds_read_b64_tr_b16 %5, %6 offset:34560\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(ahl), "=&v"(ahh), "=&v"(aml), "=&v"(amh), "=&v"(all_), "=&v"(alh)
+          : "v"(aa)
+          : "memory");
+      const bf16x8_t ah = op8(ahl, ahh), am = op8(aml, amh), al = op8(all_, alh);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        u32x2_t bhl, bhh, bml, bmh, bll, blh;
+        const unsigned bb = ba + kx * 64;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %6\n\t"
+            "ds_read_b64_tr_b16 %1, %6 offset:256\n\t"
+            "ds_read_b64_tr_b16 %2, %6 offset:17152\n\t"
+            "ds_read_b64_tr_b16 %3, %6 offset:17408\n\t"
+            "ds_read_b64_tr_b16 %4, %6 offset:34304\n\t"
+            "ds_read_b64_tr_b16 %5, %6 offset:34560\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(bhl), "=&v"(bhh), "=&v"(bml), "=&v"(bmh), "=&v"(bll), "=&v"(blh)
+            : "v"(bb)
+            : "memory");
+        const bf16x8_t bh = op8(bhl, bhh), bm = op8(bml, bmh), bl = op8(bll, blh);
+        f32x16 c = acc[kx];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // small terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        acc[kx] = c;
+      }
+    }
+    if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6: the exact fp32 values are hi + mid + lo
+      const char* stp = ldsb + (i & 1) * STG;
+      const int c = tid & 63;
+#pragma unroll
+      for (int j = 0; j < P / 8; ++j) {
+        const int el = (c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31);
+        float v = 0.f;
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+          v += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(stp + pl * PLB)[el] << 16);
+        bsum += v;
+      }
+    }
+    if (i + 1 < nst) stash((i + 1) & 1);    // ring slot (i + 1) & 1 was last read in stage i - 1, behind the previous barrier
+    __syncthreads();
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (tid < 512) red[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[64 * w + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t;
+    }
+  }
+  if ((ci0 + wci * 32) < p.K) {
+    float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = acc[kx][e];
+      }
+  }
+#endif
+}
+
 template <int CIT>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2595,6 +2834,40 @@ extern "C" int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, in
   }
   DF_CHECK_LAUNCH();
   return DF_OK;
+}
+
+// fp32-accurate 3x3 stride-1 weight gradient through three bf16 planes per operand (wgrad3_x3_kernel): fp32 x and dy, splits /
+// workspace / reduce as df_conv2d_wgrad_mp.  DF_WGRAD_X3=0 switches it off (df_conv2d_wgrad_x3_ok -> 0).
+extern "C" int df_conv2d_wgrad_x3_ok(df_img x, df_img dy, int ksize, int stride) {
+  static const int on = getenv("DF_WGRAD_X3") ? atoi(getenv("DF_WGRAD_X3")) : 1;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  return on && ksize == 3 && stride == 1 && x.elt == 0 && dy.elt == 0 && img_ok(x) && img_ok(dy) && x.n == dy.n && x.h == dy.h &&
+         x.w == dy.w && (x.c % 32) == 0 && (dy.c % 64) == 0 && (dy.w % 32) == 0 && x.img_stride >= 0 && dy.img_stride >= 0 &&
+         x.grp_off >= 0 && dy.grp_off >= 0 && extent(x) < (int64_t)DMA_BAD && extent(dy) < (int64_t)DMA_BAD;
+}
+
+extern "C" int df_conv2d_wgrad_x3(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws,
+                                  void* stream) {
+  DF_REQUIRE(ws && df_aligned16(ws) && pad == 1 && df_conv2d_wgrad_x3_ok(x, dy, ksize, stride) == 1, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
+  p.stride = 1; p.pad = 1; p.K = x.c; p.N = dy.c;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  p.x_bytes = (unsigned)extent(x);
+  p.dy_bytes = (unsigned)extent(dy);
+  p.chunks_per_row = dy.w / 32;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
+  return launch_wgrad_dma(wgrad3_x3_kernel, grid, 2 * 3 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
 }
 
 // bf16-STORAGE training: 3x3 stride-1 weight gradient of bfloat16 x and dy (wgrad3_tr_kernel); splits / workspace / reduce as

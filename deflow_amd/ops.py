@@ -376,14 +376,18 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         e0.record()
     bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
     t16 = bool(x.elt and dy.elt)
+    x3 = (not t16 and not MFMA_BF16 and ks == 3 and stride == 1 and row_counts is None
+          and call("df_conv2d_wgrad_x3_ok", x, dy, ks, stride) == 1)
     if t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
+    elif x3:     # fp32 mode: fp32-accurate product from three bf16 planes per operand (wgrad3_x3_kernel)
+        call("df_conv2d_wgrad_x3", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     else:
         call("df_conv2d_wgrad_mp", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(row_counts), rows_per_seg, ptr(bias_ws),
              int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = ("wgrad3_tr_kernel<4>" if t16 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"

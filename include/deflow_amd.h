@@ -262,6 +262,12 @@ int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, int pad, floa
                        const int32_t* row_counts, int rows_per_seg, float* bias_ws, int mfma_bf16, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
+/* fp32-ACCURATE 3x3 stride-1 weight gradient on the bf16 matrix pipe (round 3, "bf16x3", the twin of df_conv2d_x3): fp32 x and
+ * dy, each staged element split into three bf16 planes, six exact products per operand pair, transposing LDS reads, fp32
+ * accumulation and split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce as df_conv2d_wgrad_mp.  _ok: 1 if the form
+ * exists for the call (3x3, stride 1, W % 32 == 0, DMA-addressable tensors).  [REF decoder.py:205,213] weight gradient. */
+int df_conv2d_wgrad_x3(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws, void* stream);
+int df_conv2d_wgrad_x3_ok(df_img x, df_img dy, int ksize, int stride);
 /* bf16-STORAGE training (round 3): the 3x3 stride-1 weight gradient of BFLOAT16 x and dy (df_img.elt = 1 on both; W % 32 == 0):
  * bf16 tiles by LDS-DMA into a four-deep ring, fragments by transposing LDS reads (ds_read_b64_tr_b16), fp32 accumulation and
  * fp32 split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce exactly as df_conv2d_wgrad_mp.  Replaces the weight

@@ -1023,3 +1023,31 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
             check("x3 stats sumsq", partial.sum(0).cpu()[:, 1], (ref.reshape(-1, oc) ** 2).sum(0).float(), 2e-5)
     print(f"[parity] conv x3 {mode} {cin}->{cout} @{h}x{w}x{n}: bf16x3 err {outs['x3']:.2e} | fp32-MFMA err {outs['fp32']:.2e} (vs float64)")
     assert outs["x3"] <= 2e-6, outs
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
+def test_wgrad_x3_fp32_accurate(dev, cin, cout, n, h, w):
+    """df_conv2d_wgrad_x3 (wgrad3_x3_kernel): the fp32 weight gradient from three bf16 planes per operand against float64 on the
+    same fp32 inputs: <= 2e-6 of the largest entry (the fp32-MFMA ring kernel's own error is printed beside it); bias sums too."""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call, ptr, stream
+    g = torch.Generator().manual_seed(cin * 11 + w)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    dy = torch.randn(n, h, w, cout, generator=g).to(dev)
+    assert call("df_conv2d_wgrad_x3_ok", img(x), img(dy), 3, 1) == 1
+    dw = torch.empty(cout, 3, 3, cin, device=dev)
+    db = ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw, want_bias=True)          # fp32 mode -> the x3 kernel
+    splits = call("df_conv2d_wgrad_splits", img(x), img(dy), 3, 1)
+    ws = torch.empty(splits * cout * 9 * cin, device=dev)
+    call("df_conv2d_wgrad_mp", img(x), img(dy), 3, 1, 1, ptr(ws), splits, None, 0, None, 0, stream())   # the fp32-MFMA ring kernel
+    dw_ring = torch.empty_like(dw)
+    call("df_conv2d_wgrad_reduce", ptr(ws), splits, cout, 9, cin, ptr(dw_ring), 9 * cin, 0, stream())
+    torch.cuda.synchronize()
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wref, padding=1).backward(dy.cpu().permute(0, 3, 1, 2).double())
+    want = wref.grad.permute(0, 2, 3, 1)
+    e3, er = rel_err(dw, want), rel_err(dw_ring, want)
+    print(f"[parity] wgrad x3 {cin}->{cout} @{h}x{w}x{n}: bf16x3 err {e3:.2e} | fp32-MFMA ring err {er:.2e} (vs float64)")
+    assert e3 <= 2e-6, (e3, er)
+    check("x3 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)

@@ -34,3 +34,15 @@ for cin, cout, n, h in [(128, 128, 32, 128), (256, 128, 16, 256), (128, 128, 16,
     tx3 = timeit(lambda: call("df_conv2d_x3", img(x), ptr(w3), ptr(b), img(y), 3, 1, 1, 0, 0, None, None, None, 0, stream())) if ok else float("nan")
     print(f"{cin:3d}->{cout:3d} @{h}^2 x{n:2d} {gf:7.1f} GF | fp32 MFMA {t32:8.1f} us {gf / t32 * 1e3:6.0f} TF | bf16x3 {tx3:8.1f} us {gf / tx3 * 1e3:6.0f} TF-equivalent"
           f" | {t32 / tx3:.2f}x", flush=True)
+
+print("weight gradients:")
+for cin, cout, n, h in [(128, 128, 32, 128), (256, 128, 16, 256), (128, 128, 16, 256), (512, 256, 16, 128), (256, 256, 16, 128),
+                        (64, 64, 32, 256), (128, 64, 16, 512), (64, 64, 16, 512), (256, 256, 32, 64)]:
+    x = torch.randn(n, h, h, cin, device=dev); dy = torch.randn(n, h, h, cout, device=dev)
+    gf = 2.0 * n * h * h * 9 * cin * cout / 1e9
+    splits = call("df_conv2d_wgrad_splits", img(x), img(dy), 3, 1)
+    ws = torch.empty(splits * cout * 9 * cin, device=dev)
+    t32 = timeit(lambda: call("df_conv2d_wgrad_mp", img(x), img(dy), 3, 1, 1, ptr(ws), splits, None, 0, None, 0, stream()))
+    tx3 = timeit(lambda: call("df_conv2d_wgrad_x3", img(x), img(dy), 3, 1, 1, ptr(ws), splits, None, stream()))
+    print(f"{cin:3d}->{cout:3d} @{h}^2 x{n:2d} {gf:7.1f} GF | fp32 ring {t32:8.1f} us {gf / t32 * 1e3:6.0f} TF | bf16x3 {tx3:8.1f} us {gf / tx3 * 1e3:6.0f} TF-equivalent"
+          f" | {t32 / tx3:.2f}x  (splits {splits})", flush=True)
