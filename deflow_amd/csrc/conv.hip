@@ -62,6 +62,7 @@ struct ConvParams {
   unsigned y_bytes;                   // extent of y in bytes if it fits 32-bit buffer offsets (branch-free epilogue), else 0
   int dbg;  // ablation switch (env DF_CONV_DBG): 1 = no global loads after the prologue, 2 = also no LDS stores
   int bf16; // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
+  int stats_mul;  // statistics rows per tile (1; 2 when a 256-row tile fills the partial table sized for 128-row tiles: the second is 0)
 };
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
@@ -225,9 +226,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         s1 += red[(w * BN + tid) * 2 + 0];
         s2 += red[(w * BN + tid) * 2 + 1];
       }
-      float* o = p.stats + ((int64_t)tile_m * p.N + n0 + tid) * 2;
+      float* o = p.stats + ((int64_t)tile_m * p.stats_mul * p.N + n0 + tid) * 2;
       o[0] = s1;
       o[1] = s2;
+      for (int r = 1; r < p.stats_mul; ++r) {
+        o[(int64_t)r * p.N * 2] = 0.f;
+        o[(int64_t)r * p.N * 2 + 1] = 0.f;
+      }
     }
   }
 }
@@ -966,17 +971,21 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 // cycles per wave -- and the weight tiles run through a DB-deep LDS ring with COUNTED vmcnt (DB - 1 stages = ~2 us of
 // prefetch), the halo is fetched a whole group (three stages) ahead.  LDS: A [2][3 planes][132][64 B] = 50 KB + B
 // [DB][3][BN][64 B] = 96 KB: one 8-wave workgroup per CU.
-template <int BN, int WM, int WN, int DB>
+// BM = 128, SEG = 1: the tile is 128 pixels of one image row (W % 128 == 0); BM = 128, SEG = 2: two whole rows of a W == 64
+// image (halo 2 x 66); BM = 256, SEG = 1: 256 pixels of one row (W % 256 == 0) -- the form of the 64-output-channel layers, whose
+// 128 x 64 tile had 32 x 32 wave tiles (12 MFMAs per 12 fragment reads); with 256 rows the wave tile is 64 x 32 again.
+template <int BM, int BN, int WM, int WN, int SEG, int DB>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 128, HR = 132, SW = BM + 2;
+  constexpr int SW = BM / SEG + 2;                     // halo pixels per segment
+  constexpr int HR = (SEG * SW + 3) / 4 * 4;           // halo rows (130 / 132 / 258 used)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NW = WM * WN, NT = 64 * NW;
-  constexpr int NIT = (SW * 4 + NT - 1) / NT;          // A staging items (one 16-byte bf16 slot = 8 floats) per thread
+  constexpr int NIT = (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte bf16 slot = 8 floats) per thread
   constexpr int AP = HR * LDH, AB = 3 * AP;            // A plane / buffer (floats)
   constexpr int BP = BN * LDH, BSL = 3 * BP;           // B plane / ring slot (floats)
   constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
-  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3, "8 waves");
+  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || (BM == 256 && SEG == 1)), "8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                      // [2][3][HR][LDH]
   float* Bs = lds + 2 * AB;             // [DB][3][BN][LDH]
@@ -999,19 +1008,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
       (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   // A staging (as conv_halo_w16_kernel): item e = LDS slot (tid + e NT): halo row j = slot >> 2, physical 16-byte slot tid & 3
-  // holding k = 8 (s ^ ((j >> 2) & 3)) .. + 7 of the chunk.  EVERY thread issues every item's two loads (out-of-range items read
-  // zeros from an out-of-range offset): the counted vmcnt waits below need the same number of operations in every wave.
+  // holding k = 8 (s ^ ((j >> 2) & 3)) .. + 7 of the chunk.  Halo row j = segment sg, pixel j - sg SW: input pixel
+  // (oy + sg - 1 + ty, ox0 - 1 + j - sg SW).  EVERY thread issues every item's two loads (out-of-range items read zeros from an
+  // out-of-range offset): the counted vmcnt waits below need the same number of operations in every wave.
   const int aslot = tid & 3;
   unsigned aoff[NIT];
+  int aseg[NIT];
   bool aon[NIT];
 #pragma unroll
   for (int e = 0; e < NIT; ++e) {
     const int j = (tid + e * NT) >> 2;
-    const int ix = ox0 - 1 + j;
-    aon[e] = j < SW;
+    const int sg = SEG == 1 ? 0 : j / SW;
+    const int ix = ox0 - 1 + j - sg * SW;
+    aon[e] = j < SEG * SW;
+    aseg[e] = sg;
     const int sl = aslot ^ ((j >> 2) & 3);
     aoff[e] = (aon[e] && ix >= 0 && ix < wx)
-                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
   }
   // weight DMA: a wave moves 16 rows x 64 B of one plane per instruction; plane pl sits pl * N * 9 * K elements further.
   // BN = 64: waves 4 .. 7 repeat the rows of waves 0 .. 3 (same data to the same place) so that EVERY wave issues exactly three
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   auto fetch_a = [&]() {                              // the next group's halo -> registers, then advance the group cursor
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
-      const unsigned v = (unsigned)(oy - 1 + ty_next) < (unsigned)hx ? aoff[e] : DMA_BAD;
+      const unsigned v = (unsigned)(oy + aseg[e] - 1 + ty_next) < (unsigned)hx ? aoff[e] : DMA_BAD;
       ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, sa_next, 0));
       ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, sa_next, 0));
     }
@@ -1115,13 +1128,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     const float* b0 = Bs + cur_slot * BSL + (wn * TN * 32 + li) * LDH;
     if (++cur_slot == DB) cur_slot = 0;
     const float* a = a0 + tx * LDH;
-    const int sa = ((li + tx) >> 2) & 3, sb = (li >> 2) & 3;
+    const int sb = (li >> 2) & 3;
 #pragma unroll
     for (int q = 0; q < BK / 16; ++q) {
       bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float* ap = a + i * 32 * LDH + (((2 * q + kh) ^ sa) * 4);
+        // output rows of block i sit 2 halo rows further per completed segment (SEG = 2: blocks 2, 3 of the tile)
+        const int sh = SEG == 1 ? 0 : 2 * ((wm * TM + i) * 32 / (BM / SEG));
+        const int sa = ((li + tx + sh) >> 2) & 3;
+        const float* ap = a + (i * 32 + sh) * LDH + (((2 * q + kh) ^ sa) * 4);
         ah[i] = *reinterpret_cast<const bf16x8_t*>(ap);
         am[i] = *reinterpret_cast<const bf16x8_t*>(ap + AP);
         al[i] = *reinterpret_cast<const bf16x8_t*>(ap + 2 * AP);
@@ -1203,11 +1219,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #endif
 }
 
-template <int BN, int WM, int WN, int DB>
+template <int BM, int BN, int WM, int WN, int SEG, int DB>
 static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
-  const size_t lds_bytes = (size_t)(2 * 3 * 132 + DB * 3 * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BN, WM, WN, DB>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_x3_kernel<BN, WM, WN, DB>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  constexpr int HR = (SEG * (BM / SEG + 2) + 3) / 4 * 4;
+  const size_t lds_bytes = (size_t)(2 * 3 * HR + DB * 3 * BN) * LDH * sizeof(float);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -2598,6 +2615,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
   p.bf16 = mfma_bf16 != 0;
+  p.stats_mul = 1;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -2649,15 +2667,25 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   static const int use_halo = getenv("DF_CONV_HALO") ? atoi(getenv("DF_CONV_HALO")) : 1;
   const bool halo_ok = use_halo && p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && (y.w % 128) == 0 &&
                        x.w == y.w && x.h == y.h && (var == 128128 || var == 128064);
-  if (w3) {    // df_conv2d_x3: fp32-accurate product from three bf16 planes per operand (W % 128 == 0 forms only)
-    const bool ok = halo_ok && (p.K % BK) == 0 && x.elt == 0 && y.elt == 0;
+  if (w3) {    // df_conv2d_x3: fp32-accurate product from three bf16 planes per operand (W % 128 == 0, or W == 64 as row pairs)
+    const bool two = p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && y.w == 64 && (y.h % 2) == 0 && x.w == y.w &&
+                     x.h == y.h && (var == 128128 || var == 128064);
+    const bool ok = (halo_ok || two) && (p.K % BK) == 0 && x.elt == 0 && y.elt == 0;
     if (query) return ok ? 1 : 0;
     DF_REQUIRE(ok, DF_E_SHAPE);
     p.w = reinterpret_cast<const float*>(w3);
     p.w_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2 * 3);
     p.bf16 = 0;
-    if (var == 128128) return launch_conv_halo_x3<128, 2, 4, 4>(p, s);
-    return launch_conv_halo_x3<64, 4, 2, 8>(p, s);
+    if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8>(p, s);
+    if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4>(p, s);
+    // 64 output channels: 256-pixel row tiles where the image allows (wave tile 64 x 32 instead of 32 x 32)
+    static const int bm256 = getenv("DF_CONV_X3_BM256") ? atoi(getenv("DF_CONV_X3_BM256")) : 1;
+    if (bm256 && (y.w % 256) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0)) {
+      p.tiles_m = (int)(M / 256);
+      p.stats_mul = 2;
+      return launch_conv_halo_x3<256, 64, 4, 2, 1, 4>(p, s);
+    }
+    return launch_conv_halo_x3<128, 64, 4, 2, 1, 8>(p, s);
   }
   if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed forms exist (W % 128 == 0, or W == 64 as row pairs)
     const bool two = p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && y.w == 64 && (y.h % 2) == 0 && x.w == y.w &&

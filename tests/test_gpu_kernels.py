@@ -974,7 +974,9 @@ def test_wgrad_bf16_tr_kernel(dev, cin, cout, n, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 2, 40, 128), (128, 128, 1, 72, 128), (256, 256, 1, 66, 128), (64, 64, 1, 36, 256),
-                                            (128, 64, 2, 33, 128)])
+                                            (128, 64, 2, 33, 128),                      # 128-pixel row tiles (64-wide: W % 256 != 0)
+                                            (128, 64, 1, 20, 512), (64, 64, 2, 18, 256),  # 256-pixel row tiles of the 64-channel layers
+                                            (256, 256, 4, 36, 64), (64, 64, 4, 36, 64)])  # W == 64: two image rows per tile
 @pytest.mark.parametrize("mode", ["fwd_bias", "fwd_stats", "dgrad", "dgrad_acc"])
 def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
     """df_conv2d_x3 (conv_halo_x3_kernel): the fp32 3x3 convolution computed on the bf16 matrix pipe from three bf16 planes per
