@@ -209,9 +209,13 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
         name = _conv_variant(x, y, ks, stride, mode, epi)
-        if x3:
+        if x3:   # mirrors conv2d_impl's dispatch of the bf16x3 forms (BM, BN, WM, WN, SEG, DB)
             bn = 128 if y.c % 128 == 0 else 64
-            name = f"conv_halo_x3_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2}>"
+            seg = 1 if y.w % 128 == 0 else 2
+            m_rows, rpg = y.n * y.h * y.w, y.grp_size * y.h * y.w
+            bm = 256 if (bn == 64 and seg == 1 and y.w % 256 == 0 and m_rows % 256 == 0 and (epi != EPI_STATS or rpg % 256 == 0)
+                         and os.environ.get("DF_CONV_X3_BM256", "1") != "0") else 128
+            name = f"conv_halo_x3_kernel<{bm},{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{seg},{4 if (bn == 128 or bm == 256) else 8}>"
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"
