@@ -207,7 +207,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
-        tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n}"
+        tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n} {'fb'[x.elt]}{'fb'[y.elt]}"
         name = _conv_variant(x, y, ks, stride, mode, epi)
         if x3:   # mirrors conv2d_impl's dispatch of the bf16x3 forms (BM, BN, WM, WN, SEG, DB)
             bn = 128 if y.c % 128 == 0 else 64
@@ -394,7 +394,7 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         name = ("wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
-        tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n}"
+        tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fb'[x.elt]}{'fb'[dy.elt]}"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())

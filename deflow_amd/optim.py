@@ -394,16 +394,12 @@ class Trainer:
             if kind == "graph":
                 op[1].replay()
             elif kind == "allreduce":
-                if os.environ.get("DF_DEBUG_SYNC") == "1":
-                    torch.cuda.synchronize()
                 for lo, hi in op[1]:
                     works.append(self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
             else:   # "wait": the optimizer segment follows
                 for w in works:
                     w.wait()
                 works.clear()
-                if os.environ.get("DF_DEBUG_SYNC") == "2":
-                    torch.cuda.synchronize()
         self.opt.step_count += 1
         ops.PARAM_GEN[0] += 1
         return self._graph_loss

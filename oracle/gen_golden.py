@@ -129,8 +129,8 @@ def main():
     d.update({"gw." + k: p.grad for k, p in gru.named_parameters()})
     np.savez_compressed(os.path.join(OUT, "g1_convgru.npz"), **_np(d))
 
-    # ---- G2 ConvGRUDecoder (iters 1,4,8; duplicate cells; N_b in {0,1,333}) --------------
-    for iters in (1, 4, 8):
+    # ---- G2 ConvGRUDecoder (iters 1,4,8 and 16 = the fastflow3d-ablation / 1_train.sh:50 setting; duplicate cells; N_b in {0,1,333})
+    for iters in (1, 4, 8, 16):
         torch.manual_seed(200 + iters)
         dec = R.ConvGRUDecoder(num_iters=iters)
         Hh = Ww = 16

@@ -63,7 +63,7 @@ def cwn_twin(R, path):
 def main():
     torch.set_num_threads(1)
     R = _load_ref_decoder()
-    for it in (1, 4, 8):
+    for it in (1, 4, 8, 16):
         p = os.path.join(OUT, f"g2_grudecoder_it{it}.npz")
         np.savez_compressed(p.replace(".npz", "_f64.npz"), **decoder_twin(R, p, R.ConvGRUDecoder, num_iters=it))
     p = os.path.join(OUT, "g3_lineardecoder.npz")

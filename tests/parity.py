@@ -36,6 +36,7 @@ def record(test: str, name: str, **kw):
     try:
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
         with open(REPORT, "a") as f:
+            kw = {k: (v.item() if hasattr(v, "item") else v) for k, v in kw.items()}      # numpy / torch scalars
             f.write(json.dumps({"test": test, "tensor": name, **kw}) + "\n")
     except OSError:
         pass

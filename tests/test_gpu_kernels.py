@@ -118,10 +118,12 @@ def test_conv_dgrad_wgrad(dev, cin, cout, k, s, n, h, w):
 # 12-wave ring weight gradient, the 1x1 weight-gradient tiles -- reached directly here, not only through the model tests,
 # so that the DF_CONV_HALO / DF_CONV_W8 / DF_WGRAD_RING legs of test_alternate_kernel_paths switch something
 BIG_CONV_CASES = [  # cin, cout, k, stride, n, h, w, forward kernel, dgrad kernel, wgrad kernel (default switches)
-    (128, 128, 3, 1, 2, 64, 128, "conv_halo_kernel<128,2,4>", "conv_halo_kernel<128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
-    (64, 64, 3, 1, 2, 32, 256, "conv_halo_kernel<64,4,2>", "conv_halo_kernel<64,4,2>", "wgrad3_ring_kernel<32,2,1>"),
-    (128, 64, 3, 1, 2, 64, 128, "conv_halo_kernel<64,4,2>", "conv_halo_kernel<128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
-    (256, 128, 3, 1, 3, 64, 64, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad3_ring_kernel<32,2,1>"),
+    # 3x3 stride 1: the fp32-accurate bf16x3 forms since round 3 (DF_CONV_X3=0 / DF_WGRAD_X3=0 legs of the alternate-path matrix
+    # run the fp32-MFMA kernels conv_halo_kernel / conv_dma_kernel / wgrad3_ring_kernel through the same comparisons)
+    (128, 128, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,128,2,4,1,4>", "conv_halo_x3_kernel<128,128,2,4,1,4>", "wgrad3_x3_kernel"),
+    (64, 64, 3, 1, 2, 32, 256, "conv_halo_x3_kernel<256,64,4,2,1,4>", "conv_halo_x3_kernel<256,64,4,2,1,4>", "wgrad3_x3_kernel"),
+    (128, 64, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,64,4,2,1,8>", "conv_halo_x3_kernel<128,128,2,4,1,4>", "wgrad3_x3_kernel"),
+    (256, 128, 3, 1, 3, 64, 64, "conv_halo_x3_kernel<128,128,2,4,2,4>", "conv_halo_x3_kernel<128,128,2,4,2,4>", "wgrad3_x3_kernel"),
     (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1x1_kernel<128>"),
     (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad3_ring_kernel<16,2,2>"),
 ]
@@ -659,7 +661,7 @@ def _load_head(cls, g, dev, **kw):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("iters", [1, 4, 8])
+@pytest.mark.parametrize("iters", [1, 4, 8, 16])       # 16: [REF assets/slurm/1_train.sh:50] (model.target.num_iters=16 ablation)
 def test_gru_decoder_golden(dev, golden_dir, iters):
     """REAL reference vectors: ConvGRUDecoder forward + all gradients ([REF decoder.py:141-199]).  Each tensor is measured
     against the reference executed in float64 on the same weights / inputs (oracle/gen_golden_f64.py) and must satisfy

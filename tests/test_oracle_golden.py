@@ -46,7 +46,7 @@ def test_g1_convgru(golden_dir):
         _close(p.grad, g["gw." + k], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("iters", [1, 4, 8])
+@pytest.mark.parametrize("iters", [1, 4, 8, 16])
 def test_g2_grudecoder(golden_dir, iters):
     g = _load(golden_dir, f"g2_grudecoder_it{iters}.npz")
     m = O.ConvGRUDecoder(num_iters=int(g["num_iters"]))
@@ -194,7 +194,7 @@ def test_scatter_max_restatement_selects_first_maximal_point():
             assert hit.tolist() == [first], (p, c)
 
 
-@pytest.mark.parametrize("iters", [1, 4, 8])
+@pytest.mark.parametrize("iters", [1, 4, 8, 16])
 def test_f64_twins_pin_the_oracle_in_double(golden_dir, iters):
     """tests/golden/*_f64.npz = the REAL reference classes executed in float64 (oracle/gen_golden_f64.py).  The oracle in
     double must reproduce them to round-off -- this pins the fp64 yardstick the GPU tests measure both fp32 sides against."""
