@@ -40,22 +40,15 @@ P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> argtypes (restype int unless listed in _RESTYPE)
 _SIGS = {
     "df_version": [],
-    "df_pillar_keys": [P, I, I, DfGeom, P, P, P],
-    "df_pillar_scan": [P, I, I, P, P, P],
-    "df_pillar_compact": [P, P, P, I, I, DfGeom, P, P, P, P, P, P],
-    "df_pillar_sort_ws_bytes": [L],
-    "df_pillar_sort": [P, P, P, L, I, P, L, P],
-    "df_pillar_gather_sorted": [P, P, P, L, L, P, P],
-    "df_pillar_cells": [P, L, L, P, P],
     "df_pillar2_rows_per_band": [I, I],
     "df_pillar2_tile": [],
     "df_pillar2_hist": [P, I, I, DfGeom, I, P, P],
     "df_pillar2_scan": [P, I, I, I, P, P, P, P],
     "df_pillar2_scatter": [P, I, I, DfGeom, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_pillar2_band": [P, P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P],
-    "df_pfn_stats": [P, P, P, P, I, DfGeom, P, P, I, P],
+    "df_cell_sort_ws_bytes": [L],
+    "df_cell_sort": [P, L, L, P, P, P, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
-    "df_pfn_canvas": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, I, P],
     "df_pfn_bwd_stats": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, P, I, P],
     "df_pfn_bwd_finalize": [P, I, I, P, P, P, I, P, P],
     "df_pfn_bwd_weights": [P, P, P, P, I, DfGeom, P, P, I, I, P, DfImg, P, I, P],
@@ -117,8 +110,8 @@ _SIGS = {
     "df_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
     "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
-_RESTYPE = {"df_pillar_sort_ws_bytes": C.c_int64}
-_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_pillar_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
+_RESTYPE = {"df_cell_sort_ws_bytes": C.c_int64}
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

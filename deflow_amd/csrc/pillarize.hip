@@ -1,138 +1,19 @@
-// Dynamic pillar featurisation: the MI355X replacement for mmcv's dynamic_voxelize +
-// dynamic_point_to_voxel (scatter) CUDA ops and the DynamicPillarFeatureNet / PointPillarsScatter
-// modules behind DynamicEmbedder ([REF deflow.py:27-30,82-83]; sources live in the absent
-// OpenSceneFlow submodule -- the algorithm restated here is documented in oracle/ref_torch.py).
-//
-// Formulation (no float atomics, deterministic):
-//   keys      per point: IEEE fp32 floor-divide voxel coords -> cell key b*H*W + y*W + x   (integer, bit-exact)
-//   compact   stable order-preserving compaction of the kept points (ballot/popcount ranks + block offsets)
-//   sort      stable LSD radix sort of (key, point index): a pillar's points become one contiguous run,
-//             ascending original index inside the run
-//   cells     dense [start, end) table per BEV cell from the sorted keys
-//   canvas    GATHER form of the scatter: 8 lanes own one cell, walk its run, compute the 9-d feature,
-//             Linear(9->32) + BN1d + ReLU, reduce, and write the cell's 32 floats (zeros for empty cells);
-//             every canvas byte is written exactly once, 128 B per cell, fully coalesced.
-// The canvas write (32*H*W*4 B per cloud) is >95 % of the stage's HBM bytes.
+// Pillar feature net, BACKWARD side, and the sparse-edge kernels of the UNet.  The forward pillariser (voxelise, sort, feature
+// net, canvas) is csrc/pillar_bands.hip; the first-generation forward kernels that lived here (keys / scan / compact / library
+// radix sort / gather / cells / stats / canvas) were retired in round 3 together with the rocPRIM dependency.  What is here:
+//   pfn_bn_finalize / running     per-sample BatchNorm1d statistics of the feature net from the band kernel's partials
+//   pfn_bwd_stats / finalize / weights   backward of Linear(9->32) + BN1d + ReLU + per-pillar mean|max over the sorted runs
+//   pillar_input_grad, sparse_in_wgrad, sparse_conv3x3, sparse_wgrad3x3   the UNet's first / last convolutions evaluated at
+//                                 occupied pillars only (the canvas is >90 % zeros; the decoder reads pc0's cells only)
+//   cell sort                     counting sort of caller-supplied cell keys for the stand-alone decoder head (pack_infos)
+// ([REF deflow.py:27-30,82-83]; the mmcv / OpenSceneFlow sources are absent -- the algorithm is restated in oracle/ref_torch.py.)
+// No float atomics anywhere: every sum has one fixed order.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 #include "pillar_common.h"
 
 namespace {
-
-__global__ __launch_bounds__(256) void pillar_keys_kernel(const float* __restrict__ pts, int N, df_pillar_geom g,
-                                                          uint32_t invalid_key, uint32_t* __restrict__ key,
-                                                          int32_t* __restrict__ blk_cnt) {
-  __shared__ int wcnt[4];
-  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-  bool valid = false;
-  if (n < N) {
-    const float* p = pts + ((int64_t)b * N + n) * 3;
-    int cx = 0, cy = 0;
-    valid = voxelize(g, p[0], p[1], p[2], cx, cy);
-    key[(int64_t)b * N + n] = valid ? (uint32_t)((b * g.gy + cy) * g.gx + cx) : invalid_key;
-  }
-  const unsigned long long bal = __ballot(valid);
-  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) blk_cnt[b * gridDim.x + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-}
-
-__global__ __launch_bounds__(256) void pillar_scan_kernel(const int32_t* __restrict__ blk_cnt, int nblk,
-                                                          int32_t* __restrict__ blk_off, int32_t* __restrict__ counts) {
-  __shared__ int buf[256];
-  const int b = blockIdx.x, t = threadIdx.x;
-  int carry = 0;
-  for (int base = 0; base < nblk; base += 256) {
-    const int i = base + t;
-    const int v = i < nblk ? blk_cnt[b * nblk + i] : 0;
-    buf[t] = v;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
-      const int add = t >= d ? buf[t - d] : 0;
-      __syncthreads();
-      buf[t] += add;
-      __syncthreads();
-    }
-    if (i < nblk) blk_off[b * nblk + i] = carry + buf[t] - v;
-    const int tot = buf[255];
-    __syncthreads();
-    carry += tot;
-  }
-  if (t == 0) counts[b] = carry;
-}
-
-__global__ __launch_bounds__(256) void pillar_compact_kernel(const float* __restrict__ pts,
-                                                             const uint32_t* __restrict__ key,
-                                                             const int32_t* __restrict__ blk_off, int N,
-                                                             df_pillar_geom g, uint32_t invalid_key,
-                                                             float* __restrict__ points_c, int32_t* __restrict__ coords_c,
-                                                             int64_t* __restrict__ idx_c, float* __restrict__ offs_c,
-                                                             int32_t* __restrict__ cpos) {
-  __shared__ int wcnt[4];
-  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t k = invalid_key;
-  if (n < N) k = key[(int64_t)b * N + n];
-  const bool valid = k != invalid_key;
-  const unsigned long long bal = __ballot(valid);
-  if (lane == 0) wcnt[wave] = __popcll(bal);
-  __syncthreads();
-  int rank = __popcll(bal & ((1ull << lane) - 1ull));
-  for (int w = 0; w < wave; ++w) rank += wcnt[w];
-  if (n >= N) return;
-  if (!valid) {
-    cpos[(int64_t)b * N + n] = -1;
-    return;
-  }
-  const int pos = blk_off[b * gridDim.x + blockIdx.x] + rank;
-  const int cell = (int)(k - (uint32_t)b * (uint32_t)(g.gx * g.gy));
-  const int cy = cell / g.gx, cx = cell - cy * g.gx;
-  const float* p = pts + ((int64_t)b * N + n) * 3;
-  const float px = p[0], py = p[1], pz = p[2];
-  const int64_t o = (int64_t)b * N + pos;
-  points_c[o * 3 + 0] = px;
-  points_c[o * 3 + 1] = py;
-  points_c[o * 3 + 2] = pz;
-  coords_c[o * 3 + 0] = 0;
-  coords_c[o * 3 + 1] = cy;
-  coords_c[o * 3 + 2] = cx;
-  idx_c[o] = n;
-  // centre = c * vs + min + vs / 2, three roundings, no contraction (DynamicVoxelizer._get_point_offsets)
-  const float ctx = __fadd_rn(__fadd_rn(__fmul_rn((float)cx, g.vx), g.minx), g.vx * 0.5f);
-  const float cty = __fadd_rn(__fadd_rn(__fmul_rn((float)cy, g.vy), g.miny), g.vy * 0.5f);
-  const float ctz = __fadd_rn(__fadd_rn(0.f, g.minz), g.vz * 0.5f);
-  offs_c[o * 3 + 0] = __fsub_rn(px, ctx);
-  offs_c[o * 3 + 1] = __fsub_rn(py, cty);
-  offs_c[o * 3 + 2] = __fsub_rn(pz, ctz);
-  cpos[(int64_t)b * N + n] = pos;
-}
-
-__global__ void iota_kernel(uint32_t* p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
-}
-
-__global__ void pillar_gather_sorted_kernel(const float* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
-                                            const uint32_t* __restrict__ key_sorted, uint32_t invalid_key, int64_t n,
-                                            float* __restrict__ pts_sorted) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || key_sorted[i] >= invalid_key) return;  // dropped points sort to the tail and are never read
-  const float* p = pts + (int64_t)idx_sorted[i] * 3;
-  float* o = pts_sorted + i * 3;
-  o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
-}
-
-__global__ void pillar_cells_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t ncells,
-                                    int32_t* __restrict__ cell_rng) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t k = key[i];
-  if (k >= ncells) return;
-  if (i == 0 || key[i - 1] != k) cell_rng[2 * (int64_t)k] = (int32_t)i;
-  if (i == n - 1 || key[i + 1] != k) cell_rng[2 * (int64_t)k + 1] = (int32_t)(i + 1);
-}
 
 constexpr int CELLS_PER_BLOCK = 32;
 
@@ -161,48 +42,6 @@ __device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*
     for (int gi = 1; gi < CELLS_PER_BLOCK; ++gi)
 #pragma unroll
       for (int k = 0; k < NV; ++k) v[k] += lds[k * 256 + gi * 8 + sub];
-  }
-}
-
-__global__ __launch_bounds__(256) void pfn_stats_kernel(const float* __restrict__ pts,
-                                                        const int32_t* __restrict__ cell_rng,
-    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
-                                                        const float* __restrict__ w_pfn, float* __restrict__ partial) {
-  __shared__ float lds[256 * 8];
-  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int ncell = g.gx * g.gy;
-  PfnCtx c;
-  pfn_load_w(c, w_pfn, sub);
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const SampleRange sr = sample_range(counts, b);
-  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
-    const uint32_t key = key_sorted[i0];
-    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
-    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
-    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
-    if (e <= s) continue;
-    float mx, my, mz, ctx, cty, ctz;
-    pfn_mean(pts, s, e, mx, my, mz);
-    pfn_centre(g, cell, ctx, cty, ctz);
-    for (int i = s; i < e; ++i) {
-      float f[9], u[4];
-      pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
-      pfn_linear(c, f, u);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        acc[k] += u[k];
-        acc[4 + k] += u[k] * u[k];
-      }
-    }
-  }
-  reduce_groups<8>(acc, lds);
-  if (threadIdx.x < 8) {
-    float* o = partial + (((int64_t)b * gridDim.x + blockIdx.x) * 32 + 4 * sub) * 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      o[k * 2 + 0] = acc[k];
-      o[k * 2 + 1] = acc[4 + k];
-    }
   }
 }
 
@@ -263,50 +102,6 @@ __global__ void pfn_bn_running_kernel(const float* __restrict__ partial, int B, 
   }
   running_mean[c] = (float)rm;
   running_var[c] = (float)rv;
-}
-
-__global__ __launch_bounds__(256) void pfn_canvas_kernel(const float* __restrict__ pts,
-                                                         const int32_t* __restrict__ cell_rng,
-    const uint32_t* __restrict__ key_sorted, const int32_t* __restrict__ counts, df_pillar_geom g,
-                                                         const float* __restrict__ w_pfn,
-                                                         const float* __restrict__ bn_ss, int bn_sample_stride,
-                                                         int mode, df_img out) {
-  const int b = blockIdx.y, sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int ncell = g.gx * g.gy;
-  PfnCtx c;
-  pfn_load_w(c, w_pfn, sub);
-  pfn_load_bn(c, bn_ss + (int64_t)b * bn_sample_stride, sub);
-  float* __restrict__ op = reinterpret_cast<float*>(out.ptr) + df_img_base(out, b);
-  const SampleRange sr = sample_range(counts, b);
-  for (int i0 = sr.off + blockIdx.x * CELLS_PER_BLOCK + grp; i0 < sr.off + sr.cnt; i0 += gridDim.x * CELLS_PER_BLOCK) {
-    const uint32_t key = key_sorted[i0];
-    if (i0 > sr.off && key_sorted[i0 - 1] == key) continue;  // not a pillar head
-    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
-    const int s = i0, e = cell_rng[2 * (int64_t)key + 1];
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    {
-      float mx, my, mz, ctx, cty, ctz;
-      pfn_mean(pts, s, e, mx, my, mz);
-      pfn_centre(g, cell, ctx, cty, ctz);
-      for (int i = s; i < e; ++i) {
-        float f[9], u[4];
-        pfn_feat(pts + (int64_t)i * 3, mx, my, mz, ctx, cty, ctz, f);
-        pfn_linear(c, f, u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float v = fmaxf(fmaf(u[k], c.sc[k], c.sh[k]), 0.f);
-          if (mode == 0) r[k] += v;
-          else r[k] = (i == s) ? v : fmaxf(r[k], v);
-        }
-      }
-      if (mode == 0) {
-        const float cnt = (float)(e - s);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = r[k] / cnt;
-      }
-    }
-    st4(op + (int64_t)cell * out.ld + 4 * sub, r);
-  }
 }
 
 // backward pass A: per-sample sums of (g_hat, g_hat * xhat) where g_hat = dL/d(BN output) after the ReLU mask
@@ -892,90 +687,136 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
       for (int r = 0; r < 4; ++r) o[((16 * ct + 4 * lq + r) * 9 + tap) * 32 + 16 * nt + li] = acc[ct][nt][r];
 }
 
+// ---------------------------------------------------------------------------- cell sort -------------
+// Counting sort of arbitrary cell keys (the stand-alone decoder-head call, decoder.pack_infos: voxel coordinates handed in by
+// the caller, not produced by the pillariser): idx_sorted = the indices i of the keys < ncells grouped by key, ASCENDING i
+// inside a group (= a stable sort, so the gather-backward's per-cell sums have one fixed order), cell_rng[k] = [start, end).
+//   hist     cell_rng[k].end   = number of keys equal to k          (integer atomics: order-independent)
+//   offsets  cell_rng[k].start = cell_rng[k].end = exclusive prefix  (2048 cells per workgroup + one pass over the block sums)
+//   scatter  idx[cell_rng[k].end++] = i                              (arrival order inside a group ...)
+//   order    insertion sort of each group with more than one member  (... made ascending: the result is deterministic)
+constexpr int CS_CHUNK = 2048;
+
+__global__ void cell_hist_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t ncells, int32_t* __restrict__ cell_rng) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  if (k < ncells) atomicAdd(&cell_rng[2 * (int64_t)k + 1], 1);
+}
+
+// exclusive scan of one int per thread across a 256-thread workgroup; returns the prefix, *total = the workgroup's sum
+__device__ __forceinline__ int block_excl_scan256(int v, int* lds /*[256]*/, int* total) {
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int a = t >= d ? lds[t - d] : 0;
+    __syncthreads();
+    lds[t] += a;
+    __syncthreads();
+  }
+  const int incl = lds[t];
+  *total = lds[255];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ __launch_bounds__(256) void cell_blocksum_kernel(const int32_t* __restrict__ cell_rng, int64_t ncells,
+                                                            int32_t* __restrict__ blk_sum) {
+  __shared__ int lds[256];
+  const int64_t c0 = (int64_t)blockIdx.x * CS_CHUNK + threadIdx.x * 8;
+  int v = 0;
+  for (int j = 0; j < 8; ++j)
+    if (c0 + j < ncells) v += cell_rng[2 * (c0 + j) + 1];
+  int total;
+  block_excl_scan256(v, lds, &total);
+  if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void cell_blockscan_kernel(int32_t* __restrict__ blk_sum, int nb) {
+  __shared__ int lds[256];
+  int carry = 0;
+  for (int base = 0; base < nb; base += 256) {      // one workgroup walks the block sums (nb <= ncells / 2048)
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? blk_sum[i] : 0;
+    int total;
+    const int ex = block_excl_scan256(v, lds, &total);
+    if (i < nb) blk_sum[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(256) void cell_offsets_kernel(int32_t* __restrict__ cell_rng, int64_t ncells,
+                                                           const int32_t* __restrict__ blk_off) {
+  __shared__ int lds[256];
+  const int64_t c0 = (int64_t)blockIdx.x * CS_CHUNK + threadIdx.x * 8;
+  int cnt[8], v = 0;
+  for (int j = 0; j < 8; ++j) {
+    cnt[j] = c0 + j < ncells ? cell_rng[2 * (c0 + j) + 1] : 0;
+    v += cnt[j];
+  }
+  int total;
+  int off = blk_off[blockIdx.x] + block_excl_scan256(v, lds, &total);
+  for (int j = 0; j < 8; ++j) {
+    if (c0 + j < ncells) {
+      cell_rng[2 * (c0 + j)] = off;
+      cell_rng[2 * (c0 + j) + 1] = off;       // the scatter's fill cursor; back at `end` when it is done
+    }
+    off += cnt[j];
+  }
+}
+
+__global__ void cell_scatter_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t ncells, int32_t* __restrict__ cell_rng,
+                                    uint32_t* __restrict__ idx_sorted) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  if (k < ncells) idx_sorted[atomicAdd(&cell_rng[2 * (int64_t)k + 1], 1)] = (uint32_t)i;
+}
+
+__global__ void cell_order_kernel(const int32_t* __restrict__ cell_rng, int64_t ncells, uint32_t* __restrict__ idx_sorted) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const int s = cell_rng[2 * c], e = cell_rng[2 * c + 1];
+  for (int i = s + 1; i < e; ++i) {
+    const uint32_t v = idx_sorted[i];
+    int j = i - 1;
+    while (j >= s && idx_sorted[j] > v) {
+      idx_sorted[j + 1] = idx_sorted[j];
+      --j;
+    }
+    idx_sorted[j + 1] = v;
+  }
+}
+
 }  // namespace
 
-extern "C" int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt,
-                              void* stream) {
-  DF_REQUIRE(pts && key && blk_cnt && B > 0 && N > 0, DF_E_ARG);
-  DF_REQUIRE(geom_ok(g) && (int64_t)B * g.gx * g.gy < 0x7fffffffll && (int64_t)B * N < 0x7fffffffll, DF_E_SHAPE);
-  const uint32_t invalid = (uint32_t)((int64_t)B * g.gx * g.gy);
-  hipLaunchKernelGGL(pillar_keys_kernel, dim3((N + 255) / 256, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     pts, N, g, invalid, key, blk_cnt);
-  DF_CHECK_LAUNCH();
-  return DF_OK;
+extern "C" int64_t df_cell_sort_ws_bytes(int64_t ncells) {
+  return ((ncells + CS_CHUNK - 1) / CS_CHUNK) * (int64_t)sizeof(int32_t);
 }
 
-extern "C" int df_pillar_scan(const int32_t* blk_cnt, int B, int nblk, int32_t* blk_off, int32_t* counts,
-                              void* stream) {
-  DF_REQUIRE(blk_cnt && blk_off && counts && B > 0 && nblk > 0, DF_E_ARG);
-  hipLaunchKernelGGL(pillar_scan_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), blk_cnt, nblk,
-                     blk_off, counts);
-  DF_CHECK_LAUNCH();
-  return DF_OK;
-}
-
-extern "C" int df_pillar_compact(const float* pts, const uint32_t* key, const int32_t* blk_off, int B, int N,
-                                 df_pillar_geom g, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
-                                 int32_t* cpos, void* stream) {
-  DF_REQUIRE(pts && key && blk_off && points_c && coords_c && idx_c && offs_c && cpos, DF_E_ARG);
-  DF_REQUIRE(geom_ok(g), DF_E_SHAPE);
-  const uint32_t invalid = (uint32_t)((int64_t)B * g.gx * g.gy);
-  hipLaunchKernelGGL(pillar_compact_kernel, dim3((N + 255) / 256, B), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), pts, key, blk_off, N, g, invalid, points_c, coords_c, idx_c,
-                     offs_c, cpos);
-  DF_CHECK_LAUNCH();
-  return DF_OK;
-}
-
-static size_t sort_temp_bytes(int64_t n, int bits) {
-  size_t bytes = 0;
-  rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t*, uint32_t*, const uint32_t*, uint32_t*>(
-      nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, bits, 0, false);
-  return bytes;
-}
-
-extern "C" int64_t df_pillar_sort_ws_bytes(int64_t n) {
-  const size_t iota = ((size_t)n * 4 + 255) & ~(size_t)255;
-  return (int64_t)(iota + sort_temp_bytes(n, 32) + 256);
-}
-
-extern "C" int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_t* idx_out, int64_t n, int key_bits,
-                              void* ws, int64_t ws_bytes, void* stream) {
-  DF_REQUIRE(key_in && key_out && idx_out && ws && n > 0 && key_bits > 0 && key_bits <= 32, DF_E_ARG);
-  const size_t iota = ((size_t)n * 4 + 255) & ~(size_t)255;
-  size_t temp = sort_temp_bytes(n, key_bits);
-  DF_REQUIRE((int64_t)(iota + temp) <= ws_bytes, DF_E_WORKSPACE);
+// idx_sorted [n] u32, cell_rng [ncells][2] i32 (both fully written here), ws >= df_cell_sort_ws_bytes(ncells).
+// Keys >= ncells are dropped (the caller's "invalid" sentinel).  Replaces the library radix sort of rounds 1-2.
+extern "C" int df_cell_sort(const uint32_t* key, int64_t n, int64_t ncells, uint32_t* idx_sorted, int32_t* cell_rng, void* ws,
+                            void* stream) {
+  DF_REQUIRE(key && idx_sorted && cell_rng && ws && n > 0 && ncells > 0 && ncells < 0x3fffffffll && n < 0x7fffffffll, DF_E_ARG);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  uint32_t* idx_in = reinterpret_cast<uint32_t*>(ws);
-  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx_in, n);
+  const int nb = (int)((ncells + CS_CHUNK - 1) / CS_CHUNK);
+  int32_t* blk = reinterpret_cast<int32_t*>(ws);
+  hipError_t e = hipMemsetAsync(cell_rng, 0, (size_t)ncells * 2 * sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  const dim3 pts_grid((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(cell_hist_kernel, pts_grid, dim3(256), 0, s, key, n, (uint32_t)ncells, cell_rng);
   DF_CHECK_LAUNCH();
-  hipError_t e = rocprim::radix_sort_pairs(reinterpret_cast<char*>(ws) + iota, temp, key_in, key_out,
-                                           (const uint32_t*)idx_in, idx_out, (size_t)n, 0u, (unsigned)key_bits, s, false);
-  return (int)e;
-}
-
-extern "C" int df_pillar_gather_sorted(const float* pts, const uint32_t* idx_sorted, const uint32_t* key_sorted,
-                                       int64_t n, int64_t ncells, float* pts_sorted, void* stream) {
-  DF_REQUIRE(pts && idx_sorted && key_sorted && pts_sorted && n > 0 && ncells > 0 && ncells < 0x7fffffffll, DF_E_ARG);
-  hipLaunchKernelGGL(pillar_gather_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), pts, idx_sorted, key_sorted, (uint32_t)ncells, n, pts_sorted);
+  hipLaunchKernelGGL(cell_blocksum_kernel, dim3(nb), dim3(256), 0, s, cell_rng, ncells, blk);
   DF_CHECK_LAUNCH();
-  return DF_OK;
-}
-
-extern "C" int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream) {
-  DF_REQUIRE(key_sorted && cell_rng && n > 0 && ncells > 0 && ncells < 0x7fffffffll, DF_E_ARG);
-  hipLaunchKernelGGL(pillar_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), key_sorted, n, (uint32_t)ncells, cell_rng);
+  hipLaunchKernelGGL(cell_blockscan_kernel, dim3(1), dim3(256), 0, s, blk, nb);
   DF_CHECK_LAUNCH();
-  return DF_OK;
-}
-
-extern "C" int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
-    const int32_t* counts, int B,
-                            df_pillar_geom g, const float* w_pfn, float* partial, int nblk_stat, void* stream) {
-  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && partial && B > 0 && nblk_stat > 0 && geom_ok(g), DF_E_ARG);
-  hipLaunchKernelGGL(pfn_stats_kernel, dim3(nblk_stat, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, partial);
+  hipLaunchKernelGGL(cell_offsets_kernel, dim3(nb), dim3(256), 0, s, cell_rng, ncells, blk);
+  DF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cell_scatter_kernel, pts_grid, dim3(256), 0, s, key, n, (uint32_t)ncells, cell_rng, idx_sorted);
+  DF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cell_order_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, s, cell_rng, ncells, idx_sorted);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -992,19 +833,6 @@ extern "C" int df_pfn_bn_finalize(float* partial, int B, int nblk_stat, const in
                        running_var);
     DF_CHECK_LAUNCH();
   }
-  return DF_OK;
-}
-
-extern "C" int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
-    const int32_t* counts, int B,
-                             df_pillar_geom g, const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode,
-                             df_img out, int nblk, void* stream) {
-  DF_REQUIRE(pts_sorted && cell_rng && key_sorted && counts && w_pfn && bn_ss && out.ptr && B > 0 && nblk > 0 && geom_ok(g), DF_E_ARG);
-  DF_REQUIRE(out.n == B && out.h == g.gy && out.w == g.gx && out.c == 32 && (out.ld % 4) == 0 && df_aligned16(out.ptr),
-             DF_E_SHAPE);
-  DF_REQUIRE(mode == 0 || mode == 1, DF_E_ARG);
-  hipLaunchKernelGGL(pfn_canvas_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts_sorted, cell_rng, key_sorted, counts, g, w_pfn, bn_ss, bn_sample_stride, mode, out);
-  DF_CHECK_LAUNCH();
   return DF_OK;
 }
 

@@ -58,14 +58,11 @@ def pack_infos(infos: List[Dict[str, torch.Tensor]], H: int, W: int, device, nee
         key = bidx * (H * W) + coords[..., 1].long() * W + coords[..., 2].long()
         valid = torch.arange(N, device=device)[None, :] < counts[:, None]
         key = torch.where(valid, key, torch.full_like(key, ncells)).to(torch.int32).reshape(-1).contiguous()
-        key_sorted = torch.empty_like(key)
         idx_sorted = torch.empty_like(key)
-        ws_bytes = call("df_pillar_sort_ws_bytes", B * N)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        call("df_pillar_sort", ptr(key), ptr(key_sorted), ptr(idx_sorted), B * N, max(1, int(ncells).bit_length()),
-             ptr(ws), ws_bytes, stream())
-        cell_rng = torch.zeros(ncells, 2, dtype=torch.int32, device=device)
-        call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), stream())
+        cell_rng = torch.empty(ncells, 2, dtype=torch.int32, device=device)
+        ws = torch.empty(call("df_cell_sort_ws_bytes", ncells), dtype=torch.uint8, device=device)
+        # stable counting sort by cell (csrc/pillarize.hip): a cell's points become one run, ascending index inside it
+        call("df_cell_sort", ptr(key), B * N, ncells, ptr(idx_sorted), ptr(cell_rng), ptr(ws), stream())
         ps.idx_sorted, ps.cell_rng = idx_sorted, cell_rng
         ps.cpos = torch.arange(N, device=device, dtype=torch.int32).repeat(B).contiguous()
     return ps

@@ -18,10 +18,7 @@ from ._lib import DfGeom, DfImg, call, img, ptr, stream
 
 
 def canvas_alloc(*shape, device) -> torch.Tensor:
-    """canvas buffer for pillarize(): the band pipeline writes every byte itself; the first generation (DF_PILLAR_V1=1) writes
-    occupied cells only and needs the zero fill"""
-    if os.environ.get("DF_PILLAR_V1") == "1":
-        return torch.zeros(*shape, dtype=torch.float32, device=device)
+    """canvas buffer for pillarize(): the band pipeline writes every byte itself (zeros included), so no fill here"""
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
@@ -107,8 +104,6 @@ class DynamicEmbedder(nn.Module):
         B, N, _ = pts.shape
         # algorithmic traffic of the stage: the points once in, the dense 32-channel canvas once out
         with ops.timed("pillarise_fwd", bytes=B * (N * 12.0 + 32.0 * self.H * self.W * 4.0), tag=f"B={B} N={N}"):
-            if os.environ.get("DF_PILLAR_V1") == "1":
-                return self._pillarize_v1(pts, out, train)
             return self._pillarize(pts, out, train, need_cells)
 
     def _bn_state(self, train: bool, partial, counts, B: int, nbs: int, dev):
@@ -182,52 +177,6 @@ class DynamicEmbedder(nn.Module):
                  self.mode, out, ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), ptr(cell_rng), None, s)
         return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss,
                            bn_stride)
-
-    def _pillarize_v1(self, pts: torch.Tensor, out: DfImg, train: bool) -> PillarState:
-        """First generation (csrc/pillarize.hip; DF_PILLAR_V1=1, tested alternate): keys -> scan -> compact -> library radix sort
-        -> gather -> cell table -> (statistics) -> canvas over occupied pillars of a canvas zeroed here."""
-        assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
-        B, N, _ = pts.shape
-        dev, g, s = pts.device, self.geom, stream()
-        H, W = self.H, self.W
-        # this generation writes occupied cells only: the caller allocates the canvas with canvas_alloc() (zero-filled)
-        nblk = (N + 255) // 256
-        i32 = dict(dtype=torch.int32, device=dev)
-        key = torch.empty(B * N, **i32)
-        blk_cnt = torch.empty(B, nblk, **i32)
-        blk_off = torch.empty(B, nblk, **i32)
-        counts = torch.empty(B, **i32)
-        call("df_pillar_keys", ptr(pts), B, N, g, ptr(key), ptr(blk_cnt), s)
-        call("df_pillar_scan", ptr(blk_cnt), B, nblk, ptr(blk_off), ptr(counts), s)
-        points_c = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
-        coords_c = torch.empty(B, N, 3, **i32)
-        idx_c = torch.empty(B, N, dtype=torch.int64, device=dev)
-        offs_c = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
-        cpos = torch.empty(B * N, **i32)
-        call("df_pillar_compact", ptr(pts), ptr(key), ptr(blk_off), B, N, g, ptr(points_c), ptr(coords_c), ptr(idx_c),
-             ptr(offs_c), ptr(cpos), s)
-        key_sorted = torch.empty(B * N, **i32)
-        idx_sorted = torch.empty(B * N, **i32)
-        ws_bytes = call("df_pillar_sort_ws_bytes", B * N)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        ncells = B * H * W
-        call("df_pillar_sort", ptr(key), ptr(key_sorted), ptr(idx_sorted), B * N, max(1, int(ncells).bit_length()),
-             ptr(ws), ws_bytes, s)
-        pts_sorted = torch.empty(B * N, 3, dtype=torch.float32, device=dev)
-        call("df_pillar_gather_sorted", ptr(pts), ptr(idx_sorted), ptr(key_sorted), B * N, ncells, ptr(pts_sorted), s)
-        cell_rng = torch.zeros(ncells, 2, **i32)
-        call("df_pillar_cells", ptr(key_sorted), B * N, ncells, ptr(cell_rng), s)
-        w = self._lin.weight.detach()
-        partial = None
-        nbs = max(1, min(256, (N + 31) // 32))
-        if train:
-            partial = torch.empty(B, nbs, 32, 2, dtype=torch.float32, device=dev)
-            call("df_pfn_stats", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(partial), nbs, s)
-        bn_ss, bn_stride = self._bn_state(train, partial, counts, B, nbs, dev)
-        nbc = max(1, min(2048, (N + 31) // 32))
-        call("df_pfn_canvas", ptr(pts_sorted), ptr(cell_rng), ptr(key_sorted), ptr(counts), B, g, ptr(w), ptr(bn_ss), bn_stride, self.mode,
-             out, nbc, s)
-        return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss, bn_stride)
 
     def _sync_bn_stats(self, partial: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
         """sync_bn form of df_pfn_bn_finalize: per-sample statistics (the feature net is called once per sample) over the

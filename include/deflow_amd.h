@@ -58,7 +58,7 @@ typedef struct df_pillar_geom {
  * 1024-point tiles (hist -> scan -> scatter) and each band's workgroup finishes the sort by cell in LDS, runs the feature
  * net and writes its slice of the canvas -- zeros included, every byte once; no separate zero-fill, no library sort.
  * S = number of cloud samples in this call (B, or 2B when both clouds are pillarised together), NB = ceil(gy / R),
- * nblk = ceil(N / df_pillar2_tile()).  Sorted layout = first generation: sample s owns sorted positions
+ * nblk = ceil(N / df_pillar2_tile()).  Sorted layout: sample s owns sorted positions
  * [sum counts[0..s), + counts[s]), ascending cell key, input order inside a cell; positions past the last valid point are
  * not written. */
 int df_pillar2_rows_per_band(int H, int W);   /* 0 if the grid is not supported (W > 2048) */
@@ -68,7 +68,7 @@ int df_pillar2_hist(const float* pts, int S, int N, df_pillar_geom g, int rows_p
 /* off (shape of hist): exclusive scan over the tiles of every (sample, column); tot [S, NB+1]; counts [S] = valid points */
 int df_pillar2_scan(const int32_t* hist, int S, int ncol, int nblk, int32_t* off, int32_t* tot, int32_t* counts,
                     void* stream);
-/* order-preserving compaction (shapes as df_pillar_compact) + bucketed key [S*N] u32 / flat index [S*N] u32 / xyz [S*N,3] */
+/* order-preserving compaction (points_c [S,N,3] f32, coords_c [S,N,3] i32 (z,y,x), idx_c [S,N] i64, offs_c [S,N,3] f32, cpos [S*N] i32 = compact position of each original point or -1; rows >= counts[s] untouched) + bucketed key [S*N] u32 / flat index [S*N] u32 / xyz [S*N,3] */
 int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom g, int rows_per_band, const int32_t* off,
                        const int32_t* tot, float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c,
                        int32_t* cpos, uint32_t* bkey, uint32_t* bidx, float* bpts, int32_t* bucket0 /* [S, NB] out */,
@@ -83,47 +83,25 @@ int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float*
                     int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted, uint32_t* idx_sorted,
                     float* pts_sorted, int32_t* cell_rng, float* stats_partial, void* stream);
 
-/* ---- first generation (csrc/pillarize.hip): kept for the stand-alone decoder-head API (arbitrary voxel_coords) and as
- * the tested alternate DF_PILLAR_V1=1.
- * step 1: per point voxel coords / validity / sort key; per-256-point-block valid counts.
- * pts [B,N,3] f32 (NaN rows = padding).  key [B*N] u32 = b*gy*gx + y*gx + x, or B*gy*gx if dropped.
- * blk_cnt [B, ceil(N/256)] i32. */
-int df_pillar_keys(const float* pts, int B, int N, df_pillar_geom g, uint32_t* key, int32_t* blk_cnt, void* stream);
-/* step 2: per-sample exclusive scan of blk_cnt -> blk_off (same shape), counts[b] = M_b. */
-int df_pillar_scan(const int32_t* blk_cnt, int B, int nblk, int32_t* blk_off, int32_t* counts, void* stream);
-/* step 3: stable compaction in original order.  Outputs are padded [B,N,...]; rows >= M_b untouched.
- * points_c [B,N,3] f32, coords_c [B,N,3] i32 (z,y,x), idx_c [B,N] i64, offs_c [B,N,3] f32,
- * cpos [B*N] i32 = compact position of each original point (or -1). */
-int df_pillar_compact(const float* pts, const uint32_t* key, const int32_t* blk_off, int B, int N, df_pillar_geom g,
-                      float* points_c, int32_t* coords_c, int64_t* idx_c, float* offs_c, int32_t* cpos, void* stream);
-/* step 4: stable sort of (key, original flat index b*N+n) by key.  ws: df_pillar_sort_ws_bytes(n). */
-int64_t df_pillar_sort_ws_bytes(int64_t n);
-int df_pillar_sort(const uint32_t* key_in, uint32_t* key_out, uint32_t* idx_out, int64_t n, int key_bits,
-                   void* ws, int64_t ws_bytes, void* stream);
-/* step 4b: points gathered into sorted order, pts_sorted[i] = pts[idx_sorted[i]] (rows of dropped points untouched):
- * the feature-net passes then read one contiguous run per pillar instead of chasing indices. */
-int df_pillar_gather_sorted(const float* pts, const uint32_t* idx_sorted, const uint32_t* key_sorted, int64_t n,
-                            int64_t ncells, float* pts_sorted, void* stream);
-/* step 5: dense per-cell [start,end) table from the sorted keys.  cell_rng [B*gy*gx, 2] i32 must be zeroed. */
-int df_pillar_cells(const uint32_t* key_sorted, int64_t n, int64_t ncells, int32_t* cell_rng, void* stream);
-/* step 6 (training): BatchNorm1d batch statistics of u = W f per sample.  partial [B, nblk_stat, 32, 2] f32 */
-int df_pfn_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
-    const int32_t* counts, int B, df_pillar_geom g,
-                 const float* w_pfn /*[32,9]*/, float* partial, int nblk_stat, void* stream);
-/* finalize: per-sample scale/shift/mean/invstd from the partials, sequential running-stat update (one
- * update per sample, as the reference calls feature_net once per sample).
+/* (the first-generation forward entry points df_pillar_keys / _scan / _compact / _sort / _gather_sorted / _cells, df_pfn_stats
+ * and df_pfn_canvas -- a library radix sort and separate kernels over a zero-filled canvas -- were retired in round 3: the band
+ * pipeline above is the only pillariser; its tests compare it with the oracle directly.)
+ * finalize (training): per-sample scale/shift/mean/invstd of the feature net's BatchNorm1d from the band kernel's statistics
+ * partials (flag 2), sequential running-stat update (one update per sample, as the reference calls feature_net once per sample).
  * counts [B] i32 valid points; bn_ss [B,4,32] f32 = scale, shift, mean, invstd. */
 int df_pfn_bn_finalize(float* partial /* clobbered: slot 0 of every sample is reused as scratch */, int B, int nblk_stat, const int32_t* counts, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                        float* bn_ss, void* stream);
-/* step 7: canvas.  `out` (n=B images, c=32) must be ZERO-FILLED by the caller (a streaming memset); this writes the
- * occupied cells only: the pillar mean (mode 0) / max (mode 1) of ReLU(BN(W f)).  All pfn kernels iterate over occupied
- * pillars (heads of the sorted key runs of sample b = sorted positions [sum counts[0..b), +counts[b])), not over cells.  bn_sample_stride = 128 (per-sample stats) or 0 (shared: eval). */
-int df_pfn_canvas(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,
-    const int32_t* counts, int B, df_pillar_geom g,
-                  const float* w_pfn, const float* bn_ss, int bn_sample_stride, int mode, df_img out, int nblk,
-                  void* stream);
-/* backward; mode as df_pfn_canvas (0 'avg': every point of a pillar gets g / count; 1 'max': per channel the pillar's
+/* Stable counting sort of caller-supplied cell keys (the stand-alone decoder-head call takes arbitrary voxel_coords
+ * [REF decoder.py:185-199], not the pillariser's): idx_sorted [n] u32 = indices of the keys < ncells grouped by key, ascending
+ * index inside a group (entries past the number of such keys are not written); cell_rng [ncells, 2] i32 = [start, end) per key,
+ * written completely.  Keys >= ncells are dropped.  ws: df_cell_sort_ws_bytes(ncells).  In-tree replacement of the rocPRIM radix
+ * sort of rounds 1-2 (hist / offsets / scatter with integer atomics, then each group put in ascending order: deterministic). */
+int64_t df_cell_sort_ws_bytes(int64_t ncells);
+int df_cell_sort(const uint32_t* key, int64_t n, int64_t ncells, uint32_t* idx_sorted, int32_t* cell_rng, void* ws, void* stream);
+/* backward of the feature net over the sorted runs (all pfn kernels iterate over occupied pillars = heads of the sorted key
+ * runs of sample b = sorted positions [sum counts[0..b), +counts[b])); bn_sample_stride = 128 (per-sample stats) or 0 (shared:
+ * eval); mode (0 'avg': every point of a pillar gets g / count; 1 'max': per channel the pillar's
  * first maximal point gets g, mmcv's traceback rule): pass A partial sums [B,nblk_stat,32,2] of (g_hat, g_hat*xhat); finalize -> dgamma, dbeta,
  * coef [B,2,32] = (S1/M_b, S2/M_b); pass B dW partials [B*nblk_stat,32,9] (sum with df_colsum_finalize). */
 int df_pfn_bwd_stats(const float* pts_sorted, const int32_t* cell_rng, const uint32_t* key_sorted,

@@ -417,72 +417,73 @@ def test_pillarize_vs_oracle(dev, train):
         check("bn1d running_var", mine._bn.running_var, bn.running_var)
 
 
-def _pillar_case(dev, monkeypatch, pts, grid, ext, train, mode="avg", merged_img=False):
-    """run both pillariser generations on the same cloud set; -> (state, canvas) of each"""
+def _bands_vs_oracle(dev, pts, vs, rng, dims, train, mode="avg", merged_img=False, tol=2e-5):
+    """the band pipeline (hist / scan / scatter / band) against the CPU oracle ALONE (the first-generation pillariser it used to
+    be compared with was retired in round 3): compaction outputs, the (sample, cell)-sorted arrays (= a stable sort of the valid
+    points by cell key, input order inside a cell), the dense cell table, and the canvas incl. its zeros (NaN-poisoned before the
+    call).  merged_img: S = 2B samples writing the two 32-channel halves of one [B,H,W,64] buffer (the tape-less forward's
+    layout).  -> (state, sorted keys wanted)"""
     from deflow_amd.encoder import DynamicEmbedder
     from deflow_amd._lib import DfImg, img
-    vs, rng, dims = [2 * ext / grid, 2 * ext / grid, 6], [-ext, -ext, -3, ext, ext, 3], [grid, grid]
-    out = []
-    for v1 in (False, True):
-        if v1:
-            monkeypatch.setenv("DF_PILLAR_V1", "1")
-        else:
-            monkeypatch.delenv("DF_PILLAR_V1", raising=False)
-        torch.manual_seed(5)
-        emb = DynamicEmbedder(vs, dims, rng, 32, mode=mode)
-        with torch.no_grad():
-            emb._bn.weight.uniform_(0.5, 1.5); emb._bn.bias.uniform_(-0.2, 0.2)
-            emb._bn.running_mean.uniform_(-1, 1); emb._bn.running_var.uniform_(0.5, 2)
-        emb = emb.to(dev).train(train)
-        S = pts.shape[0]
-        if merged_img:   # S = 2B samples writing the two 32-channel halves of one [B,H,W,64] buffer (the tape-less forward)
-            B = S // 2
-            buf = torch.full((B, grid, grid, 64), float("nan"), device=dev) if not v1 else torch.zeros(B, grid, grid, 64, device=dev)
-            d = DfImg(buf.data_ptr(), S, grid, grid, 32, 64, B, buf.stride(0), 32)
-            canvas = buf
-        else:            # NaN-poisoned: the band pipeline must write every byte itself
-            canvas = torch.full((S, grid, grid, 32), float("nan"), device=dev) if not v1 else torch.zeros(S, grid, grid, 32, device=dev)
-            d = img(canvas)
-        with torch.no_grad():
-            st = emb.pillarize(pts.to(dev), d, train)
-        torch.cuda.synchronize()
-        out.append((st, canvas, emb))
-    monkeypatch.delenv("DF_PILLAR_V1", raising=False)
-    return out
-
-
-PILLAR_CASES = [  # S, N, grid, extent
-    (3, 700, 64, 6.4), (2, 20000, 256, 25.6), (2, 80000, 512, 51.2), (1, 160000, 1024, 51.2), (5, 1023, 64, 6.4), (1, 1025, 128, 12.8),
-]
-
-
-@pytest.mark.parametrize("S,N,grid,ext", PILLAR_CASES)
-@pytest.mark.parametrize("train", [False, True])
-def test_pillar_bands_equal_first_generation(dev, monkeypatch, S, N, grid, ext, train):
-    """the band-bucketed pipeline (hist / scan / scatter / band: in-tree stable counting sort, LDS cell sort, fused canvas incl.
-    its zeros) against the first generation (library radix sort + separate kernels): identical integer outputs (compaction,
-    sorted keys / indices / cell table), identical sorted points, and the same canvas -- bit for bit in eval mode (same
-    arithmetic in the same order), to fp32 rounding of the batch statistics in training mode; no canvas byte left unwritten."""
-    pts = _cloud(S, N, 1000 + N, ext)
-    (s2, c2, e2), (s1, c1, e1) = _pillar_case(dev, monkeypatch, pts, grid, ext, train)
-    assert torch.equal(s2.counts, s1.counts)
-    tot = int(s1.counts.sum())
-    for name in ("points_c", "coords_c", "idx_c", "offs_c"):
-        a, b = getattr(s2, name), getattr(s1, name)
-        for k in range(S):
-            m = int(s1.counts[k])
-            assert torch.equal(a[k, :m], b[k, :m]), (name, k)
-    assert torch.equal(s2.cpos, s1.cpos)
-    assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
-    assert torch.equal(s2.pts_sorted[:tot], s1.pts_sorted[:tot])
-    assert torch.equal(s2.cell_rng, s1.cell_rng)
-    assert torch.isfinite(c2).all(), "every canvas byte must be written (zeros included)"
-    if train:
-        check("band canvas (train)", c2, c1, 1e-5)
-        check("band running_mean", e2._bn.running_mean, e1._bn.running_mean, 1e-6)
-        check("band running_var", e2._bn.running_var, e1._bn.running_var, 1e-6)
+    from oracle import ref_torch as O
+    H, W = dims
+    S, N, _ = pts.shape
+    torch.manual_seed(5)
+    ref = O.DynamicEmbedder(vs, dims, rng, 32)
+    ref.feature_net.mode = mode
+    bn = ref.feature_net.pfn_layers[0][1]
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    mine = DynamicEmbedder(vs, dims, rng, 32, mode=mode)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).train(train)
+    ref.train(train)
+    with torch.no_grad():
+        want_img, want_infos = ref(pts)
+    if merged_img:
+        B = S // 2
+        buf = torch.full((B, H, W, 64), float("nan"), device=dev)
+        d = DfImg(buf.data_ptr(), S, H, W, 32, 64, B, buf.stride(0), 32)
     else:
-        assert torch.equal(c2, c1)
+        buf = torch.full((S, H, W, 32), float("nan"), device=dev)
+        d = img(buf)
+    with torch.no_grad():
+        st = mine.pillarize(pts.to(dev), d, train)
+    torch.cuda.synchronize()
+    canvas = torch.cat([buf[..., :32], buf[..., 32:]], 0) if merged_img else buf
+    counts = st.counts.cpu().tolist()
+    assert counts == [int(i["voxel_coords"].shape[0]) for i in want_infos]
+    keys, idxs, ptss = [], [], []
+    for b in range(S):
+        m = counts[b]
+        wi = want_infos[b]
+        assert torch.equal(st.coords_c[b, :m].cpu().long(), wi["voxel_coords"].long()), b
+        assert torch.equal(st.idx_c[b, :m].cpu(), wi["point_idxes"].long()), b
+        assert torch.equal(st.points_c[b, :m].cpu(), wi["points"]) and torch.equal(st.offs_c[b, :m].cpu(), wi["point_offsets"]), b
+        key = b * H * W + wi["voxel_coords"][:, 1].long() * W + wi["voxel_coords"][:, 2].long()
+        order = torch.sort(key, stable=True).indices
+        keys.append(key[order]); idxs.append(b * N + wi["point_idxes"].long()[order]); ptss.append(wi["points"][order])
+    key_want, idx_want, pts_want = torch.cat(keys), torch.cat(idxs), torch.cat(ptss)
+    tot = sum(counts)
+    assert torch.equal(st.key_sorted[:tot].cpu().long(), key_want) and torch.equal(st.idx_sorted[:tot].cpu().long(), idx_want)
+    assert torch.equal(st.pts_sorted[:tot].cpu(), pts_want)
+    # compact position of every original point (or -1 for a dropped one)
+    cpos_want = torch.full((S, N), -1, dtype=torch.int32)
+    for b in range(S):
+        cpos_want[b, want_infos[b]["point_idxes"].long()] = torch.arange(counts[b], dtype=torch.int32)
+    assert torch.equal(st.cpos.cpu().view(S, N), cpos_want)
+    # dense [start, end) table: runs of equal keys; empty cells hold (0, 0)
+    uk, cnt = torch.unique_consecutive(key_want, return_counts=True)
+    end = torch.cumsum(cnt, 0)
+    rng_want = torch.zeros(S * H * W, 2, dtype=torch.int32)
+    rng_want[uk, 0], rng_want[uk, 1] = (end - cnt).int(), end.int()
+    assert torch.equal(st.cell_rng.cpu(), rng_want)
+    assert torch.isfinite(canvas).all(), "every canvas byte must be written (zeros included)"
+    check(f"band canvas vs oracle train={train} {mode}", canvas.permute(0, 3, 1, 2), want_img, tol)
+    if train:
+        check("band running_mean", mine._bn.running_mean, bn.running_mean, 1e-5)
+        check("band running_var", mine._bn.running_var, bn.running_var, 1e-5)
+    return st, uk
 
 
 def _dense_cloud(S, N, seed, extent, rows_m):
@@ -506,98 +507,34 @@ BAND_ORACLE_CASES = [  # S, N, grid, extent, dense rows (m; 0 = gaussian cloud),
 @pytest.mark.parametrize("S,N,grid,ext,dense,min_wgs", BAND_ORACLE_CASES)
 @pytest.mark.parametrize("train", [False, True])
 def test_pillar_bands_vs_oracle(dev, monkeypatch, S, N, grid, ext, dense, min_wgs, train):
-    """the band pipeline (hist / scan / scatter / band) against the CPU oracle alone: compaction outputs, the (sample, cell)-
-    sorted arrays (= a stable sort of the valid points by cell key, input order inside a cell), the dense cell table, and the
-    canvas incl. its zeros (NaN-poisoned before the call)"""
-    from deflow_amd.encoder import DynamicEmbedder
-    from deflow_amd._lib import img
-    from oracle import ref_torch as O
+    """the band pipeline against the CPU oracle (see _bands_vs_oracle) over the sizes the model runs at, incl. the WIDE band kernel
+    with more than 1024 occupied cells inside one band"""
     if min_wgs is not None:
         monkeypatch.setenv("DF_P2_MIN_WGS", min_wgs)
     vs, rng, dims = [2 * ext / grid, 2 * ext / grid, 6], [-ext, -ext, -3, ext, ext, 3], [grid, grid]
     pts = _dense_cloud(S, N, 77 + N, ext, dense) if dense else _cloud(S, N, 1000 + N, ext)
-    torch.manual_seed(5)
-    ref = O.DynamicEmbedder(vs, dims, rng, 32)
-    bn = ref.feature_net.pfn_layers[0][1]
-    with torch.no_grad():
-        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
-    mine = DynamicEmbedder(vs, dims, rng, 32)
-    mine.load_state_dict(ref.state_dict())
-    mine = mine.to(dev).train(train)
-    ref.train(train)
-    with torch.no_grad():
-        want_img, want_infos = ref(pts)
-    canvas = torch.full((S, grid, grid, 32), float("nan"), device=dev)
-    with torch.no_grad():
-        st = mine.pillarize(pts.to(dev), img(canvas), train)
-    torch.cuda.synchronize()
-    counts = st.counts.cpu().tolist()
-    assert counts == [int(i["voxel_coords"].shape[0]) for i in want_infos]
-    keys, idxs, ptss = [], [], []
-    for b in range(S):
-        m = counts[b]
-        wi = want_infos[b]
-        assert torch.equal(st.coords_c[b, :m].cpu().long(), wi["voxel_coords"].long()), b
-        assert torch.equal(st.idx_c[b, :m].cpu(), wi["point_idxes"].long()), b
-        assert torch.equal(st.points_c[b, :m].cpu(), wi["points"]) and torch.equal(st.offs_c[b, :m].cpu(), wi["point_offsets"]), b
-        key = b * grid * grid + wi["voxel_coords"][:, 1].long() * grid + wi["voxel_coords"][:, 2].long()
-        order = torch.sort(key, stable=True).indices
-        keys.append(key[order]); idxs.append(b * N + wi["point_idxes"].long()[order]); ptss.append(wi["points"][order])
-    key_want, idx_want, pts_want = torch.cat(keys), torch.cat(idxs), torch.cat(ptss)
-    tot = sum(counts)
-    assert torch.equal(st.key_sorted[:tot].cpu().long(), key_want) and torch.equal(st.idx_sorted[:tot].cpu().long(), idx_want)
-    assert torch.equal(st.pts_sorted[:tot].cpu(), pts_want)
-    # dense [start, end) table: runs of equal keys; empty cells hold (0, 0)
-    uk, cnt = torch.unique_consecutive(key_want, return_counts=True)
-    end = torch.cumsum(cnt, 0)
-    rng_want = torch.zeros(S * grid * grid, 2, dtype=torch.int32)
-    rng_want[uk, 0], rng_want[uk, 1] = (end - cnt).int(), end.int()
-    assert torch.equal(st.cell_rng.cpu(), rng_want)
+    st, uk = _bands_vs_oracle(dev, pts, vs, rng, dims, train)
     if dense:   # the case the test exists for: more than 1024 occupied cells inside one band of the wide kernel
         R = 2048 // grid
         occ_per_band = torch.bincount((uk % (grid * grid)) // (R * grid) + (uk // (grid * grid)) * (grid // R))
         assert int(occ_per_band.max()) > 1024, int(occ_per_band.max())
-    assert torch.isfinite(canvas).all(), "every canvas byte must be written (zeros included)"
-    check(f"band canvas vs oracle train={train}", canvas.permute(0, 3, 1, 2), want_img, 2e-5)
-    if train:
-        check("band running_mean", mine._bn.running_mean, bn.running_mean, 1e-5)
-        check("band running_var", mine._bn.running_var, bn.running_var, 1e-5)
 
 
 @pytest.mark.parametrize("H,W,N", [(40, 72, 5000), (104, 24, 3000), (8, 1000, 4097)])
-def test_pillar_bands_rectangular_grids(dev, monkeypatch, H, W, N):
+@pytest.mark.parametrize("train", [False, True])
+def test_pillar_bands_rectangular_grids(dev, H, W, N, train):
     """non-square grids whose height is not a multiple of the band height, a width that is not a power of two, a single-band
-    grid: both generations must agree bit for bit (eval) and no canvas byte may stay unwritten"""
-    from deflow_amd.encoder import DynamicEmbedder
-    from deflow_amd._lib import img
+    grid -- against the oracle; no canvas byte may stay unwritten"""
     vs, rng = [0.2, 0.2, 6], [-0.1 * W, -0.1 * H, -3, 0.1 * W, 0.1 * H, 3]
     g = torch.Generator().manual_seed(H * W)
     pts = torch.cat([(torch.rand(3, N, 1, generator=g) - 0.5) * 0.22 * W, (torch.rand(3, N, 1, generator=g) - 0.5) * 0.22 * H,
                      torch.rand(3, N, 1, generator=g) * 6.6 - 3.3], 2)
     pts[:, -N // 40:] = float("nan")
-    res = []
-    for v1 in (False, True):
-        if v1:
-            monkeypatch.setenv("DF_PILLAR_V1", "1")
-        else:
-            monkeypatch.delenv("DF_PILLAR_V1", raising=False)
-        torch.manual_seed(9)
-        emb = DynamicEmbedder(vs, [H, W], rng, 32).to(dev).eval()
-        canvas = torch.zeros(3, H, W, 32, device=dev) if v1 else torch.full((3, H, W, 32), float("nan"), device=dev)
-        with torch.no_grad():
-            st = emb.pillarize(pts.to(dev), img(canvas), False)
-        torch.cuda.synchronize()
-        res.append((st, canvas))
-    monkeypatch.delenv("DF_PILLAR_V1", raising=False)
-    (s2, c2), (s1, c1) = res
-    tot = int(s1.counts.sum())
-    assert tot > N and torch.equal(s2.counts, s1.counts)
-    assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
-    assert torch.equal(s2.cell_rng, s1.cell_rng) and torch.equal(s2.coords_c[0, :int(s1.counts[0])], s1.coords_c[0, :int(s1.counts[0])])
-    assert torch.isfinite(c2).all() and torch.equal(c2, c1)
+    st, _ = _bands_vs_oracle(dev, pts, vs, rng, [H, W], train)
+    assert int(st.counts.sum()) > N
 
 
-def test_pillar_bands_degenerate_clouds(dev, monkeypatch):
+def test_pillar_bands_degenerate_clouds(dev):
     """buckets far beyond the LDS chunk (5000 points in ONE cell, 3000 in one row), an all-NaN sample, a sample with a
     single point, max mode, and the merged two-cloud image layout"""
     g = torch.Generator().manual_seed(3)
@@ -611,16 +548,11 @@ def test_pillar_bands_degenerate_clouds(dev, monkeypatch):
     pts[3, 17] = torch.tensor([0.1, 0.1, 0.1])                          # sample 2 stays all NaN, sample 3 has one point
     for mode in ("avg", "max"):
         for train in (False, True):
-            (s2, c2, _), (s1, c1, _) = _pillar_case(dev, monkeypatch, pts, 64, 6.4, train, mode=mode, merged_img=True)
-            tot = int(s1.counts.sum())
-            assert s1.counts.tolist() == s2.counts.tolist() and s1.counts.tolist()[2] == 0 and s1.counts.tolist()[3] == 1
-            assert torch.equal(s2.key_sorted[:tot], s1.key_sorted[:tot]) and torch.equal(s2.idx_sorted[:tot], s1.idx_sorted[:tot])
-            assert torch.equal(s2.cell_rng, s1.cell_rng)
-            assert torch.isfinite(c2).all()
-            if train:
-                check(f"degenerate canvas {mode} train", c2, c1, 1e-5)
-            else:
-                assert torch.equal(c2, c1), mode
+            p = pts.clone()
+            if train:   # the reference's BatchNorm1d REFUSES a one-point sample in training mode ("Expected more than 1 value per
+                p[3, 4000] = torch.tensor([-3.3, 2.2, -1.0])      # channel"): two points there; the one-point sample runs in eval mode
+            st, _ = _bands_vs_oracle(dev, p, [0.2, 0.2, 6], [-6.4, -6.4, -3, 6.4, 6.4, 3], [64, 64], train, mode=mode, merged_img=True)
+            assert st.counts.tolist()[2] == 0 and st.counts.tolist()[3] == (2 if train else 1)
 
 
 def test_pillarize_backward(dev):
