@@ -65,6 +65,10 @@ _SIGS = {
     "df_conv2d_x3": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_x3_ok": [DfImg, DfImg, I, I, I, I],
     "df_split_bf16x3": [P, P, L, P],
+    "df_absmax": [DfImg, P, P],
+    "df_split_h2": [P, P, P, L, P],
+    "df_conv2d_h2": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
+    "df_conv2d_amax": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],
@@ -72,12 +76,13 @@ _SIGS = {
     "df_upsample2x_bf16": [DfImg, DfImg, I, P],
     "df_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, I, P],
     "df_bn_gelu_apply": [P, P, I, DfImg, P],
-    "df_bn_gelu_apply_t": [P, I, P, I, DfImg, P],
+    "df_bn_gelu_apply_t": [P, I, P, I, DfImg, P, P],
     "df_bn_gelu_bwd_reduce_t": [DfImg, P, I, P, I, P, I, P],
-    "df_bn_gelu_bwd_apply_t": [DfImg, P, I, P, P, I, P, I, P, I, P],
+    "df_bn_gelu_bwd_apply_t": [DfImg, P, I, P, P, I, P, I, P, I, P, P],
     "df_conv2d_wgrad_bf16": [DfImg, DfImg, I, I, I, P, I, P, P],
     "df_conv2d_wgrad_x3": [DfImg, DfImg, I, I, I, P, I, P, P],
     "df_conv2d_wgrad_x3_ok": [DfImg, DfImg, I, I],
+    "df_conv2d_wgrad_h2": [DfImg, DfImg, P, P, I, I, I, P, I, P, P],
     "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],
     "df_bn_bwd_finalize": [P, I, I, I, L, P, P, P, P],
     "df_bn_gelu_bwd_apply": [DfImg, P, P, P, I, P, P, I, P],
@@ -167,7 +172,13 @@ def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
     assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2), (t.shape, t.stride())
     n, h, w, cc = t.shape
     c = cc - c_off if c is None else c
-    return DfImg(t.data_ptr() + t.element_size() * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, _elt(t), 0)
+    d = DfImg(t.data_ptr() + t.element_size() * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, _elt(t), 0)
+    a = getattr(t, "_df_amax", None)     # max |t| measured by the kernel that wrote t (ops.bn_gelu_bwd, ops.conv2d): a bound for any view of it
+    if a is not None:
+        d._amax = a
+    if c_off == 0 and c == cc:
+        d._src = t                       # whole-tensor descriptor: a producer may leave the bound on the tensor (ops.conv2d)
+    return d
 
 
 def img_pair(t: torch.Tensor, c: int) -> DfImg:

@@ -101,5 +101,24 @@ __device__ __forceinline__ float df_tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
 }
 
+// max |x| bookkeeping of the fp16x2 convolution kernels (conv.hip): block-wide max of one non-negative float per thread (blocks of
+// up to 1024 threads), then ONE integer atomic max of its bit pattern into *amax -- skipped when the value already there is not smaller (non-
+// negative floats order like their bit patterns; the result is exact and order-independent)
+__device__ __forceinline__ void df_block_amax(float mf, unsigned* __restrict__ amax) {
+  unsigned m = __builtin_bit_cast(unsigned, mf);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned df_amax_red[16];
+  if ((threadIdx.x & 63) == 0) df_amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)((blockDim.x + 63) >> 6);
+    for (int w = 1; w < nw; ++w) m = max(m, df_amax_red[w]);
+    if (m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);
+  }
+}
+__device__ __forceinline__ float df_amax4(float m, const f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -30,6 +30,24 @@ constexpr int LDT = BK;  // LDS row pitch (floats); slots swizzled instead of pa
 // exact in the fp32 accumulator (v_mfma_f32_32x32x16_bf16: 16 k per instruction instead of 2).  What torch.autocast(bf16)
 // computes for a conv -- operands in bf16, fp32 accumulation -- with the output kept in fp32.  Templates carry `BF`.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// fp16x2 operands (NP = 2 forms of the x3 kernels): a tensor with max|x| <= amax is scaled by the power of two s that puts amax
+// into [2^14, 2^15) and split as  x s = hi + lo / 2048,  hi = fp16(x s), lo = fp16((x s - hi) 2048)  -- 22 significant bits for
+// every element down to 2^-29 amax (where hi leaves fp16's normal range; below that the absolute error is < 2^-39 amax).
+__device__ __forceinline__ float df_h2_scale(float amax) {
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);     // amax in [2^(e-127), 2^(e-126))
+  const int f = min(max(268 - e, 1), 254);                                     // s = 2^(141 - e), clamped to normal floats
+  return __builtin_bit_cast(float, (unsigned)f << 23);
+}
+constexpr float H2_LO = 2048.f, H2_LO_INV = 1.f / 2048.f;
+__device__ __forceinline__ void df_h2_split(const float (&v)[8], float s, f16x8_t& hi, f16x8_t& lo) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = v[k] * s;
+    hi[k] = (_Float16)t;
+    lo[k] = (_Float16)((t - (float)hi[k]) * H2_LO);
+  }
+}
 __device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
   bf16x8_t r;
 #pragma unroll
@@ -63,6 +81,9 @@ struct ConvParams {
   int dbg;  // ablation switch (env DF_CONV_DBG): 1 = no global loads after the prologue, 2 = also no LDS stores
   int bf16; // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
   int stats_mul;  // statistics rows per tile (1; 2 when a 256-row tile fills the partial table sized for 128-row tiles: the second is 0)
+  const float* amax_x;   // fp16x2 form (conv_halo_x3_kernel<.., NP = 2>): upper bounds of max|x| and max|w| (device scalars) that
+  const float* amax_w;   // set the power-of-two scales of the two fp16 planes
+  unsigned* amax_y;      // optional: the epilogue leaves max |y| there (bit pattern, atomic max) for an fp16x2 consumer of y
 };
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
@@ -108,6 +129,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   }
   __syncthreads();
   float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
+  float amax_t = 0.f;                                           // max |y| over this thread's stored elements
   if (p.y_bytes) {
     // Straight-line stores: buffer stores whose offset is out of range for rows past the end (dropped by the hardware)
     // instead of a branch per element.  With the branch the compiler had to re-wait for the bias / scale loads inside every
@@ -163,6 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             if (ob[e] != ROW_BAD) {
               s1 += v;
               s2 += v * v;
+              amax_t = fmaxf(amax_t, fabsf(v));
             }
           }
         }
@@ -203,6 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             yp[off + co] = v;
             s1 += v;
             s2 += v * v;
+            amax_t = fmaxf(amax_t, fabsf(v));
           }
         }
       }
@@ -235,6 +259,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       }
     }
   }
+  if (p.amax_y) df_block_amax(amax_t, p.amax_y);                // (uniform branch)
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -974,7 +999,13 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 // BM = 128, SEG = 1: the tile is 128 pixels of one image row (W % 128 == 0); BM = 128, SEG = 2: two whole rows of a W == 64
 // image (halo 2 x 66); BM = 256, SEG = 1: 256 pixels of one row (W % 256 == 0) -- the form of the 64-output-channel layers, whose
 // 128 x 64 tile had 32 x 32 wave tiles (12 MFMAs per 12 fragment reads); with 256 rows the wave tile is 64 x 32 again.
-template <int BM, int BN, int WM, int WN, int SEG, int DB>
+// NP = 2 ("fp16x2", df_conv2d_h2): TWO fp16 planes per operand instead of three bf16 ones.  With per-tensor power-of-two scales
+// (df_h2_scale of an upper bound of max|x| resp. max|w|; the caller measures them, df_absmax) x s = hi + lo / 2048 carries 22
+// significant bits, and  x w = [hi hi' + (hi lo' + lo hi') / 2048] / (s s')  + O(2^-22 |x w|): THREE fp16 MFMAs (the hi.hi terms
+// in one accumulator, the two cross terms in a second one that is folded in at the end) instead of six -- half the matrix
+// work of the bf16x3 form, 2 / 3 of its LDS bytes, at an error 3 x 2^-22 per product, i.e. far below the fp32 accumulation's own
+// rounding over K = 9 Cin terms.
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SW = BM / SEG + 2;                     // halo pixels per segment
@@ -982,13 +1013,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int NIT = (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte bf16 slot = 8 floats) per thread
-  constexpr int AP = HR * LDH, AB = 3 * AP;            // A plane / buffer (floats)
-  constexpr int BP = BN * LDH, BSL = 3 * BP;           // B plane / ring slot (floats)
+  constexpr int AP = HR * LDH, AB = NP * AP;           // A plane / buffer (floats)
+  constexpr int BP = BN * LDH, BSL = NP * BP;          // B plane / ring slot (floats)
   constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
-  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || (BM == 256 && SEG == 1)), "8 waves");
+  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || (BM == 256 && SEG == 1)) && (NP == 2 || NP == 3), "8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                      // [2][3][HR][LDH]
-  float* Bs = lds + 2 * AB;             // [DB][3][BN][LDH]
+  float* As = lds;                      // [2][NP][HR][LDH]
+  float* Bs = lds + 2 * AB;             // [DB][NP][BN][LDH]
+  float sx = 1.f, sw = 1.f;
+  if constexpr (NP == 2) { sx = df_h2_scale(*p.amax_x); sw = df_h2_scale(*p.amax_w); }
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
@@ -1033,7 +1066,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   const int brow = ((wave * 16) % BN) + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);
   const unsigned boff = (unsigned)(((int64_t)(n0 + brow) * 9 * p.K + bslot * 8) * 2);
   const unsigned plane_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2);
-  constexpr int NBW = 3, NFA = 2 * NIT;               // VMEM operations per wave: per weight stage / per halo fetch
+  constexpr int NBW = NP, NFA = 2 * NIT;              // VMEM operations per wave: per weight stage / per halo fetch
 
   // carried scalar offsets (see conv_halo_w16_kernel): halo row / chunk of the NEXT group to fetch, tap (ty, tx, kc) of the next
   // weight stage to issue
@@ -1061,7 +1094,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
       sa_next += BK * 4;
     }
   };
-  auto stash_a = [&](int abuf) {                      // registers -> three bf16 planes -> LDS
+  auto stash_a = [&](int abuf) {                      // registers -> three bf16 (two fp16) planes -> LDS
     float* a = As + abuf * AB;
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
@@ -1069,6 +1102,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
         float v[8], r[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        if constexpr (NP == 2) {
+          f16x8_t h, l;
+          df_h2_split(v, sx, h, l);
+          float* d = a + (tid + e * NT) * 4;
+          *reinterpret_cast<f16x8_t*>(d) = h;
+          *reinterpret_cast<f16x8_t*>(d + AP) = l;
+          continue;
+        }
         bf16x8_t hi, mi, lo;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { hi[k] = (__bf16)v[k]; r[k] = v[k] - (float)hi[k]; }
@@ -1089,7 +1130,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     float* b = Bs + bslot_ring * BSL + ((wave * 16) % BN) * LDH;
     const unsigned soff = (unsigned)(swb_next + btx * dtap);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + pl * BP), 16, boff, soff + pl * plane_bytes, 0, 0);
     if (++bslot_ring == DB) bslot_ring = 0;
     if (++btx == 3) {                                 // next weight group: next k chunk, or the next tap row's first
@@ -1105,12 +1146,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #define DF_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
 
   f32x16 acc[TM][TN];
+  f32x16 acc1[NP == 2 ? TM : 1][NP == 2 ? TN : 1];     // fp16x2: the cross terms (hi lo' + lo hi'), scaled by 2048
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if constexpr (NP == 2) acc1[i][j][e] = 0.f;
+      }
 
   int cur_slot = 0;
   // one tap stage: issue (MAIN: the next group's halo at tx == 0, weight stage s + PD), 2 k-steps x 6 products, the waits
@@ -1131,6 +1176,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     const int sb = (li >> 2) & 3;
 #pragma unroll
     for (int q = 0; q < BK / 16; ++q) {
+      if constexpr (NP == 2) {
+        f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int sh = SEG == 1 ? 0 : 2 * ((wm * TM + i) * 32 / (BM / SEG));
+          const int sa = ((li + tx + sh) >> 2) & 3;
+          const float* ap = a + (i * 32 + sh) * LDH + (((2 * q + kh) ^ sa) * 4);
+          ah[i] = *reinterpret_cast<const f16x8_t*>(ap);
+          al[i] = *reinterpret_cast<const f16x8_t*>(ap + AP);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float* bp = b0 + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4);
+          bh[j] = *reinterpret_cast<const f16x8_t*>(bp);
+          bl[j] = *reinterpret_cast<const f16x8_t*>(bp + BP);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+          }
+        continue;
+      }
       bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -1215,18 +1286,55 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #undef DF_VMCNT
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
+  if constexpr (NP == 2) {   // fold the cross terms in and take the two power-of-two scales out (exact multiplications)
+    const float ix = 1.f / sx, iw = 1.f / sw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
+  }
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int SEG, int DB>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3>
 static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
   constexpr int HR = (SEG * (BM / SEG + 2) + 3) / 4 * 4;
-  const size_t lds_bytes = (size_t)(2 * 3 * HR + DB * 3 * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  const size_t lds_bytes = (size_t)(2 * NP * HR + DB * NP * BN) * LDH * sizeof(float);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
+}
+
+// w [n] fp32 -> two fp16 planes out2[2][n] of w s (s = df_h2_scale(*amax)): hi = fp16(w s), lo = fp16((w s - hi) 2048)
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ w, const float* __restrict__ amax,
+                                                       _Float16* __restrict__ out2, int64_t n) {
+  const float s = df_h2_scale(*amax);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = w[i] * s;
+    const _Float16 hi = (_Float16)t;
+    out2[i] = hi;
+    out2[n + i] = (_Float16)((t - (float)hi) * H2_LO);
+  }
+}
+
+// amax (a float's bit pattern, zero-initialised by the caller) <- max(amax, max |x|) over an image view: non-negative floats
+// order like their bit patterns, so an integer atomic max is exact and order-independent.  One thread per 4 channels.
+__global__ __launch_bounds__(256) void absmax_kernel(df_img d, int64_t total4, unsigned* __restrict__ amax) {
+  const int c4 = d.c >> 2;
+  const int64_t hw = (int64_t)d.h * d.w;
+  float mf = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / c4;
+    const int q = (int)(i - row * c4);
+    const int64_t n = row / hw;
+    const float* src = reinterpret_cast<const float*>(d.ptr) + df_img_base(d, (int)n) + (row - n * hw) * d.ld + q * 4;
+    mf = df_amax4(mf, ld4(src));
+  }
+  df_block_amax(mf, amax);
 }
 
 // w [n] fp32 -> three bf16 planes out3[3][n]: hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)  (w == hi + mid + lo)
@@ -1272,6 +1380,8 @@ struct WgradParams {
   float* bias_ws;              // optional [splits][N]: per-split column sums of dy (bias gradient), written by ci-tile 0
   int bf16;                    // MFMA operands rounded to bf16 (fp32 tensors, fp32 accumulation)
   int xcd_map;                 // ring kernel: all (ci, co) tiles of a split on one XCD (shared x / dy tiles hit its L2)
+  const float* amax_x;         // fp16x2 form (wgrad3_x3_kernel<2>): upper bounds of max|x| / max|dy| (device scalars)
+  const float* amax_dy;
 };
 
 // chunk = one output-row segment of P pixels: (image n, output row oy, first column ox0)
@@ -2116,13 +2226,19 @@ __global__ __launch_bounds__(768) void wgrad3_tr_kernel(WgradParams p) {
 // is multiplied as six exact bf16 products -- 36 MFMAs per wave and 32-pixel stage, dW to fp32 rounding at 16 / 6 of the fp32
 // MFMA rate.  12 waves = (32 co x 32 ci quadrant) x kernel row; two LDS stages of 3 x 17 KB (one workgroup per CU); the next
 // stage's elements are fetched into registers while the current stage is multiplied.
+// NP = 2: two fp16 planes per operand with per-tensor power-of-two scales (see conv_halo_x3_kernel): three MFMAs per operand pair
+// instead of six, two accumulators per tap (hi.hi | cross terms x 2048), 2 / 3 of the LDS bytes.
+template <int NP>
 __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 32, XW = P + 2, LC = 64;
   constexpr int YB = 2 * P * 64;                        // dY image bytes of one plane: [2 halves][32 px][64 B]
   constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows x 34 px][64 B]
   constexpr int PLB = YB + 2 * XH;                      // one plane of a stage (17152 B)
-  constexpr int STG = 3 * PLB;                          // stage bytes (51456)
+  constexpr int STG = NP * PLB;                         // stage bytes (51456 / 34304)
+  static_assert(NP == 2 || NP == 3, "planes");
+  float sx = 1.f, sdy = 1.f;
+  if constexpr (NP == 2) { sx = df_h2_scale(*p.amax_x); sdy = df_h2_scale(*p.amax_dy); }
   constexpr int NYS = YB / 16, NXS = 2 * XH / 16;       // 16-byte slots: 256 + 816
   constexpr int NIT = (NYS + NXS + 767) / 768;          // items per thread (2)
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -2145,10 +2261,14 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
   float bsum = 0.f;
 
   f32x16 acc[3];
+  f32x16 acc1[NP == 2 ? 3 : 1];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+      acc[t][e] = 0.f;
+      if constexpr (NP == 2) acc1[t][e] = 0.f;
+    }
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
@@ -2229,6 +2349,14 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
         float v[8], r[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        if constexpr (NP == 2) {
+          f16x8_t h, l;
+          df_h2_split(v, lqy[e] == -100 ? sdy : sx, h, l);
+          char* d = st + ldst[e];
+          *reinterpret_cast<f16x8_t*>(d) = h;
+          *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+          continue;
+        }
         bf16x8_t hi, mi, lo;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { hi[k] = (__bf16)v[k]; r[k] = v[k] - (float)hi[k]; }
@@ -2267,6 +2395,38 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
 #pragma unroll
     for (int ks = 0; ks < P / 16; ++ks) {
       const unsigned aa = a_base + so + ks * 16 * 64, ba = b_base + so + ks * 16 * 64;
+      if constexpr (NP == 2) {
+        u32x2_t ahl, ahh, all_, alh;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\t"
+            "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+            "ds_read_b64_tr_b16 %2, %4 offset:17152\n\t"
+            "ds_read_b64_tr_b16 %3, %4 offset:17408\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(ahl), "=&v"(ahh), "=&v"(all_), "=&v"(alh)
+            : "v"(aa)
+            : "memory");
+        const f16x8_t ah = __builtin_bit_cast(f16x8_t, op8(ahl, ahh)), al = __builtin_bit_cast(f16x8_t, op8(all_, alh));
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          u32x2_t bhl, bhh, bll, blh;
+          const unsigned bb = ba + kx * 64;
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %4\n\t"
+              "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+              "ds_read_b64_tr_b16 %2, %4 offset:17152\n\t"
+              "ds_read_b64_tr_b16 %3, %4 offset:17408\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(bhl), "=&v"(bhh), "=&v"(bll), "=&v"(blh)
+              : "v"(bb)
+              : "memory");
+          const f16x8_t bh = __builtin_bit_cast(f16x8_t, op8(bhl, bhh)), bl = __builtin_bit_cast(f16x8_t, op8(bll, blh));
+          acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[kx], 0, 0, 0);
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[kx], 0, 0, 0);
+          acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[kx], 0, 0, 0);
+        }
+        continue;
+      }
       // dY operand: three planes x (pixels +0..3, +4..7); plane stride PLB = 17152 bytes (immediate offsets)
       u32x2_t ahl, ahh, aml, amh, all_, alh;
       asm volatile(
@@ -2314,9 +2474,13 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
       for (int j = 0; j < P / 8; ++j) {
         const int el = (c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31);
         float v = 0.f;
+        if constexpr (NP == 2) {
+          v = (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+        } else {
 #pragma unroll
-        for (int pl = 2; pl >= 0; --pl)
-          v += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(stp + pl * PLB)[el] << 16);
+          for (int pl = 2; pl >= 0; --pl)
+            v += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(stp + pl * PLB)[el] << 16);
+        }
         bsum += v;
       }
     }
@@ -2331,18 +2495,21 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += red[64 * w + tid];
-      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t;
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = NP == 2 ? t * (1.f / sdy) : t;
     }
   }
   if ((ci0 + wci * 32) < p.K) {
     float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+    const float ix = 1.f / sx, iy = 1.f / sdy;      // (NP == 2) exact powers of two
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         const int ci = ci0 + wci * 32 + li;
-        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = acc[kx][e];
+        float v = acc[kx][e];
+        if constexpr (NP == 2) v = (v + acc1[kx][e] * H2_LO_INV) * ix * iy;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = v;
       }
   }
 #endif
@@ -2536,7 +2703,8 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
 // exists for this call" without launching anything
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
-                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr);
+                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr,
+                       const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -2572,6 +2740,47 @@ extern "C" int df_conv2d_x3_ok(df_img x, df_img y, int ksize, int stride, int mo
   return r == 1 ? 1 : 0;
 }
 
+// fp32-accurate convolution through TWO fp16 planes per operand (conv_halo_x3_kernel<.., NP = 2>): w2 = df_split_h2 of the
+// weights with w_amax = df_absmax of them; x_amax = an upper bound of max|x| (df_absmax of x or of any tensor containing it).
+// Shapes as df_conv2d_x3 (df_conv2d_x3_ok answers for both).
+extern "C" int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y,
+                            int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift,
+                            float* stats_partial, int accumulate, float* y_amax, void* stream) {
+  DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax, DF_E_ALIGN);
+  return conv2d_impl(x, nullptr, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false,
+                     stream, w2, x_amax, w_amax, y_amax);
+}
+
+// df_conv2d (fp32 MFMA kernels, any supported shape) that also leaves max |y| in *y_amax (zero-initialised by the caller; see
+// df_absmax): the 1x1 and stride-2 convolutions whose output an fp16x2 convolution reads next
+extern "C" int df_conv2d_amax(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
+                              const float* scale, const float* shift, float* stats_partial, int accumulate, float* y_amax,
+                              void* stream) {
+  return conv2d_impl(x, w, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false, stream,
+                     nullptr, nullptr, nullptr, y_amax);
+}
+
+extern "C" int df_absmax(df_img x, float* amax, void* stream) {
+  DF_REQUIRE(img_ok(x) && amax && (x.c % 4) == 0, DF_E_ARG);
+  const int64_t total4 = (int64_t)x.n * x.h * x.w * (x.c / 4);
+  int64_t blocks = (total4 + 1023) / 1024;          // ~4 float4 per thread
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, total4,
+                     reinterpret_cast<unsigned*>(amax));
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_split_h2(const float* w, const float* amax, void* out2, int64_t n, void* stream) {
+  DF_REQUIRE(w && amax && out2 && n > 0 && df_aligned16(out2), DF_E_ARG);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, amax,
+                     reinterpret_cast<_Float16*>(out2), n);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 extern "C" int df_split_bf16x3(const float* w, void* out3, int64_t n, void* stream) {
   DF_REQUIRE(w && out3 && n > 0 && df_aligned16(out3), DF_E_ARG);
   int64_t blocks = (n + 255) / 256;
@@ -2593,7 +2802,8 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
-                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3) {
+                       int accumulate, int mfma_bf16, bool query, void* stream, const void* w3, const float* h2_amax_x,
+                       const float* h2_amax_w, float* y_amax) {
   if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
@@ -2616,6 +2826,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
   p.bf16 = mfma_bf16 != 0;
   p.stats_mul = 1;
+  p.amax_x = p.amax_w = nullptr;
+  p.amax_y = reinterpret_cast<unsigned*>(y_amax);
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -2674,17 +2886,27 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     if (query) return ok ? 1 : 0;
     DF_REQUIRE(ok, DF_E_SHAPE);
     p.w = reinterpret_cast<const float*>(w3);
-    p.w_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2 * 3);
+    const bool h2 = h2_amax_x != nullptr;        // two fp16 planes (df_conv2d_h2) instead of three bf16 ones
+    p.w_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2 * (h2 ? 2 : 3));
     p.bf16 = 0;
-    if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8>(p, s);
-    if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4>(p, s);
-    // 64 output channels: 256-pixel row tiles where the image allows (wave tile 64 x 32 instead of 32 x 32)
+    p.amax_x = h2_amax_x;
+    p.amax_w = h2_amax_w;
     static const int bm256 = getenv("DF_CONV_X3_BM256") ? atoi(getenv("DF_CONV_X3_BM256")) : 1;
-    if (bm256 && (y.w % 256) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0)) {
+    // 64 output channels: 256-pixel row tiles where the image allows (wave tile 64 x 32 instead of 32 x 32)
+    const bool wide = !two && var != 128128 && bm256 && (y.w % 256) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0);
+    if (wide) {
       p.tiles_m = (int)(M / 256);
       p.stats_mul = 2;
-      return launch_conv_halo_x3<256, 64, 4, 2, 1, 4>(p, s);
     }
+    if (h2) {
+      if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4, 2>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8, 2>(p, s);
+      if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4, 2>(p, s);
+      if (wide) return launch_conv_halo_x3<256, 64, 4, 2, 1, 4, 2>(p, s);
+      return launch_conv_halo_x3<128, 64, 4, 2, 1, 8, 2>(p, s);
+    }
+    if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8>(p, s);
+    if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4>(p, s);
+    if (wide) return launch_conv_halo_x3<256, 64, 4, 2, 1, 4>(p, s);
     return launch_conv_halo_x3<128, 64, 4, 2, 1, 8>(p, s);
   }
   if (w16) {   // df_conv2d_w16: bf16 tiles in LDS, only the haloed forms exist (W % 128 == 0, or W == 64 as row pairs)
@@ -2876,11 +3098,27 @@ extern "C" int df_conv2d_wgrad_x3_ok(df_img x, df_img dy, int ksize, int stride)
          x.grp_off >= 0 && dy.grp_off >= 0 && extent(x) < (int64_t)DMA_BAD && extent(dy) < (int64_t)DMA_BAD;
 }
 
+static int wgrad_x3_impl(df_img x, df_img dy, const float* x_amax, const float* dy_amax, int ksize, int stride, int pad, float* ws,
+                         int splits, float* bias_ws, void* stream);
+
 extern "C" int df_conv2d_wgrad_x3(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws,
                                   void* stream) {
+  return wgrad_x3_impl(x, dy, nullptr, nullptr, ksize, stride, pad, ws, splits, bias_ws, stream);
+}
+
+// the fp16x2 form (wgrad3_x3_kernel<2>): x_amax / dy_amax = upper bounds of max|x| / max|dy| (df_absmax); shapes as the x3 form
+extern "C" int df_conv2d_wgrad_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, int ksize, int stride, int pad,
+                                  float* ws, int splits, float* bias_ws, void* stream) {
+  DF_REQUIRE(x_amax && dy_amax, DF_E_ARG);
+  return wgrad_x3_impl(x, dy, x_amax, dy_amax, ksize, stride, pad, ws, splits, bias_ws, stream);
+}
+
+static int wgrad_x3_impl(df_img x, df_img dy, const float* x_amax, const float* dy_amax, int ksize, int stride, int pad, float* ws,
+                         int splits, float* bias_ws, void* stream) {
   DF_REQUIRE(ws && df_aligned16(ws) && pad == 1 && df_conv2d_wgrad_x3_ok(x, dy, ksize, stride) == 1, DF_E_SHAPE);
   WgradParams p;
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
+  p.amax_x = x_amax; p.amax_dy = dy_amax;
   p.stride = 1; p.pad = 1; p.K = x.c; p.N = dy.c;
   auto extent = [](const df_img& d) {
     return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
@@ -2895,7 +3133,8 @@ extern "C" int df_conv2d_wgrad_x3(df_img x, df_img dy, int ksize, int stride, in
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
   p.xcd_map = xcd_map;
-  return launch_wgrad_dma(wgrad3_x3_kernel, grid, 2 * 3 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
+  if (x_amax) return launch_wgrad_dma(wgrad3_x3_kernel<2>, grid, 2 * 2 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
+  return launch_wgrad_dma(wgrad3_x3_kernel<3>, grid, 2 * 3 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
 }
 
 // bf16-STORAGE training: 3x3 stride-1 weight gradient of bfloat16 x and dy (wgrad3_tr_kernel); splits / workspace / reduce as

@@ -129,9 +129,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const void* __restric
 // ------------------------------------------------------------------ BN+GELU apply -------
 template <int YE = 0, int ZE = 0>
 __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restrict__ y, const float* __restrict__ bn_ss,
-                                                            int imgs_per_group, df_img z, int64_t total4) {
+                                                            int imgs_per_group, df_img z, int64_t total4,
+                                                            unsigned* __restrict__ amax) {
   const int C4 = z.c >> 2;
   const int hw = z.h * z.w;
+  float mf = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / C4;
     const int c = (int)(i - m * C4) * 4;
@@ -142,7 +144,9 @@ __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = df_gelu(v[k] * sc[k] + sh[k]);
     stx4<ZE>(z.ptr, df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
+    mf = df_amax4(mf, o);
   }
+  if (amax) df_block_amax(mf, amax);      // max |z| for the fp16x2 convolution that reads z next (uniform branch)
 }
 
 // block layout shared by the row-partitioned channel reductions: C/4 channel lanes x 256/(C/4) row lanes
@@ -260,8 +264,9 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
                                                                 const float* __restrict__ bn_ss,
                                                                 const float* __restrict__ coef, int imgs_per_group,
                                                                 void* __restrict__ dy, float* __restrict__ dbias_partial,
-                                                                int64_t rows, int64_t rows_per_blk) {
+                                                                int64_t rows, int64_t rows_per_blk, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4];
+  float mf = 0.f;
   const int C = dz.c, hw = dz.h * dz.w;
   const RowPart rp = row_part(C);
   const void* __restrict__ dzp = dz.ptr;
@@ -288,8 +293,10 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
         acc[0][k] += o[k];
       }
       stx4<DE>(dy, m * C + rp.c, o);
+      mf = df_amax4(mf, o);
     }
   }
+  if (amax) df_block_amax(mf, amax);      // max |dy| for the fp16x2 data- / weight-gradient kernels (uniform branch)
   if (dbias_partial) {
     block_reduce_rows<1>(acc, rp, lds);
     if (rp.row_lane == 0) st4(dbias_partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
@@ -483,22 +490,24 @@ extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int gro
   return DF_OK;
 }
 
-extern "C" int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
+extern "C" int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, float* z_amax,
+                                  void* stream) {
+  unsigned* amax = reinterpret_cast<unsigned*>(z_amax);
   DF_REQUIRE(y && bn_ss && img_ok(z, true) && df_aligned16(y) && imgs_per_group > 0 && (y_elt == 0 || y_elt == 1), DF_E_ARG);
   const int64_t total4 = (int64_t)z.n * z.h * z.w * (z.c / 4);
   const dim3 grid(grid_for(total4));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
-  else if (y_elt == 1 && z.elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
-  else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
-  else hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4);
+  if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  else if (y_elt == 1 && z.elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  else hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
 
 extern "C" int df_bn_gelu_apply(const float* y, const float* bn_ss, int imgs_per_group, df_img z, void* stream) {
   DF_REQUIRE(z.elt == 0, DF_E_ARG);
-  return df_bn_gelu_apply_t(y, 0, bn_ss, imgs_per_group, z, stream);
+  return df_bn_gelu_apply_t(y, 0, bn_ss, imgs_per_group, z, nullptr, stream);
 }
 
 extern "C" int df_bn_gelu_bwd_reduce_t(df_img dz, const void* y, int y_elt, const float* bn_ss, int imgs_per_group, float* partial,
@@ -534,7 +543,9 @@ extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int 
 }
 
 extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const float* bn_ss, const float* coef,
-                                      int imgs_per_group, void* dy, int dy_elt, float* dbias_partial, int nblk, void* stream) {
+                                      int imgs_per_group, void* dy, int dy_elt, float* dbias_partial, int nblk, float* dy_amax,
+                                      void* stream) {
+  unsigned* amax = reinterpret_cast<unsigned*>(dy_amax);
   DF_REQUIRE(img_ok(dz, true) && y && bn_ss && coef && dy && nblk > 0 && rowpart_ok(dz.c) && (y_elt == 0 || y_elt == 1) &&
                  (dy_elt == 0 || dy_elt == 1), DF_E_ARG);
   const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
@@ -544,7 +555,7 @@ extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const
   DF_REQUIRE(rows_per_group % rpb == 0, DF_E_SHAPE);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DF_BWD_APPLY(G, Y, D) \
-  hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<G, Y, D>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb)
+  hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<G, Y, D>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb, amax)
   const int key = dz.elt * 4 + y_elt * 2 + dy_elt;
   switch (key) {
     case 0: DF_BWD_APPLY(0, 0, 0); break;
@@ -564,7 +575,7 @@ extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const
 extern "C" int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const float* coef,
                                     int imgs_per_group, float* dy, float* dbias_partial, int nblk, void* stream) {
   DF_REQUIRE(dz.elt == 0, DF_E_ARG);
-  return df_bn_gelu_bwd_apply_t(dz, y, 0, bn_ss, coef, imgs_per_group, dy, 0, dbias_partial, nblk, stream);
+  return df_bn_gelu_bwd_apply_t(dz, y, 0, bn_ss, coef, imgs_per_group, dy, 0, dbias_partial, nblk, nullptr, stream);
 }
 
 extern "C" int df_colsum_partial(df_img x, float* partial, int nblk, void* stream) {

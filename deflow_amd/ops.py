@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import DfImg, call, ptr, stream
+from ._lib import DfImg, call, img, ptr, stream
 
 CONV_FWD, CONV_DGRAD = 0, 1
 EPI_BIAS, EPI_STATS, EPI_BN_GELU = 0, 1, 2
@@ -176,8 +176,69 @@ def _conv_variant(x: DfImg, y: DfImg, ks: int, stride: int, mode: int, epi: int)
     return f"{kern}<{bm},{bn},{wm},{wn}>"
 
 
+# ---- max |x| bookkeeping of the fp16x2 convolution kernels (df_conv2d_h2 / df_conv2d_wgrad_h2) -------------------------------
+# The kernels scale each operand by a power of two taken from an UPPER BOUND of its absolute maximum (a device scalar, so nothing
+# here synchronises); any bound within a factor of ~2^10 serves.  Where the bound comes from:
+#   activations / gradients  written by the BatchNorm + GELU passes: measured by those kernels as they write (bn_gelu_apply,
+#                            bn_gelu_bwd); everything else: one df_absmax pass the first time a convolution reads the tensor,
+#                            remembered on the descriptor / tensor object (the tape keeps it for the weight gradient)
+#   weights                  ops.W_AMAX when a Trainer set it (one df_absmax over the whole parameter arena per step), else
+#                            per call
+# Slots come zero-filled from a small pool (one fill per _AMAX_POOL_N slots; amax_pool_reset() starts a fresh pool -- the Trainer
+# does so at the top of every step, inside a captured step too, so that a replay re-zeroes what it accumulates into).
+_AMAX_POOL_N = 256
+_amax_pool = [None, 0]
+W_AMAX: Optional[torch.Tensor] = None
+
+
+def amax_pool_reset():
+    _amax_pool[0] = None
+
+
+def amax_slot(device) -> torch.Tensor:
+    if _amax_pool[0] is None or _amax_pool[1] >= _AMAX_POOL_N or _amax_pool[0].device != torch.device(device):
+        _amax_pool[0] = torch.zeros(_AMAX_POOL_N, dtype=torch.float32, device=device)
+        _amax_pool[1] = 0
+    i = _amax_pool[1]
+    _amax_pool[1] = i + 1
+    return _amax_pool[0][i:i + 1]
+
+
+def amax_of(d: DfImg, device) -> torch.Tensor:
+    """device scalar >= max |x| of the image view: the producer's measurement if it left one, else one df_absmax pass"""
+    a = getattr(d, "_amax", None)
+    if a is None:
+        a = amax_slot(device)
+        call("df_absmax", d, ptr(a), stream())
+        d._amax = a
+    return a
+
+
+def _h2_on() -> bool:
+    return os.environ.get("DF_CONV_H2", "1") != "0"
+
+
+def h2_active() -> bool:
+    """are the fp32-mode 3x3 stride-1 convolutions on the fp16x2 kernels (so that producers should measure max |x|)?"""
+    return (not MFMA_BF16) and _h2_on() and os.environ.get("DF_CONV_X3", "1") != "0"
+
+
+def _split_h2(w_ohwi: torch.Tensor):
+    """weights -> (two fp16 planes, their amax): per call (they change every optimizer step; each conv uses them once per direction)"""
+    wa = W_AMAX
+    if wa is None:
+        wa = amax_slot(w_ohwi.device)
+        call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
+    w2 = torch.empty(2 * w_ohwi.numel(), dtype=torch.float16, device=w_ohwi.device)
+    call("df_split_h2", ptr(w_ohwi), ptr(wa), ptr(w2), w_ohwi.numel(), stream())
+    return w2, wa
+
+
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
-           mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False):
+           mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False,
+           amax_out: Optional[torch.Tensor] = None):
+    """amax_out: the slot the output's max |y| is accumulated into (fp16x2 mode; default: a fresh one) -- several producers of one
+    buffer (the two halves of a concatenation) share a slot"""
     prof = PROFILER
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -186,7 +247,26 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
            and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1)
     x3 = (not MFMA_BF16 and not w16 and ks == 3 and stride == 1 and x.elt == 0 and y.elt == 0
           and call("df_conv2d_x3_ok", x, y, ks, stride, mode, epi) == 1)
-    if x3:
+    h2 = x3 and _h2_on()
+    # fp32 mode with the fp16x2 kernels on: every fp32 conv output carries its max |y| for a possible fp16x2 consumer (measured by
+    # the epilogue; outputs that go through BatchNorm + GELU first get theirs from that pass instead)
+    ya = None
+    if h2_active() and y.elt == 0 and epi != EPI_STATS and not w16:
+        ya = amax_out if amax_out is not None else amax_slot(w_ohwi.device)
+        y._amax = ya
+        src = getattr(y, "_src", None)      # the descriptor covers a whole tensor: descriptors made of it later inherit the bound
+        if src is not None:
+            src._df_amax = ya
+    if h2:
+        # fp32-accurate product from TWO fp16 planes per operand with per-tensor power-of-two scales (conv_halo_x3_kernel<NP = 2>:
+        # three MFMAs per operand pair instead of six)
+        w2, wa = _split_h2(w_ohwi)
+        call("df_conv2d_h2", x, ptr(w2), ptr(amax_of(x, w_ohwi.device)), ptr(wa), ptr(bias), y, ks, stride, ks // 2, mode, epi,
+             ptr(scale), ptr(shift), ptr(stats), int(accumulate), ptr(ya), stream())
+    elif ya is not None and not x3:
+        call("df_conv2d_amax", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
+             int(accumulate), ptr(ya), stream())
+    elif x3:
         # fp32-accurate product from three bf16 planes per operand (conv_halo_x3_kernel): the weights are split once per call
         # (they change every optimizer step), the activations in the kernel's staging
         w3 = torch.empty(3 * w_ohwi.numel(), dtype=torch.bfloat16, device=w_ohwi.device)
@@ -215,7 +295,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             m_rows, rpg = y.n * y.h * y.w, y.grp_size * y.h * y.w
             bm = 256 if (bn == 64 and seg == 1 and y.w % 256 == 0 and m_rows % 256 == 0 and (epi != EPI_STATS or rpg % 256 == 0)
                          and os.environ.get("DF_CONV_X3_BM256", "1") != "0") else 128
-            name = f"conv_halo_x3_kernel<{bm},{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{seg},{4 if (bn == 128 or bm == 256) else 8}>"
+            name = f"conv_halo_x3_kernel<{bm},{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{seg},{4 if (bn == 128 or bm == 256) else 8}{',2' if h2 else ''}>"
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"
@@ -294,7 +374,10 @@ def _elt(t: torch.Tensor) -> int:
 
 def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):
     with timed("bn_gelu_apply", bytes=(y.element_size() + (2.0 if z.elt else 4.0)) * y.numel()):          # read y, write z
-        call("df_bn_gelu_apply_t", ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, z, stream())
+        a = amax_slot(y.device) if (h2_active() and z.elt == 0) else None     # max |z| for the fp16x2 convolution that reads z
+        call("df_bn_gelu_apply_t", ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, z, ptr(a), stream())
+        if a is not None:
+            z._amax = a
 
 
 def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
@@ -333,8 +416,11 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
     dy = torch.empty(y.shape, dtype=dy_dtype, device=dev)
     dbp = _f32(nblk, C, device=dev)
     with timed("bn_gelu_bwd_apply", bytes=(gb + y.element_size() + dy.element_size()) * y.numel()):     # read dz, y; write dy
+        a = amax_slot(dev) if (h2_active() and dy_dtype == torch.float32) else None     # max |dy| for the fp16x2 dgrad / wgrad
         call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), _elt(dy), ptr(dbp), nblk,
-             stream())
+             ptr(a), stream())
+        if a is not None:
+            dy._df_amax = a          # _lib.img() hands it on to the descriptors made of this tensor
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
     return dy, dgamma, dbeta, dbias
@@ -382,8 +468,12 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     t16 = bool(x.elt and dy.elt)
     x3 = (not t16 and not MFMA_BF16 and ks == 3 and stride == 1 and row_counts is None
           and call("df_conv2d_wgrad_x3_ok", x, dy, ks, stride) == 1)
+    h2 = x3 and _h2_on()
     if t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
+    elif h2:     # fp32 mode: fp32-accurate product from two scaled fp16 planes per operand (wgrad3_x3_kernel<2>)
+        call("df_conv2d_wgrad_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws),
+             stream())
     elif x3:     # fp32 mode: fp32-accurate product from three bf16 planes per operand (wgrad3_x3_kernel)
         call("df_conv2d_wgrad_x3", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     else:
@@ -391,7 +481,7 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
              int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = ("wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fb'[x.elt]}{'fb'[dy.elt]}"

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import call, ptr, stream
+from ._lib import call, img, ptr, stream
 
 
 def _arena_order(named: List[tuple]) -> List[tuple]:
@@ -417,6 +417,21 @@ class Trainer:
         forward keeps its own tape, the loss kernels produce d(flow) directly and autograd.deflow_backward runs on this thread
         (the autograd path -- DeFlowFn / loss.backward(), which every non-Trainer caller uses -- computes the same launches
         from a worker thread; tests/test_gpu_model.py::test_direct_step_equals_autograd_step)."""
+        model = self.model
+        # fp16x2 convolutions (fp32 mode): a fresh zero-filled pool of max |x| slots for this step, and ONE bound for every weight
+        # tensor -- max |p| over the whole parameter arena (any upper bound serves; the convolutions then need no per-call pass)
+        ops.amax_pool_reset()
+        ops.W_AMAX = None
+        if ops.h2_active() and self.flat.param.is_cuda:
+            wa = ops.amax_slot(self.flat.param.device)
+            call("df_absmax", img(self.flat.param.view(1, 1, -1, 4)), ptr(wa), stream())       # (numel is a multiple of 4)
+            ops.W_AMAX = wa
+        try:
+            return self._forward_backward_impl(batch)
+        finally:
+            ops.W_AMAX = None
+
+    def _forward_backward_impl(self, batch) -> torch.Tensor:
         model = self.model
         if not hasattr(model, "forward_padded") or os.environ.get("DF_TRAINER_AUTOGRAD") == "1":
             model.forward_padded(batch)

@@ -176,8 +176,8 @@ class FastFlow3DUNet(nn.Module):
                 tape.append(("conv", m4, u, 3))
         return v
 
-    def _conv(self, m: nn.Conv2d, x: torch.Tensor, y: DfImg, ks: int, tape: Optional[list]):
-        ops.conv2d(img(x), ops.ohwi(m.weight), m.bias.detach(), y, ks, 1)
+    def _conv(self, m: nn.Conv2d, x: torch.Tensor, y: DfImg, ks: int, tape: Optional[list], amax=None):
+        ops.conv2d(img(x), ops.ohwi(m.weight), m.bias.detach(), y, ks, 1, amax_out=amax)
         if tape is not None:
             tape.append(("conv", m, x, ks))
 
@@ -192,12 +192,17 @@ class FastFlow3DUNet(nn.Module):
                    and _stage_store16_ok(B, 2 * h, 2 * w, outc, dev) and _stage_store16_ok(B, 2 * h, 2 * w, 2 * lat, dev))
         mid = dict(dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
         t = torch.empty(B, h, w, lat, **f32)
-        self._conv(m.u1_u2[0], a, img(t), 1, tape)
+        # fp16x2 mode: ONE max |x| slot for the concatenation -- both 1x1 convolutions accumulate into it (the upsampled half is
+        # made of convex combinations of t, so max |t| bounds it)
+        cat_amax = ops.amax_slot(dev) if (ops.h2_active() and not s16) else None
+        self._conv(m.u1_u2[0], a, img(t), 1, tape, amax=cat_amax)
         cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **mid)
         ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
         if tape is not None:
             tape.append(("up", h, w, lat))
-        self._conv(m.u3, b, img(cat, lat, lat), 1, tape)
+        self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=cat_amax)
+        if cat_amax is not None:
+            cat._df_amax = cat_amax
         u4 = torch.empty(B, 2 * h, 2 * w, outc, **mid)
         self._conv(m.u4_u5[0], cat, img(u4), 3, tape)
         u5 = torch.empty(B, 2 * h, 2 * w, outc, **f32)

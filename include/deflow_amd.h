@@ -188,6 +188,23 @@ int df_conv2d_x3(df_img x, const void* w3, const float* bias, df_img y, int ksiz
                  const float* scale, const float* shift, float* stats_partial, int accumulate, void* stream);
 int df_conv2d_x3_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 int df_split_bf16x3(const float* w, void* out3, int64_t n, void* stream);
+/* The same convolution through TWO fp16 planes per operand ("fp16x2", round 3; conv_halo_x3_kernel<.., NP = 2>): with power-of-
+ * two scales s taken from upper bounds of max|x| and max|w| (device scalars, df_absmax) an fp32 value is x s = hi + lo / 2048 with
+ * hi = fp16(x s), lo = fp16((x s - hi) 2048) -- 22 significant bits -- and x w = [hi hi' + (hi lo' + lo hi') / 2048] / (s s') to
+ * 3 x 2^-22 relative: THREE fp16 MFMAs (v_mfma_f32_32x32x16_f16, two accumulators) instead of six, still far inside the rounding
+ * of the fp32 accumulation over K = 9 Cin terms; elements more than 2^29 below the tensor's maximum lose relative (not absolute)
+ * accuracy.  w2 = df_split_h2 of the weights with w_amax = df_absmax of them; shapes: df_conv2d_x3_ok.
+ * df_absmax: *amax (a float, ZERO-initialised by the caller) <- max(*amax, max |x|) by an integer atomic max of the bit patterns
+ * (exact, order-independent); a bound taken over a larger tensor that contains the operand is as good. */
+int df_absmax(df_img x, float* amax, void* stream);
+int df_split_h2(const float* w, const float* amax, void* out2, int64_t n, void* stream);
+/* y_amax (optional, zero-initialised): the epilogue also leaves max |y| there -- the next fp16x2 kernel's bound, for free.
+ * df_conv2d_amax: df_conv2d (the fp32-MFMA kernels: 1x1, stride 2) with the same by-product. */
+int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y, int ksize,
+                 int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                 int accumulate, float* y_amax, void* stream);
+int df_conv2d_amax(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
+                   const float* scale, const float* shift, float* stats_partial, int accumulate, float* y_amax, void* stream);
 int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);
@@ -215,11 +232,13 @@ int df_bn_gelu_bwd_apply(df_img dz, const float* y, const float* bn_ss, const fl
  * arithmetic in fp32 registers either way.  df_bn_gelu_bwd_apply_t with dy_elt = 1 takes the bias-gradient column sums from
  * the ROUNDED dy (what the weight- and data-gradient kernels read).  Replaces the BatchNorm2d + GELU of ConvWithNorms and its
  * backward [REF decoder.py:202-220] when activations are kept in bfloat16 (Lightning precision="bf16-mixed" keeps them so). */
-int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, void* stream);
+/* z_amax / dy_amax (optional, ZERO-initialised float): the pass also leaves max |z| resp. max |dy| there (integer atomic max of the
+ * bit patterns, as df_absmax) for the fp16x2 convolution kernels that read the tensor next. */
+int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, float* z_amax, void* stream);
 int df_bn_gelu_bwd_reduce_t(df_img dz, const void* y, int y_elt, const float* bn_ss, int imgs_per_group, float* partial, int nblk,
                             void* stream);
 int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const float* bn_ss, const float* coef, int imgs_per_group, void* dy,
-                           int dy_elt, float* dbias_partial, int nblk, void* stream);
+                           int dy_elt, float* dbias_partial, int nblk, float* dy_amax, void* stream);
 int df_colsum_partial(df_img x, float* partial, int nblk, void* stream);
 int df_colsum_finalize(const float* partial, int nblk, int C, int nvals, float* out, int accumulate, void* stream);
 /* first stage for very many partial rows: out[g][total] = sum of row group g (rows split evenly into `groups`);
@@ -246,6 +265,9 @@ int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int 
  * exists for the call (3x3, stride 1, W % 32 == 0, DMA-addressable tensors).  [REF decoder.py:205,213] weight gradient. */
 int df_conv2d_wgrad_x3(df_img x, df_img dy, int ksize, int stride, int pad, float* ws, int splits, float* bias_ws, void* stream);
 int df_conv2d_wgrad_x3_ok(df_img x, df_img dy, int ksize, int stride);
+/* its fp16x2 form (wgrad3_x3_kernel<2>): x_amax / dy_amax as for df_conv2d_h2 */
+int df_conv2d_wgrad_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, int ksize, int stride, int pad, float* ws,
+                       int splits, float* bias_ws, void* stream);
 /* bf16-STORAGE training (round 3): the 3x3 stride-1 weight gradient of BFLOAT16 x and dy (df_img.elt = 1 on both; W % 32 == 0):
  * bf16 tiles by LDS-DMA into a four-deep ring, fragments by transposing LDS reads (ds_read_b64_tr_b16), fp32 accumulation and
  * fp32 split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce exactly as df_conv2d_wgrad_mp.  Replaces the weight

@@ -118,12 +118,12 @@ def test_conv_dgrad_wgrad(dev, cin, cout, k, s, n, h, w):
 # 12-wave ring weight gradient, the 1x1 weight-gradient tiles -- reached directly here, not only through the model tests,
 # so that the DF_CONV_HALO / DF_CONV_W8 / DF_WGRAD_RING legs of test_alternate_kernel_paths switch something
 BIG_CONV_CASES = [  # cin, cout, k, stride, n, h, w, forward kernel, dgrad kernel, wgrad kernel (default switches)
-    # 3x3 stride 1: the fp32-accurate bf16x3 forms since round 3 (DF_CONV_X3=0 / DF_WGRAD_X3=0 legs of the alternate-path matrix
+    # 3x3 stride 1: the fp32-accurate fp16x2 forms since round 3 (DF_CONV_H2=0: three bf16 planes; DF_CONV_X3=0 / DF_WGRAD_X3=0 legs of the alternate-path matrix
     # run the fp32-MFMA kernels conv_halo_kernel / conv_dma_kernel / wgrad3_ring_kernel through the same comparisons)
-    (128, 128, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,128,2,4,1,4>", "conv_halo_x3_kernel<128,128,2,4,1,4>", "wgrad3_x3_kernel"),
-    (64, 64, 3, 1, 2, 32, 256, "conv_halo_x3_kernel<256,64,4,2,1,4>", "conv_halo_x3_kernel<256,64,4,2,1,4>", "wgrad3_x3_kernel"),
-    (128, 64, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,64,4,2,1,8>", "conv_halo_x3_kernel<128,128,2,4,1,4>", "wgrad3_x3_kernel"),
-    (256, 128, 3, 1, 3, 64, 64, "conv_halo_x3_kernel<128,128,2,4,2,4>", "conv_halo_x3_kernel<128,128,2,4,2,4>", "wgrad3_x3_kernel"),
+    (128, 128, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,128,2,4,1,4,2>", "conv_halo_x3_kernel<128,128,2,4,1,4,2>", "wgrad3_x3_kernel<2>"),
+    (64, 64, 3, 1, 2, 32, 256, "conv_halo_x3_kernel<256,64,4,2,1,4,2>", "conv_halo_x3_kernel<256,64,4,2,1,4,2>", "wgrad3_x3_kernel<2>"),
+    (128, 64, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,64,4,2,1,8,2>", "conv_halo_x3_kernel<128,128,2,4,1,4,2>", "wgrad3_x3_kernel<2>"),
+    (256, 128, 3, 1, 3, 64, 64, "conv_halo_x3_kernel<128,128,2,4,2,4,2>", "conv_halo_x3_kernel<128,128,2,4,2,4,2>", "wgrad3_x3_kernel<2>"),
     (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1x1_kernel<128>"),
     (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad3_ring_kernel<16,2,2>"),
 ]
@@ -936,8 +936,8 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
     oc = want.shape[3]
     xd = x.to(dev)
     outs = {}
-    for form in ("x3", "fp32"):
-        monkeypatch.setenv("DF_CONV_X3_TEST", form)
+    for form in ("h2", "x3", "fp32"):
+        monkeypatch.setenv("DF_CONV_H2", "1" if form == "h2" else "0")
         y = torch.zeros(n, h, w, oc, device=dev)
         base = None
         if mode == "dgrad_acc":
@@ -945,7 +945,7 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
             y.copy_(base.to(dev))
         rows = n * h * w
         partial = torch.zeros(rows // ops.conv_tile_m(rows, oc), oc, 2, device=dev) if epi == ops.EPI_STATS else None
-        if form == "x3":
+        if form != "fp32":
             assert call("df_conv2d_x3_ok", img(xd), img(y), 3, 1, conv_mode, epi) == 1
             ops.conv2d(img(xd), wk, bk, img(y), 3, 1, mode=conv_mode, epi=epi, stats=partial, accumulate=mode == "dgrad_acc")
         else:
@@ -954,15 +954,85 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
         torch.cuda.synchronize()
         ref = want + (base.double() if base is not None else 0.0)
         outs[form] = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
-        if partial is not None and form == "x3":
-            check("x3 stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
-            check("x3 stats sumsq", partial.sum(0).cpu()[:, 1], (ref.reshape(-1, oc) ** 2).sum(0).float(), 2e-5)
-    print(f"[parity] conv x3 {mode} {cin}->{cout} @{h}x{w}x{n}: bf16x3 err {outs['x3']:.2e} | fp32-MFMA err {outs['fp32']:.2e} (vs float64)")
-    assert outs["x3"] <= 2e-6, outs
+        if partial is not None and form != "fp32":
+            check(f"{form} stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
+            check(f"{form} stats sumsq", partial.sum(0).cpu()[:, 1], (ref.reshape(-1, oc) ** 2).sum(0).float(), 2e-5)
+    print(f"[parity] conv {mode} {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {outs['h2']:.2e} | bf16x3 err {outs['x3']:.2e} | fp32-MFMA err {outs['fp32']:.2e} (vs float64)")
+    assert outs["x3"] <= 2e-6 and outs["h2"] <= 2e-6, outs
+
+
+def _wide_range(shape, kind, g):
+    """test tensors for the fp16x2 kernels' per-tensor scale: tiny / huge magnitudes, a log-normal spread over ~2^40, one outlier
+    2^20 above everything else (the elements far below the maximum are where two scaled fp16 planes could lose bits)"""
+    x = torch.randn(*shape, generator=g)
+    if kind == "tiny":
+        return x * 3e-12
+    if kind == "huge":
+        return x * 7e8
+    if kind == "lognormal":
+        return x * torch.exp(4.0 * torch.randn(*shape, generator=g))
+    if kind == "outlier":
+        x = x * 1e-3
+        x.view(-1)[12345 % x.numel()] = 1e3
+        return x
+    if kind == "zeros":
+        return torch.zeros(*shape)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["tiny", "huge", "lognormal", "outlier", "zeros"])
+def test_conv_h2_dynamic_range(dev, monkeypatch, kind):
+    """the fp16x2 forms (df_conv2d_h2 / df_conv2d_wgrad_h2) on operands whose scale or spread would break a plain fp16 cast:
+    forward conv and weight gradient against float64; the error -- max-abs relative to the largest output AND rms-relative --
+    must stay within 4x the fp32-MFMA kernels' own error on the same operands (floor 2e-6)."""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call, ptr, stream
+    g = torch.Generator().manual_seed(len(kind))
+    n, h, w, cin, cout = 2, 12, 128, 64, 128
+    x = _wide_range((n, h, w, cin), kind, g)
+    dy = _wide_range((n, h, w, cout), "tiny" if kind == "zeros" else kind, g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5 * (1e-4 if kind == "tiny" else 1.0)
+    w_ohwi = ops.ohwi(wt.to(dev).contiguous(memory_format=torch.channels_last))
+    xd, dyd = x.to(dev), dy.to(dev)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), padding=1).permute(0, 2, 3, 1)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), wref, padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    want_dw = wref.grad.permute(0, 2, 3, 1)
+
+    def errs(got, ref):
+        d = got.cpu().double() - ref
+        return float(d.abs().max() / ref.abs().max().clamp_min(1e-300)), float(d.norm() / ref.norm().clamp_min(1e-300))
+    res = {}
+    for form in ("h2", "fp32"):
+        monkeypatch.setenv("DF_CONV_H2", "1" if form == "h2" else "0")
+        monkeypatch.setenv("DF_CONV_X3", "1" if form == "h2" else "0")
+        monkeypatch.setenv("DF_WGRAD_X3", "1" if form == "h2" else "0")
+        y = torch.empty(n, h, w, cout, device=dev)
+        dw = torch.empty(cout, 3, 3, cin, device=dev)
+        if form == "h2":
+            ops.conv2d(img(xd), w_ohwi, None, img(y), 3, 1)
+            ops.conv2d_wgrad(img(xd), img(dyd), 3, 1, dw)
+        else:
+            call("df_conv2d", img(xd), ptr(w_ohwi), None, img(y), 3, 1, 1, ops.CONV_FWD, ops.EPI_BIAS, None, None, None, 0, stream())
+            splits = call("df_conv2d_wgrad_splits", img(xd), img(dyd), 3, 1)
+            ws = torch.empty(splits * cout * 9 * cin, device=dev)
+            call("df_conv2d_wgrad_mp", img(xd), img(dyd), 3, 1, 1, ptr(ws), splits, None, 0, None, 0, stream())
+            call("df_conv2d_wgrad_reduce", ptr(ws), splits, cout, 9, cin, ptr(dw), 9 * cin, 0, stream())
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all() and torch.isfinite(dw).all()
+        res[form] = errs(y, want) + errs(dw, want_dw)
+    print(f"[parity] fp16x2 range {kind}: conv max/rms {res['h2'][0]:.2e}/{res['h2'][1]:.2e} (fp32-MFMA {res['fp32'][0]:.2e}/{res['fp32'][1]:.2e}); "
+          f"wgrad {res['h2'][2]:.2e}/{res['h2'][3]:.2e} (fp32-MFMA {res['fp32'][2]:.2e}/{res['fp32'][3]:.2e})")
+    if kind == "zeros":
+        assert float(y.abs().max()) == 0.0 and float(dw.abs().max()) == 0.0
+        return
+    for a, b in zip(res["h2"], res["fp32"]):
+        assert a <= max(2e-6, 4 * b), res
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
-def test_wgrad_x3_fp32_accurate(dev, cin, cout, n, h, w):
+def test_wgrad_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w):
     """df_conv2d_wgrad_x3 (wgrad3_x3_kernel): the fp32 weight gradient from three bf16 planes per operand against float64 on the
     same fp32 inputs: <= 2e-6 of the largest entry (the fp32-MFMA ring kernel's own error is printed beside it); bias sums too."""
     import torch.nn.functional as F
@@ -973,7 +1043,10 @@ def test_wgrad_x3_fp32_accurate(dev, cin, cout, n, h, w):
     dy = torch.randn(n, h, w, cout, generator=g).to(dev)
     assert call("df_conv2d_wgrad_x3_ok", img(x), img(dy), 3, 1) == 1
     dw = torch.empty(cout, 3, 3, cin, device=dev)
-    db = ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw, want_bias=True)          # fp32 mode -> the x3 kernel
+    db = ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw, want_bias=True)          # fp32 mode -> the fp16x2 kernel
+    monkeypatch.setenv("DF_CONV_H2", "0")
+    dw3 = torch.empty(cout, 3, 3, cin, device=dev)
+    db3 = ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw3, want_bias=True)        # -> the bf16x3 kernel
     splits = call("df_conv2d_wgrad_splits", img(x), img(dy), 3, 1)
     ws = torch.empty(splits * cout * 9 * cin, device=dev)
     call("df_conv2d_wgrad_mp", img(x), img(dy), 3, 1, 1, ptr(ws), splits, None, 0, None, 0, stream())   # the fp32-MFMA ring kernel
@@ -983,7 +1056,8 @@ def test_wgrad_x3_fp32_accurate(dev, cin, cout, n, h, w):
     wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wref, padding=1).backward(dy.cpu().permute(0, 3, 1, 2).double())
     want = wref.grad.permute(0, 2, 3, 1)
-    e3, er = rel_err(dw, want), rel_err(dw_ring, want)
-    print(f"[parity] wgrad x3 {cin}->{cout} @{h}x{w}x{n}: bf16x3 err {e3:.2e} | fp32-MFMA ring err {er:.2e} (vs float64)")
-    assert e3 <= 2e-6, (e3, er)
-    check("x3 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+    e2, e3, er = rel_err(dw, want), rel_err(dw3, want), rel_err(dw_ring, want)
+    print(f"[parity] wgrad {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {e2:.2e} | bf16x3 err {e3:.2e} | fp32-MFMA ring err {er:.2e} (vs float64)")
+    assert e3 <= 2e-6 and e2 <= 2e-6, (e2, e3, er)
+    check("h2 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+    check("x3 wgrad bias", db3, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)

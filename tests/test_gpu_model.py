@@ -185,7 +185,7 @@ def _bs16_case(dev, monkeypatch, grid, n_pts, tag, golden_dir):
     torch.cuda.synchronize()
     st = mine.last_state
     m0 = st["counts0"].tolist()
-    assert abs(float(loss_m) - float(dg["loss64"])) <= max(1e-4, 4 * abs(float(dg["loss32"]) - float(dg["loss64"])) / abs(float(dg["loss64"]))) * abs(float(dg["loss64"]))
+    assert abs(float(loss_m.detach()) - float(dg["loss64"])) <= max(1e-4, 4 * abs(float(dg["loss32"]) - float(dg["loss64"])) / abs(float(dg["loss64"]))) * abs(float(dg["loss64"]))
     SIG = 4.5
     for b in range(16):
         assert m0[b] == int(dg[f"flow.{b}.count"]), b
@@ -932,7 +932,7 @@ _X3_OFF = {"DF_CONV_X3": "0", "DF_WGRAD_X3": "0"}      # the fp32-MFMA kernels t
                                  {"DF_WGRAD_DMA_ALL": "1", "DF_CONV_HALO": "0", "DF_DENSE_CANVAS_GRAD": "1", **_X3_OFF},
                                  {"DF_WGRAD_RING": "0", "DF_WGRAD_RING_S2": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0", "DF_SIDE_STREAM": "1", **_X3_OFF},
                                  {"DF_WGRAD_RING": "3", "DF_MERGE_CLOUDS": "0", "DF_NO_FUSED_BIAS": "1", **_X3_OFF},
-                                 {**_X3_OFF, "DF_CONV_X3_BM256": "0"}])
+                                 {"DF_CONV_H2": "0", "DF_CONV_X3_BM256": "0"}])      # the bf16x3 forms the fp16x2 ones replaced by default
 def test_alternate_kernel_paths(env):
     """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors), the all-DMA wgrad variants, the
     first-generation GRU kernels with unfused gate weight gradients, and the side-stream weight-gradient schedule stay
@@ -942,7 +942,7 @@ def test_alternate_kernel_paths(env):
     import sys
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_gpu_kernels.py", "tests/test_gpu_model.py",
-                        "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size and not bs16 and not bf16 and not x3", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
+                        "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size and not bs16 and not bf16 and not x3 and not h2", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
