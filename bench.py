@@ -324,17 +324,21 @@ def main():
         except Exception:
             traffic = None
         mfma = {k: v for k, v in summ.items() if v["flops"] > 0 and not k.startswith("gru_")}
-        # conv_halo_x3_kernel / wgrad3_x3_kernel compute the fp32 product as SIX bf16 MFMAs per algorithmic multiply (three bf16
-        # planes per operand): their roof is the dense bf16 MFMA peak / 6 = 416.7 algorithmic TFLOP/s, not
-        # the fp32-MFMA peak (157.3) the round-1/2 kernels were priced against -- which they now exceed
+        # conv_halo_x3_kernel / wgrad3_x3_kernel compute the fp32 product on the 16-bit matrix pipe: the fp16x2
+        # forms (template argument NP = 2, the default since round 3) as THREE fp16 MFMAs per algorithmic multiply -- roof = dense
+        # fp16 MFMA peak (= the bf16 one, 2500) / 3 = 833.3 algorithmic TFLOP/s; the bf16x3 forms (DF_CONV_H2=0) as SIX bf16 MFMAs
+        # -- roof 416.7.  Neither is the fp32-MFMA peak (157.3) the round-1/2 kernels were priced against, which they exceed.
         x3 = "_x3_" in dom
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS
+        nmfma = (3 if dom.rstrip(">").endswith(",2") else 6) if x3 else 1
+        peak = PEAK_BF16_MFMA_TFLOPS / nmfma if x3 else PEAK_F32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                            "frac": achieved / peak, "traffic": traffic, "kernel": dom,
-                           "peak_note": ("fp32-accurate product = 6 exact bf16 x bf16 MFMAs per multiply (bf16x3): peak = 2500 dense bf16 TFLOP/s / 6; "
-                                         "= %.2f of the fp32-MFMA peak (157.3) the fp32 kernels of rounds 1-2 were bound by" % (achieved / PEAK_F32_MFMA_TFLOPS)) if x3
+                           "peak_note": ("fp32-accurate product = %d exact 16-bit MFMAs per multiply (%s): peak = 2500 dense fp16/bf16 TFLOP/s / %d; "
+                                         "achieved = %.2f x the fp32-MFMA peak (157.3) the fp32 kernels of rounds 1-2 were bound by"
+                                         % (nmfma, "fp16x2: two scaled fp16 planes per operand" if nmfma == 3 else "bf16x3: three bf16 planes per operand",
+                                            nmfma, achieved / PEAK_F32_MFMA_TFLOPS)) if x3
                            else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
-                           "executed_bf16_tflops": achieved * 6.0 if x3 else None,
+                           "executed_16bit_tflops": achieved * nmfma if x3 else None,
                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": d["ms"] / d["launches"],
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
