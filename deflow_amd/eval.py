@@ -68,7 +68,7 @@ def main(argv=None):
         from .data import HDF5Dataset, SceneLoader, ShardedSampler
         ds = HDF5Dataset(str(cfg["val_data"]))
         batches = SceneLoader(ds, B, ShardedSampler(len(ds), shuffle=False), device=dev,
-                              num_workers=max(1, int(cfg["num_workers"])), drop_last=False)
+                              num_workers=max(0, int(cfg["num_workers"])), drop_last=False)
     else:
         from .synth import synth_batch
         H = grid_from(cfg)[0]

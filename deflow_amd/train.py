@@ -170,7 +170,7 @@ def main(argv=None):
             path = dst
         ds = HDF5Dataset(path)
         sampler = ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=int(cfg["seed"]))
-        return SceneLoader(ds, B, sampler, device=dev, num_workers=max(1, int(cfg["num_workers"])), drop_last=shuffle), sampler
+        return SceneLoader(ds, B, sampler, device=dev, num_workers=max(0, int(cfg["num_workers"])), drop_last=shuffle), sampler
 
     def synthetic_epoch(epoch):
         for it in range(steps_per_epoch):
