@@ -1016,7 +1016,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   constexpr int AP = HR * LDH, AB = NP * AP;           // A plane / buffer (floats)
   constexpr int BP = BN * LDH, BSL = NP * BP;          // B plane / ring slot (floats)
   constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
-  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || (BM == 256 && SEG == 1)) && (NP == 2 || NP == 3), "8 waves");
+  static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || BM == 256 || BM == 512) && (SEG == 1 || SEG == 2 || SEG == 4) &&
+                (NP == 2 || NP == 3), "8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                      // [2][NP][HR][LDH]
   float* Bs = lds + 2 * AB;             // [DB][NP][BN][LDH]
@@ -2899,6 +2900,27 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
       p.stats_mul = 2;
     }
     if (h2) {
+      // 128-multiple output channels: 256 x 128 tiles whose waves own 64 x 64 (8 fragment reads per 12 MFMAs instead of 6 per 6 --
+      // the 128 x 128 form reads LDS for as many cycles as it multiplies) where the rows allow: 256 pixels of one image row, two
+      // rows of a W == 128 image, four of a W == 64 one
+      static const int big = getenv("DF_CONV_H2_BM256") ? atoi(getenv("DF_CONV_H2_BM256")) : 1;
+      const int seg = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
+      if (big && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+          M / 256 * p.tiles_n >= 512) {
+        p.tiles_m = (int)(M / 256);
+        p.stats_mul = 2;
+        if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2>(p, s);
+        if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 4, 2>(p, s);
+        return launch_conv_halo_x3<256, 128, 4, 2, 4, 4, 2>(p, s);
+      }
+      // 64 output channels: 512 x 64 tiles (8 x 1 waves of 64 x 64): 512 pixels of one row, or two rows of a W == 256 image
+      const int seg64 = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;
+      if (big && var != 128128 && !two && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (epi != DF_EPI_STATS || rows_per_group % 512 == 0) &&
+          M / 512 >= 512) {
+        p.tiles_m = (int)(M / 512);
+        p.stats_mul = 4;
+        return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2>(p, s);
+      }
       if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4, 2>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8, 2>(p, s);
       if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4, 2>(p, s);
       if (wide) return launch_conv_halo_x3<256, 64, 4, 2, 1, 4, 2>(p, s);

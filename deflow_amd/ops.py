@@ -296,6 +296,14 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             bm = 256 if (bn == 64 and seg == 1 and y.w % 256 == 0 and m_rows % 256 == 0 and (epi != EPI_STATS or rpg % 256 == 0)
                          and os.environ.get("DF_CONV_X3_BM256", "1") != "0") else 128
             name = f"conv_halo_x3_kernel<{bm},{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{seg},{4 if (bn == 128 or bm == 256) else 8}{',2' if h2 else ''}>"
+            seg2 = 1 if y.w % 256 == 0 else 2 if y.w == 128 else 4 if y.w == 64 else 0
+            if (h2 and bn == 128 and seg2 and y.h % seg2 == 0 and m_rows % 256 == 0 and (epi != EPI_STATS or rpg % 256 == 0)
+                    and m_rows // 256 * (y.c // 128) >= 512 and os.environ.get("DF_CONV_H2_BM256", "1") != "0"):
+                name = f"conv_halo_x3_kernel<256,128,4,2,{seg2},4,2>"     # 64 x 64 wave tiles
+            seg64 = 1 if y.w % 512 == 0 else 2 if y.w == 256 else 0
+            if (h2 and bn == 64 and seg64 and y.h % seg64 == 0 and m_rows % 512 == 0 and (epi != EPI_STATS or rpg % 512 == 0)
+                    and m_rows // 512 >= 512 and os.environ.get("DF_CONV_H2_BM256", "1") != "0"):
+                name = f"conv_halo_x3_kernel<512,64,8,1,{seg64},3,2>"
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"

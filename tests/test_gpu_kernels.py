@@ -961,6 +961,50 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
     assert outs["x3"] <= 2e-6 and outs["h2"] <= 2e-6, outs
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,kname", [
+    (128, 128, 2, 256, 256, "conv_halo_x3_kernel<256,128,4,2,1,4,2>"),      # 256 pixels of one row
+    (128, 256, 8, 128, 128, "conv_halo_x3_kernel<256,128,4,2,2,4,2>"),      # two rows of a W == 128 image
+    (256, 128, 32, 64, 64, "conv_halo_x3_kernel<256,128,4,2,4,4,2>"),       # four rows of a W == 64 image
+    (64, 64, 1, 512, 512, "conv_halo_x3_kernel<512,64,8,1,1,3,2>"),         # 512 pixels of one row, 64 output channels
+    (128, 64, 4, 256, 256, "conv_halo_x3_kernel<512,64,8,1,2,3,2>"),        # two rows of a W == 256 image
+])
+@pytest.mark.parametrize("mode", ["fwd_stats", "dgrad_acc"])
+def test_conv_h2_wide_tiles(dev, cin, cout, n, h, w, kname, mode):
+    """the fp16x2 forms whose waves own 64 x 64 of the tile (256 x 128 and 512 x 64 tiles; they need >= 512 tiles, i.e. layers of the
+    size the B = 16 step runs): kernel name asserted, result against the fp32-MFMA kernel on the same operands (itself checked
+    against float64 elsewhere): <= 3e-6 of the largest output, BatchNorm statistics partials (2 / 4 table rows per tile) included"""
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call
+    g = torch.Generator().manual_seed(cin + cout + w)
+    fwd = mode == "fwd_stats"
+    ci, co = cin, cout          # (data-gradient mode: the same [co, 3, 3, ci] operand is read as the transposed, tap-flipped weights)
+    wk = (torch.randn(cout, 3, 3, cin, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+    x = torch.randn(n, h, w, ci, generator=g).to(dev)
+    conv_mode, epi = (ops.CONV_FWD, ops.EPI_STATS) if fwd else (ops.CONV_DGRAD, ops.EPI_BIAS)
+    rows = n * h * w
+    ntile = rows // ops.conv_tile_m(rows, co)
+    base = torch.randn(n, h, w, co, generator=g).to(dev)
+    y1, y0 = base.clone(), base.clone()
+    p1 = torch.full((ntile, co, 2), float("nan"), device=dev) if fwd else None
+    p0 = torch.zeros(ntile, co, 2, device=dev) if fwd else None
+    prof = ops.KernelProfiler()
+    ops.PROFILER = prof
+    try:
+        ops.conv2d(img(x), wk, None, img(y1), 3, 1, mode=conv_mode, epi=epi, stats=p1, accumulate=not fwd)
+    finally:
+        ops.PROFILER = None
+    assert prof.records[0][0] == kname, prof.records[0][0]
+    call("df_conv2d", img(x), ops.ptr(wk), None, img(y0), 3, 1, 1, conv_mode, epi, None, None, ops.ptr(p0), int(not fwd), ops.stream())
+    torch.cuda.synchronize()
+    e = float((y1.double() - y0.double()).abs().max() / y0.double().abs().max())
+    print(f"[parity] {kname} {mode}: vs fp32-MFMA kernel {e:.2e}")
+    assert e <= 3e-6, e
+    if fwd:
+        assert torch.isfinite(p1).all()
+        check("wide-tile stats sum", p1.sum(0)[:, 0], p0.sum(0)[:, 0].cpu(), 2e-5)
+        check("wide-tile stats sumsq", p1.sum(0)[:, 1], p0.sum(0)[:, 1].cpu(), 2e-5)
+
+
 def _wide_range(shape, kind, g):
     """test tensors for the fp16x2 kernels' per-tensor scale: tiny / huge magnitudes, a log-normal spread over ~2^40, one outlier
     2^20 above everything else (the elements far below the maximum are where two scaled fp16 planes could lose bits)"""

@@ -7,7 +7,7 @@
 #   3. the training step with dtype=bf16 only -> <TAG>_bf16_train_kernel_stats.txt
 #   4. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only, as the pool requires) -> HBM bytes per launch
 #   5. SQ counter passes of the dominant conv kernel, fp32 and bf16-operand mode -> <TAG>_pmc_conv_{f32,bf16}.txt
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -47,7 +47,8 @@ done
 F=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
 python $R/tools/rocpd_pmc.py $F $W > $O/${TAG}_pmc_hbm_bytes.txt 2>&1
 python $R/tools/rocpd_pmc.py --json $O/pmc_traffic.json $F $W
-# SQ counters of the dominant conv layer (128->128 3x3 @128^2 x32 forward), fp32 MFMA and bf16-operand MFMA
+# SQ counters of the dominant conv layer (128->128 3x3 @128^2 x32: forward + weight gradient), fp32 mode (the fp16x2 kernels
+# conv_halo_x3_kernel<..,2> / wgrad3_x3_kernel<2>) and bf16 training mode (bf16 storage: conv_halo_w16_kernel<..,true> / wgrad3_tr_kernel)
 cat > /tmp/one.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -55,11 +56,13 @@ import torch
 from deflow_amd import ops
 from deflow_amd._lib import img
 dev = torch.device("cuda")
+bf = os.environ.get("BF") == "1"
+dt = torch.bfloat16 if bf else torch.float32
 n, h, cin, cout = 32, 128, 128, 128
-x = torch.randn(n, h, h, cin, device=dev); w = torch.randn(cout, 3, 3, cin, device=dev) * 0.05
-y = torch.empty(n, h, h, cout, device=dev)
-dy = torch.randn(n, h, h, cout, device=dev); dw = torch.empty(cout, 3, 3, cin, device=dev)
-with ops.mfma_bf16(os.environ.get("BF") == "1"):
+x = torch.randn(n, h, h, cin, device=dev).to(dt); w = torch.randn(cout, 3, 3, cin, device=dev) * 0.05
+y = torch.empty(n, h, h, cout, device=dev, dtype=dt)
+dy = torch.randn(n, h, h, cout, device=dev).to(dt); dw = torch.empty(cout, 3, 3, cin, device=dev)
+with ops.mfma_bf16(bf, bf):
     for _ in range(3):
         ops.conv2d(img(x), w, None, img(y), 3, 1)
         ops.conv2d_wgrad(img(x), img(dy), 3, 1, dw)
@@ -69,14 +72,14 @@ for BF in 0 1; do
   out=$O/${TAG}_pmc_conv_$([ $BF = 1 ] && echo bf16 || echo f32).txt
   rm -f $out
   i=0
-  for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "GRBM_GUI_ACTIVE"; do
+  for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_MFMA" "SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" "GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     BF=$BF rocprofv3 --kernel-trace --pmc $set -d /tmp/pc${BF}_$i -o p -- python /tmp/one.py > /tmp/pc${BF}_$i.log 2>&1
-    for k in conv_halo wgrad3_ring; do
+    for k in conv_halo wgrad3_; do
       python $R/tools/rocpd_pmc.py --raw $k $(find /tmp/pc${BF}_$i -name "*.db" | head -1) >> $out 2>&1 || tail -3 /tmp/pc${BF}_$i.log >> $out
     done
   done
   BF=$BF rocprofv3 --kernel-trace --stats -d /tmp/pcs$BF -o p -- python /tmp/one.py > /dev/null 2>&1
-  stats /tmp/pcs$BF | grep -E "conv_halo|wgrad3_ring" >> $out
+  stats /tmp/pcs$BF | grep -E "conv_halo|wgrad3_" >> $out
 done
 head -8 $O/${TAG}_train_kernel_stats.txt; head -4 $O/${TAG}_bf16_train_kernel_stats.txt; cut -c1-400 $O/${TAG}_bench.json; tail -4 $O/${TAG}_pmc_conv_bf16.txt
