@@ -1005,7 +1005,9 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 // in one accumulator, the two cross terms in a second one that is folded in at the end) instead of six -- half the matrix
 // work of the bf16x3 form, 2 / 3 of its LDS bytes, at an error 3 x 2^-22 per product, i.e. far below the fp32 accumulation's own
 // rounding over K = 9 Cin terms.
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3>
+// NP = 1: ONE bf16 plane -- the bf16-operand training mode (df_conv2d_w16) on this kernel's large tiles; X16: the activations are
+// bfloat16 in memory (bf16-storage training): one 16-byte load per staging item, stored to LDS as it is.
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SW = BM / SEG + 2;                     // halo pixels per segment
@@ -1017,7 +1019,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   constexpr int BP = BN * LDH, BSL = NP * BP;          // B plane / ring slot (floats)
   constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
   static_assert(NW == 8 && (BN == 128 || BN == 64) && DB >= 3 && (BM == 128 || BM == 256 || BM == 512) && (SEG == 1 || SEG == 2 || SEG == 4) &&
-                (NP == 2 || NP == 3), "8 waves");
+                (NP >= 1 && NP <= 3) && (!X16 || NP == 1), "8 waves");
+  constexpr int XE = X16 ? 2 : 4;                       // bytes per activation element in memory
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                      // [2][NP][HR][LDH]
   float* Bs = lds + 2 * AB;             // [DB][NP][BN][LDH]
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     aseg[e] = sg;
     const int sl = aslot ^ ((j >> 2) & 3);
     aoff[e] = (aon[e] && ix >= 0 && ix < wx)
-                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * 4 + p.dshift) : DMA_BAD;
+                  ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx + sl * 8) * XE + p.dshift) : DMA_BAD;
   }
   // weight DMA: a wave moves 16 rows x 64 B of one plane per instruction; plane pl sits pl * N * 9 * K elements further.
   // BN = 64: waves 4 .. 7 repeat the rows of waves 0 .. 3 (same data to the same place) so that EVERY wave issues exactly three
@@ -1067,11 +1070,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   const int brow = ((wave * 16) % BN) + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);
   const unsigned boff = (unsigned)(((int64_t)(n0 + brow) * 9 * p.K + bslot * 8) * 2);
   const unsigned plane_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2);
-  constexpr int NBW = NP, NFA = 2 * NIT;              // VMEM operations per wave: per weight stage / per halo fetch
+  constexpr int NBW = NP, NFA = (X16 ? 1 : 2) * NIT;  // VMEM operations per wave: per weight stage / per halo fetch
 
   // carried scalar offsets (see conv_halo_w16_kernel): halo row / chunk of the NEXT group to fetch, tap (ty, tx, kc) of the next
   // weight stage to issue
-  const unsigned a_row_step = (unsigned)(wx * ldx * 4 - KC * BK * 4);
+  const unsigned a_row_step = (unsigned)(wx * ldx * XE - KC * BK * XE);
   const int dtap = fwd ? p.K * 2 : -p.K * 2;
   unsigned sa_next = 0;
   int ty_next = 0, kc_next = 0;
@@ -1085,24 +1088,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     for (int e = 0; e < NIT; ++e) {
       const unsigned v = (unsigned)(oy + aseg[e] - 1 + ty_next) < (unsigned)hx ? aoff[e] : DMA_BAD;
       ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, sa_next, 0));
-      ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, sa_next, 0));
+      if constexpr (!X16) ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, sa_next, 0));
     }
     if (++kc_next == KC) {
       kc_next = 0;
       ++ty_next;
-      sa_next += a_row_step + BK * 4;
+      sa_next += a_row_step + BK * XE;
     } else {
-      sa_next += BK * 4;
+      sa_next += BK * XE;
     }
   };
-  auto stash_a = [&](int abuf) {                      // registers -> three bf16 (two fp16) planes -> LDS
+  auto stash_a = [&](int abuf) {                      // registers -> three bf16 (two fp16 / one bf16) planes -> LDS
     float* a = As + abuf * AB;
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
       if (e + 1 < NIT || aon[e]) {
+        if constexpr (X16) {                            // eight bfloat16 as loaded
+          *reinterpret_cast<f32x4*>(a + (tid + e * NT) * 4) = ra[e][0];
+          continue;
+        }
         float v[8], r[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        if constexpr (NP == 1) {
+          *reinterpret_cast<bf16x8_t*>(a + (tid + e * NT) * 4) = pack_bf16(v);
+          continue;
+        }
         if constexpr (NP == 2) {
           f16x8_t h, l;
           df_h2_split(v, sx, h, l);
@@ -1177,6 +1188,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     const int sb = (li >> 2) & 3;
 #pragma unroll
     for (int q = 0; q < BK / 16; ++q) {
+      if constexpr (NP == 1) {
+        bf16x8_t a1[TM], b1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int sh = SEG == 1 ? 0 : 2 * ((wm * TM + i) * 32 / (BM / SEG));
+          const int sa = ((li + tx + sh) >> 2) & 3;
+          a1[i] = *reinterpret_cast<const bf16x8_t*>(a + (i * 32 + sh) * LDH + (((2 * q + kh) ^ sa) * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = *reinterpret_cast<const bf16x8_t*>(b0 + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        continue;
+      }
       if constexpr (NP == 2) {
         f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -1300,12 +1327,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false>
 static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
   constexpr int HR = (SEG * (BM / SEG + 2) + 3) / 4 * 4;
   const size_t lds_bytes = (size_t)(2 * NP * HR + DB * NP * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -2941,6 +2968,34 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     p.w_bytes = p.w_bytes / 2;
     p.bf16 = 1;
     static const int w4 = getenv("DF_W16_WAVES4") ? atoi(getenv("DF_W16_WAVES4")) : 0;   // bit 0: 128-wide, bit 1: 64-wide tiles on 4 waves
+    {   // DF_W16_WIDE=1 (A/B; default off): the large tiles of the fp16x2 kernel with ONE bf16 plane (64 x 64 wave tiles: 4 fragment
+        // reads per 4 MFMAs; the 128 x 128 forms below read 3 per 2).  Measured SLOWER than the forms below at the bench shape
+        // (bf16 step 42.8 vs 41.4 ms; 700-930 vs 820-1000 TFLOP/s per layer): with one plane the kernel is not LDS-read-bound, and
+        // this kernel's register-staged halo costs more than conv_halo_w16_kernel's
+      static const int wide = getenv("DF_W16_WIDE") ? atoi(getenv("DF_W16_WIDE")) : 0;
+      const int seg = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
+      if (wide && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+          M / 256 * p.tiles_n >= 512) {
+        p.tiles_m = (int)(M / 256);
+        p.stats_mul = 2;
+        if (x.elt) {
+          if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 8, 1, true>(p, s);
+          if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 8, 1, true>(p, s);
+          return launch_conv_halo_x3<256, 128, 4, 2, 4, 8, 1, true>(p, s);
+        }
+        if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 8, 1, false>(p, s);
+        if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 8, 1, false>(p, s);
+        return launch_conv_halo_x3<256, 128, 4, 2, 4, 8, 1, false>(p, s);
+      }
+      const int seg64 = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;    // 64 output channels: 512 x 64 tiles, 8 x 1 waves
+      if (wide && var == 128064 && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (epi != DF_EPI_STATS || rows_per_group % 512 == 0) &&
+          M / 512 >= 512) {
+        p.tiles_m = (int)(M / 512);
+        p.stats_mul = 4;
+        if (x.elt) return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 8, 1, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 8, 1, true>(p, s);
+        return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 8, 1, false>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 8, 1, false>(p, s);
+      }
+    }
     if (x.elt) {   // bf16 activations in memory: 8-wave forms only
       if (halo_ok) return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 1, true>(p, s) : launch_conv_halo_w16<64, 4, 2, 1, true>(p, s);
       return var == 128128 ? launch_conv_halo_w16<128, 2, 4, 2, true>(p, s) : launch_conv_halo_w16<64, 4, 2, 2, true>(p, s);

@@ -307,6 +307,16 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"
+            m_rows, rpg = y.n * y.h * y.w, y.grp_size * y.h * y.w
+            wide = os.environ.get("DF_W16_WIDE", "0") == "1" and m_rows > 8192
+            seg2 = 1 if y.w % 256 == 0 else 2 if y.w == 128 else 4 if y.w == 64 else 0
+            seg64 = 1 if y.w % 512 == 0 else 2 if y.w == 256 else 0
+            if (wide and bn == 128 and seg2 and y.h % seg2 == 0 and m_rows % 256 == 0 and (epi != EPI_STATS or rpg % 256 == 0)
+                    and m_rows // 256 * (y.c // 128) >= 512):
+                name = f"conv_halo_x3_kernel<256,128,4,2,{seg2},8,1,{'true' if x.elt else 'false'}>"     # one bf16 plane, 64 x 64 wave tiles
+            elif (wide and bn == 64 and seg64 and y.h % seg64 == 0 and m_rows % 512 == 0 and (epi != EPI_STATS or rpg % 512 == 0)
+                    and m_rows // 512 >= 512):
+                name = f"conv_halo_x3_kernel<512,64,8,1,{seg64},8,1,{'true' if x.elt else 'false'}>"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
 
 
