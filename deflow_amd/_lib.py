@@ -65,6 +65,7 @@ _SIGS = {
     "df_conv2d_x3": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_x3_ok": [DfImg, DfImg, I, I, I, I],
     "df_split_bf16x3": [P, P, L, P],
+    "df_split_bf16x2_rows": [P, P, L, I, P],
     "df_absmax": [DfImg, P, P],
     "df_split_h2": [P, P, P, L, P],
     "df_conv2d_h2": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],

@@ -275,6 +275,30 @@ bool img64_ok(const df_img& d, int B) {
 int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
                        int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16, void* stream);
 
+// w [rows][ld] fp32 -> out [rows][hi (ld) | lo (ld)] bf16, hi = bf16(w), lo = bf16(w - hi): the pre-split weight rows of the
+// decoder kernels' mfma_bf16 = 3 form (gemm_dma.h, WStreamT<3>); one pass per optimizer step and weight matrix
+__global__ __launch_bounds__(256) void split_bf16x2_rows_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int64_t n, int ld) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld;
+    const int c = (int)(i - r * ld);
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v;
+    out[r * 2 * ld + c] = hi;
+    out[r * 2 * ld + ld + c] = (__bf16)(v - (float)hi);
+  }
+}
+
+extern "C" int df_split_bf16x2_rows(const float* w, void* out, int64_t rows, int ld, void* stream) {
+  DF_REQUIRE(w && out && rows > 0 && ld > 0 && (ld % 32) == 0 && df_aligned16(out), DF_E_ARG);
+  const int64_t n = rows * ld;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(split_bf16x2_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     reinterpret_cast<__bf16*>(out), n, ld);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
 extern "C" int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const float* offs,
                                   const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts, float* flow,
                                   float* save, void* stream) {

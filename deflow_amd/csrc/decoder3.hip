@@ -28,7 +28,8 @@ struct Gru3Params {
 };
 
 // W16 (with BF): the gate / head weights p.w.{w_zr, w_q, w_1} point at bf16 copies (gemm_dma.h, WStreamT<2>)
-template <bool SAVE, bool BF = false, bool W16 = false>
+// X2 (fp32 training, mfma_bf16 == 3): the same pointers hold the pre-split two-plane weights of WStreamT<3>; planes saved fp32
+template <bool SAVE, bool BF = false, bool W16 = false, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
   float* Aw = As + wave * 16 * LDH;
   const int wp0 = p0 + wave * 16;
   const int64_t grow0 = (int64_t)b * p.N + wp0;
-  constexpr int WSC = W16 ? 2 : 1;                          // weight element offsets in floats: halved for bf16 data
-  const float* a_lane = Aw + li * LDH + lq * (W16 ? 8 : 4);  // W16: a lane's two k groups are adjacent (k = 8 lq .. 8 lq + 7)
+  static_assert(!X2 || (!BF && !W16), "X2 is a mode of its own");
+  constexpr bool K8 = W16 || X2;                            // a lane's two k groups are adjacent (k = 8 lq .. 8 lq + 7)
+  constexpr int WSC = W16 ? 2 : 1;                          // weight ROW offsets in floats: halved for bf16 data (X2: the fp32 pitch)
+  const float* a_lane = Aw + li * LDH + lq * (K8 ? 8 : 4);
   float* c_lane = Aw + 4 * lq * LDH + li;                   // C-layout element (row 4 lq + r, col 16 t + li)
   float* r_lane = Aw + (lane >> 5) * LDH + (lane & 31) * 4;  // row copies: float4 j at r_lane + 2 j LDH
   const unsigned row_bytes = (unsigned)min(max(cnt - wp0, 0), 16) * 512u;
@@ -53,10 +56,9 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
   const float* w_r = p.w.w_zr + 128 * 192 / WSC;
   const float* w_q = p.w.w_q;
 
-  WStreamT<BF ? (W16 ? 2 : 1) : 0> ws;
+  WStreamT<X2 ? 3 : BF ? (W16 ? 2 : 1) : 0> ws;
   wstream_init(ws, Bs);
-  if constexpr (W16) dma_chunk16<128, 192>(w_z, 4, Bs, wave, ws.template voff16<192>());
-  else dma_chunk<128, 192>(w_z, 4, Bs, wave, ws.template voff<192>());   // first chunk of the x projection
+  dma_first<128, 192>(w_z, 4, Bs, ws);   // first chunk of the x projection
 
   // ---- x = offset encoder -> A region (temporarily) -> register fragments ------------------------------------------
   f32x4 xf[4];
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + (W16 ? (k >> 1) * 32 + (k & 1) * 4 : k * 16));
+  for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + (K8 ? (k >> 1) * 32 + (k & 1) * 4 : k * 16));
   __syncthreads();
   // ---- gather h0 = [before | after] -------------------------------------------------------------------------------
   {
@@ -228,7 +230,10 @@ int df_launch_gru_fwd3(df_img before, df_img after, const int32_t* coords, const
   p.plane_stride = p.iter_stride * num_iters;
   const dim3 grid((N + 63) / 64, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (save && mfma_bf16 == 2) hipLaunchKernelGGL((gru_fwd3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
+  if (mfma_bf16 == 3) {
+    if (save) hipLaunchKernelGGL((gru_fwd3_kernel<true, false, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gru_fwd3_kernel<false, false, false, true>), grid, dim3(256), 0, s, p);
+  } else if (save && mfma_bf16 == 2) hipLaunchKernelGGL((gru_fwd3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
   else if (mfma_bf16 == 2) hipLaunchKernelGGL((gru_fwd3_kernel<false, true, true>), grid, dim3(256), 0, s, p);
   else if (save && mfma_bf16) hipLaunchKernelGGL((gru_fwd3_kernel<true, true>), grid, dim3(256), 0, s, p);
   else if (save) hipLaunchKernelGGL((gru_fwd3_kernel<true, false>), grid, dim3(256), 0, s, p);

@@ -48,7 +48,8 @@ struct GruBwd3Params {
 };
 
 // W16 (with BF): p.w.w_1 and p.wt.{wt_zr, wt_q, wt_1} point at bf16 copies (gemm_dma.h, WStreamT<2>)
-template <bool BF, bool W16 = false>
+// X2 (fp32 training, mfma_bf16 == 3): the weight pointers hold the pre-split two-plane rows of WStreamT<3>; planes stay fp32
+template <bool BF, bool W16 = false, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];
@@ -65,8 +66,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   float* Aw = As + wave * 16 * LDH;
   const int wp0 = p0 + wave * 16;
   const int64_t grow0 = (int64_t)b * p.N + wp0;
-  constexpr int WSC = W16 ? 2 : 1;                   // weight element offsets in floats: halved for bf16 data
-  const float* a_lane = Aw + li * LDH + lq * (W16 ? 8 : 4);
+  static_assert(!X2 || (!BF && !W16), "X2 is a mode of its own");
+  constexpr bool K8 = W16 || X2;
+  constexpr int WSC = W16 ? 2 : 1;                   // weight ROW offsets in floats: halved for bf16 data (X2 rows keep the fp32 pitch)
+  constexpr int CSC = K8 ? 2 : 1;                    // weight COLUMN offsets in floats: halved for 16-bit elements
+  const float* a_lane = Aw + li * LDH + lq * (K8 ? 8 : 4);
   float* c_lane = Aw + 4 * lq * LDH + li;            // C-layout element (row 4 lq + r, col 16 t + li) = c_lane[r * LDH + 16 t]
   float* r_lane = Aw + (lane >> 5) * LDH + (lane & 31) * 4;  // row copies: float4 j at r_lane + 2 j LDH
   const unsigned nvalid = (unsigned)min(max(cnt - wp0, 0), 16);  // valid rows of this wave's 16-row tile
@@ -75,10 +79,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
   const float* wt_q = p.wt.wt_q;
   const float* wt_zr = p.wt.wt_zr;
 
-  WStreamT<BF ? (W16 ? 2 : 1) : 0> ws;
+  WStreamT<X2 ? 3 : BF ? (W16 ? 2 : 1) : 0> ws;
   wstream_init(ws, Bs);
-  if constexpr (W16) dma_chunk16<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff16<192>());
-  else dma_chunk<32, 192>(p.w.w_1, 0, Bs, ws.wave, ws.template voff<192>());
+  dma_first<32, 192>(p.w.w_1, 0, Bs, ws);
 
   auto lds_to_rows = [&](float* dst) {  // the wave's 16 x 128 A region -> global rows (coalesced; invalid rows dropped)
     const rsrc_t d = make_rsrc(dst + grow0 * 128, row_bytes);
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     }
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + (W16 ? (k >> 1) * 32 + (k & 1) * 4 : k * 16));
+    for (int k = 0; k < 4; ++k) xf[k] = ld4(a_lane + (K8 ? (k >> 1) * 32 + (k & 1) * 4 : k * 16));
     wave_lds_sync();
   }
   {  // h_T rows -> A region
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) drh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       gemm<128, 4, false, 64, 128, 128>(wt_q, 0, wt_q + 128 * 128 / WSC, 0, a_lane, xf, ws, drh);
-      gemm<64, 4, false, 128, 128, 256>(wt_q + 128 * 128 / WSC, 0, wt_zr + 128 / WSC, 0, a_lane, xf, ws, dxa);
+      gemm<64, 4, false, 128, 128, 256>(wt_q + 128 * 128 / WSC, 0, wt_zr + 128 / CSC, 0, a_lane, xf, ws, dxa);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -288,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void gru_bwd3_kernel(GruBwd3Params p) {
     wave_lds_sync();
     lds_to_plane(pl_r);  // dr_pre replaces r
     colsum(1);
-    gemm<128, 4, false, 64, 256, 256>(wt_zr + 128 / WSC, 0, wt_zr + (128 * 256 + 128) / WSC, 0, a_lane, xf, ws, dh);
-    if (it > 0) gemm<64, 4, false, 128, 256, 256>(wt_zr + (128 * 256 + 128) / WSC, 0, wt_zr, 0, a_lane, xf, ws, dxa);
-    else gemm<64, 4, false, 128, 256, 256>(wt_zr + (128 * 256 + 128) / WSC, 0, nullptr, 0, a_lane, xf, ws, dxa);
+    gemm<128, 4, false, 64, 256, 256>(wt_zr + 128 / CSC, 0, wt_zr + 128 * 256 / WSC + 128 / CSC, 0, a_lane, xf, ws, dh);
+    if (it > 0) gemm<64, 4, false, 128, 256, 256>(wt_zr + 128 * 256 / WSC + 128 / CSC, 0, wt_zr, 0, a_lane, xf, ws, dxa);
+    else gemm<64, 4, false, 128, 256, 256>(wt_zr + 128 * 256 / WSC + 128 / CSC, 0, nullptr, 0, a_lane, xf, ws, dxa);
   }
   // ---- outputs: dh0 [rows,128], dx [rows,64] ----------------------------------------------------------------------
   c_to_lds(dh);
@@ -368,7 +371,8 @@ int df_launch_gru_bwd3(const float* dflow, const float* offs, const int32_t* cou
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.dh0 = dh0; p.dx = dx; p.dpre1 = dpre1; p.xout = xout; p.bias_partial = bias_partial;
-  if (mfma_bf16 == 2) hipLaunchKernelGGL((gru_bwd3_kernel<true, true>), dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16 == 3) hipLaunchKernelGGL((gru_bwd3_kernel<false, false, true>), dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else if (mfma_bf16 == 2) hipLaunchKernelGGL((gru_bwd3_kernel<true, true>), dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else if (mfma_bf16) hipLaunchKernelGGL(gru_bwd3_kernel<true>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(gru_bwd3_kernel<false>, dim3((N + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();

@@ -35,7 +35,11 @@ struct GruWgradParams {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-template <bool BF>
+// X2 (fp32 training, mfma_bf16 == 3; round 3): fp32 planes and tiles as in the fp32 form, but every operand fragment is split in
+// registers into two bf16 planes (hi + lo, 16 significant bits) and each product takes three v_mfma_f32_32x32x16_bf16 (lo hi',
+// hi lo', hi hi') instead of eight v_mfma_f32_32x32x2_f32: 18 MFMAs of 32 cycles per 16-row stage instead of 48 of 64.  The
+// 2^-16 relative error per product is random and the sums run over millions of rows.
+template <bool BF, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WD = BF ? WD_BF : WD_F32, STG = BF ? STG_BF : STG_F32, OPS = BF ? 3 : 5;   // OPS: DMA instructions per wave and stage
@@ -185,6 +189,38 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
       }
       continue;
     }
+    if constexpr (X2) {
+      bf16x8_t ah[2], al[2], bh[3], bl[3];
+      auto split8 = [&](const float* col, int pitch, bf16x8_t& hi, bf16x8_t& lo) {   // rows 8 kh .. 8 kh + 7 of one column
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = col[(8 * kh + k) * pitch];
+          hi[k] = (__bf16)v;
+          lo[k] = (__bf16)(v - (float)hi[k]);
+        }
+      };
+      split8(st + wco * 64 + li, 128, ah[0], al[0]);
+      split8(st + wco * 64 + 32 + li, 128, ah[1], al[1]);
+      if (wci == 0) {   // (wave-uniform, as in the bf16 form)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) split8(st + WP * 128 + 32 * j + li, 128, bh[j], bl[j]);
+      } else {
+        split8(st + WP * 128 + 96 + li, 128, bh[0], bl[0]);
+        split8(st + 2 * WP * 128 + li, 64, bh[1], bl[1]);
+        split8(st + 2 * WP * 128 + 32 + li, 64, bh[2], bl[2]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          f32x16 c = acc[i2][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i2], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i2], bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i2], bh[j], c, 0, 0, 0);
+          acc[i2][j] = c;
+        }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < WP / 2; ++ks) {
       const float a0 = st[a_off + ks * 256], a1 = st[a_off + ks * 256 + 32];
@@ -232,7 +268,8 @@ extern "C" int df_gru_wgrad_mp(const float* save, const float* x, const int32_t*
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.ws = ws;
-  if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  if (mfma_bf16 == 3) hipLaunchKernelGGL((gru_wgrad_kernel<false, true>), dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(gru_wgrad_kernel<false>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;

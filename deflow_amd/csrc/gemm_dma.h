@@ -91,10 +91,18 @@ __device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
 // (16-byte slots swizzled with (row >> 2) & 3), a B fragment is ONE ds_read_b128 of 8 consecutive k -- the fp32-tile form reads
 // two b128 and converts 8 values per fragment and is LDS-bound (16 points per wave: every wave re-reads every weight fragment).
 // The A operand then holds k = 8 lq .. 8 lq + 7 of the chunk (callers pass a_lane = row + 8 lq and load the x registers to match).
+// MODE 3 ("bf16x2", fp32 training; round 3): BOTH operands as two bf16 planes, hi = bf16(v), lo = bf16(v - hi) -- 16 significant
+// bits each -- and three MFMAs per product (lo hi', hi lo', hi hi'; the lo lo' term, <= 2^-16 of the product, is dropped): the
+// gate GEMMs at 16 / 3 of the fp32-MFMA rate with a relative error <= ~2^-15 per product (rms ~1e-5), which averages out over
+// the 128..192-deep sums (measured against float64: tests/test_gpu_kernels.py::test_gru_decoder_golden).  No scales: bf16
+// has the fp32 exponent range.  The weights arrive pre-split per optimizer step as rows of [hi (LDW) | lo (LDW)] bf16 -- the
+// byte pitch of the fp32 row, so ROW offsets in floats are those of the fp32 layout and COLUMN offsets halve -- and go to LDS as
+// two 8 KB tiles per chunk (one weight buffer, exactly); the A operand is split in registers once per chunk.
 template <int MODE>
 struct WStreamT {   // the weight-chunk pipeline state shared by consecutive GEMMs
   static constexpr bool BF = MODE != 0;
-  static constexpr bool W16 = MODE == 2;
+  static constexpr bool W16 = MODE >= 2;
+  static constexpr bool X2 = MODE == 3;
   static constexpr int A2 = W16 ? 4 : 16;   // float offset of a lane's second 4-float k group inside a 32-deep chunk
   float* Bs;
   int par, wave;
@@ -110,6 +118,22 @@ struct WStreamT {   // the weight-chunk pipeline state shared by consecutive GEM
 };
 using WStream = WStreamT<0>;
 
+// MODE 3: chunk `chunk` of both planes of ROWS pre-split weight rows ([hi (LDW) | lo (LDW)] bf16 per row) -> the two halves of
+// one weight buffer
+template <int ROWS, int LDW, class WS>
+__device__ __forceinline__ void dma_chunk_x2(const float* __restrict__ W, int chunk, float* Bbuf, const WS& ws) {
+  static_assert(ROWS <= 128, "two 8 KB plane tiles per weight buffer");
+  dma_chunk16<ROWS, 2 * LDW>(W, chunk, Bbuf, ws.wave, ws.template voff16<2 * LDW>());
+  dma_chunk16<ROWS, 2 * LDW>(W + LDW / 2, chunk, Bbuf + BT / 2, ws.wave, ws.template voff16<2 * LDW>());
+}
+// the first chunk of a kernel's first GEMM, in the stream's mode
+template <int ROWS, int LDW, class WS>
+__device__ __forceinline__ void dma_first(const float* __restrict__ W, int chunk, float* Bbuf, const WS& ws) {
+  if constexpr (WS::X2) dma_chunk_x2<ROWS, LDW>(W, chunk, Bbuf, ws);
+  else if constexpr (WS::W16) dma_chunk16<ROWS, LDW>(W, chunk, Bbuf, ws.wave, ws.template voff16<LDW>());
+  else dma_chunk<ROWS, LDW>(W, chunk, Bbuf, ws.wave, ws.template voff<LDW>());
+}
+
 // acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
 // registers (XA).  Precondition: chunk c0 is in buffer ws.par, barrier passed.  The first chunk of the next GEMM
 // (Wn, cn, ROWS_NEXT rows) is fetched during the last chunk.
@@ -119,6 +143,31 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
   constexpr int NPAIR = ROWS / 32;
   auto chunk = [&](int c, const f32x4 a0, const f32x4 a1) {
     float* nb = ws.Bs + ((ws.par + c + 1) & 1) * BT;
+    if constexpr (WS::X2) {
+      if (c + 1 < NCH) dma_chunk_x2<ROWS, LDW>(W, c0 + c + 1, nb, ws);
+      else if (Wn) dma_chunk_x2<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws);
+      const float* bb = ws.b_lane16 + ((ws.par + c) & 1) * BT;
+      bf16x8_t ah, al;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ah[k] = (__bf16)a0[k];
+        al[k] = (__bf16)(a0[k] - (float)ah[k]);
+        ah[4 + k] = (__bf16)a1[k];
+        al[4 + k] = (__bf16)(a1[k] - (float)ah[4 + k]);
+      }
+#pragma unroll
+      for (int t = 0; t < ROWS / 16; ++t) {
+        const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(bb + t * 256), bl = *reinterpret_cast<const bf16x8_t*>(bb + BT / 2 + t * 256);
+        f32x4 v = acc[t];
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, v, 0, 0, 0);   // small terms first
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, v, 0, 0, 0);
+        acc[t] = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      return;
+    }
     if constexpr (WS::W16) {
       if (c + 1 < NCH) dma_chunk16<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff16<LDW>());
       else if (Wn) dma_chunk16<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff16<LDW_NEXT>());

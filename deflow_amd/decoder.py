@@ -117,6 +117,26 @@ class ConvGRUDecoder(nn.Module):
         W2 = DfGruWeights(W.w_off, W.b_off, ptr(c16[0]), W.b_zr, ptr(c16[1]), W.b_q, ptr(c16[2]), W.b_1, W.w_2, W.b_2)
         return W2, keep + c16
 
+    @staticmethod
+    def _x2_on() -> bool:
+        """fp32 mode: the gate / head GEMMs of the forward and backward kernels as bf16x2 (two bf16 planes per operand, three
+        MFMAs; csrc/gemm_dma.h WStreamT<3>) instead of fp32 MFMA.  DF_GRU_X2=0: the fp32-MFMA form."""
+        return os.environ.get("DF_GRU_X2", "1") != "0" and not os.environ.get("DF_GRU_V1")
+
+    @staticmethod
+    def _split_x2(w: torch.Tensor) -> torch.Tensor:
+        """[rows, cols] fp32 -> [rows, 2, cols] bfloat16 (hi | lo per row)"""
+        w = w.contiguous()
+        out = torch.empty(w.shape[0], 2, w.shape[1], dtype=torch.bfloat16, device=w.device)
+        call("df_split_bf16x2_rows", ptr(w), ptr(out), w.shape[0], w.shape[1], stream())
+        return out
+
+    def _weights_x2(self, W: DfGruWeights, keep: list) -> Tuple[DfGruWeights, list]:
+        w_zr, _, w_q = keep
+        c = [self._split_x2(w_zr), self._split_x2(w_q), self._split_x2(self.decoder[0].weight.detach())]
+        W2 = DfGruWeights(W.w_off, W.b_off, ptr(c[0]), W.b_zr, ptr(c[1]), W.b_q, ptr(c[2]), W.b_1, W.w_2, W.b_2)
+        return W2, keep + c
+
     # -- engine ------------------------------------------------------------------------------------------
     def run(self, before: DfImg, after: DfImg, ps: PointSet, save: bool):
         """-> flow [B,N,3] (rows >= counts[b] are not written), save buffer or None."""
@@ -127,13 +147,16 @@ class ConvGRUDecoder(nn.Module):
         sv = torch.empty((5 * T + 1) * B * N * 128, dtype=torch.float32, device=dev) if save else None
         W, keep = self._weights()
         bf = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
+        x2 = (not bf) and self._x2_on()
         if bf:
             W, keep = self._weights16(W, keep)
+        elif x2:
+            W, keep = self._weights_x2(W, keep)
         # algorithmic work per point (un-hoisted count): 589 824 * T / 4 + 12 870 FLOP; fused-minimum traffic
         # 128 * 4 B gathered + 36 B of coordinates / offsets / flow
         with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
             call("df_gru_decoder_fwd_mp", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
-                 ptr(sv), 2 if bf else 0, stream())
+                 ptr(sv), 2 if bf else 3 if x2 else 0, stream())
         if sv is not None:
             # in bf16 mode planes 0..4 hold bf16 half rows (csrc/decoder3.hip): the backward kernels must run in the mode the
             # forward ran in, whatever ops.MFMA_BF16 says by then
@@ -173,9 +196,13 @@ class ConvGRUDecoder(nn.Module):
         wt_zr = ops.weight_transpose(w_zr.view(256, 1, 1, 192)).view(192, 256)
         wt_q = ops.weight_transpose(w_q.view(128, 1, 1, 192)).view(192, 128)
         wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
+        x2 = (not bf) and self._x2_on()
         if bf:   # the kernels' mfma_bf16 = 2 form: bf16 copies of the GEMM weights
             W, keep = self._weights16(W, keep)
             wt_zr, wt_q, wt_1 = wt_zr.to(torch.bfloat16), wt_q.to(torch.bfloat16), wt_1.to(torch.bfloat16)
+        elif x2:   # mfma_bf16 = 3: two-plane rows of the GEMM weights (fp32 planes; the weight-gradient pass below is unchanged)
+            W, keep = self._weights_x2(W, keep)
+            wt_zr, wt_q, wt_1 = self._split_x2(wt_zr), self._split_x2(wt_q), self._split_x2(wt_1)
         WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
         dh0, dx = torch.empty(BN, 128, **f32), torch.empty(BN, 64, **f32)
         dpre1, xbuf = torch.empty(BN, 32, **f32), torch.empty(BN, 64, **f32)
@@ -186,7 +213,7 @@ class ConvGRUDecoder(nn.Module):
         # gru_wgrad's)
         with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
             call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
-                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), 2 if bf else 0, s)
+                 ptr(dpre1), ptr(xbuf), ptr(bias_partial), 2 if bf else 3 if x2 else 0, s)
         bias_g = torch.empty(772, **f32)
         if nblocks >= 2048:  # tens of thousands of per-workgroup rows: two-stage column sum
             staged = torch.empty(64, 772, **f32)
@@ -234,7 +261,7 @@ class ConvGRUDecoder(nn.Module):
                 nsplit = call("df_gru_wgrad_splits")
                 ws = torch.empty(nsplit, 384, 192, **f32)
                 with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
-                    call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, bf, s)
+                    call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, 3 if x2 else bf, s)
                 dW_all = torch.empty(384, 192, **f32)
                 call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
                 dW_zr, dW_q = dW_all[:256], dW_all[256:]

@@ -308,7 +308,12 @@ int df_gru_decoder_fwd(df_img before, df_img after, const int32_t* coords, const
  * stays fp32.  df_gru_decoder_fwd_mp, df_gru_decoder_bwd_mp and df_gru_wgrad_mp of one step must get the same mfma_bf16 (zero or
  * not).  mfma_bf16 == 2 (forward and backward): the GEMM weights -- wts.w_zr, wts.w_q, wts.w_1 and wtt.wt_zr, wtt.wt_q, wtt.wt_1
  * -- point at bf16 COPIES of the same [rows, cols] arrays (cast once per optimizer step); their tiles are then bf16 in LDS and
- * every weight fragment is one 16-byte read.  All other fields of the weight structs stay fp32. */
+ * every weight fragment is one 16-byte read.  All other fields of the weight structs stay fp32.
+ * mfma_bf16 == 3 (forward and backward; round 3, the default of fp32 training): "bf16x2" -- both operands of every gate / head
+ * GEMM as two bf16 planes (hi + lo: 16 significant bits), three MFMAs per product; planes saved fp32 exactly as with 0 (the
+ * weight-gradient pass gets 0).  The same six weight pointers then hold rows of [hi (cols) | lo (cols)] bfloat16
+ * (df_split_bf16x2_rows of the [rows, cols] fp32 arrays, once per optimizer step). */
+int df_split_bf16x2_rows(const float* w, void* out, int64_t rows, int ld, void* stream);
 int df_gru_decoder_fwd_mp(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts,
                           int B, int N, int num_iters, df_gru_weights wts, float* flow, float* save, int mfma_bf16,
                           void* stream);

@@ -929,7 +929,7 @@ _X3_OFF = {"DF_CONV_X3": "0", "DF_WGRAD_X3": "0"}      # the fp32-MFMA kernels t
 
 
 @pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1", "DF_CONV_WIDE_EPI": "1", "DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1", **_X3_OFF},
-                                 {"DF_WGRAD_DMA_ALL": "1", "DF_CONV_HALO": "0", "DF_DENSE_CANVAS_GRAD": "1", **_X3_OFF},
+                                 {"DF_WGRAD_DMA_ALL": "1", "DF_CONV_HALO": "0", "DF_DENSE_CANVAS_GRAD": "1", "DF_GRU_X2": "0", **_X3_OFF},
                                  {"DF_WGRAD_RING": "0", "DF_WGRAD_RING_S2": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0", "DF_SIDE_STREAM": "1", **_X3_OFF},
                                  {"DF_WGRAD_RING": "3", "DF_MERGE_CLOUDS": "0", "DF_NO_FUSED_BIAS": "1", **_X3_OFF},
                                  {"DF_CONV_H2": "0", "DF_CONV_X3_BM256": "0"}])      # the bf16x3 forms the fp16x2 ones replaced by default
