@@ -359,7 +359,11 @@ def main():
                  "note": note}
             if fl:
                 e["tflops"] = fl / (msx * 1e-3) / 1e12
-                e["frac_mfma_f32"] = e["tflops"] / PEAK_F32_MFMA_TFLOPS
+                # the decoder GEMMs run as bf16x2 (three 16-bit MFMAs per multiply: roof = 2500 / 3) unless DF_GRU_X2=0 (fp32 MFMA: 157.3)
+                x2 = os.environ.get("DF_GRU_X2", "1") != "0"
+                e["mfma_peak_tflops"] = PEAK_BF16_MFMA_TFLOPS / 3.0 if x2 else PEAK_F32_MFMA_TFLOPS
+                e["frac_mfma"] = e["tflops"] / e["mfma_peak_tflops"]
+                e["x_fp32_mfma_peak"] = e["tflops"] / PEAK_F32_MFMA_TFLOPS
             hbm[name] = e
 
         entry("pillarise_fwd", ["pillarise_fwd", "canvas_zero_fill"],
