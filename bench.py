@@ -282,6 +282,13 @@ def main():
         "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # every tensor, accumulator, statistic and the optimizer are fp32; what the GEMMs multiply with (round 3): the 3x3 stride-1
+        # convs and weight gradients as two scaled fp16 planes per operand (22 significant bits, three MFMAs: <= 2e-6 vs float64),
+        # the GRU decoder's GEMMs as two bf16 planes (16 bits, three MFMAs: <= 2.9e-5 vs float64), everything else fp32 MFMA.
+        # DF_CONV_X3=0 DF_WGRAD_X3=0 DF_GRU_X2=0 put every GEMM back on the fp32 MFMA (107 pairs/s, round 2's step)
+        "dtype_note": ("f32 tensors and accumulation; GEMM operands: 3x3 convs fp16x2 (2 scaled fp16 planes, 3 MFMAs), GRU decoder bf16x2 "
+                       "(2 bf16 planes, 3 MFMAs), other layers fp32 MFMA" if (os.environ.get("DF_CONV_X3", "1") != "0" or os.environ.get("DF_GRU_X2", "1") != "0")
+                       else "f32 tensors, accumulation and MFMA operands"),
         "config": {"workload": "deflow train step (deflowLoss, Adam lr=2e-4): BASELINE configs[2] per GPU", "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
                    "parallelism": f"dp{world}", "loss": float(loss)},
