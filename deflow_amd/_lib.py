@@ -174,9 +174,12 @@ def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
     n, h, w, cc = t.shape
     c = cc - c_off if c is None else c
     d = DfImg(t.data_ptr() + t.element_size() * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, _elt(t), 0)
-    a = getattr(t, "_df_amax", None)     # max |t| measured by the kernel that wrote t (ops.bn_gelu_bwd, ops.conv2d): a bound for any view of it
-    if a is not None:
-        d._amax = a
+    # max |t| measured by the kernel that wrote t (ops.bn_gelu_bwd, ops.conv2d): a bound for any view of it -- as long as nobody
+    # has written t since (the kernels write through raw pointers and leave torch's version counter alone; an in-place torch op
+    # bumps it, and the bound is dropped)
+    rec = getattr(t, "_df_amax", None)
+    if rec is not None and rec[1] == t._version:
+        d._amax = rec[0]
     if c_off == 0 and c == cc:
         d._src = t                       # whole-tensor descriptor: a producer may leave the bound on the tensor (ops.conv2d)
     return d

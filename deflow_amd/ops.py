@@ -256,7 +256,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         y._amax = ya
         src = getattr(y, "_src", None)      # the descriptor covers a whole tensor: descriptors made of it later inherit the bound
         if src is not None:
-            src._df_amax = ya
+            src._df_amax = (ya, src._version)
     if h2:
         # fp32-accurate product from TWO fp16 planes per operand with per-tensor power-of-two scales (conv_halo_x3_kernel<NP = 2>:
         # three MFMAs per operand pair instead of six)
@@ -438,7 +438,7 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
         call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), _elt(dy), ptr(dbp), nblk,
              ptr(a), stream())
         if a is not None:
-            dy._df_amax = a          # _lib.img() hands it on to the descriptors made of this tensor
+            dy._df_amax = (a, dy._version)          # _lib.img() hands it on to the descriptors made of this tensor
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
     return dy, dgamma, dbeta, dbias

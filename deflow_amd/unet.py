@@ -202,7 +202,7 @@ class FastFlow3DUNet(nn.Module):
             tape.append(("up", h, w, lat))
         self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=cat_amax)
         if cat_amax is not None:
-            cat._df_amax = cat_amax
+            cat._df_amax = (cat_amax, cat._version)
         u4 = torch.empty(B, 2 * h, 2 * w, outc, **mid)
         self._conv(m.u4_u5[0], cat, img(u4), 3, tape)
         u5 = torch.empty(B, 2 * h, 2 * w, outc, **f32)

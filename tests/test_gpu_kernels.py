@@ -1075,6 +1075,29 @@ def test_conv_h2_dynamic_range(dev, monkeypatch, kind):
         assert a <= max(2e-6, 4 * b), res
 
 
+def test_h2_bound_is_dropped_after_an_inplace_write(dev):
+    """the fp16x2 kernels scale an operand by a bound of max|x| that the PRODUCING kernel left on the tensor object; a torch
+    in-place write after that (here: x 1e6) must invalidate it -- with the stale bound the scaled operand overflows fp16"""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 2, 12, 128, 64
+    x = torch.randn(n, h, w, c, generator=g).to(dev)
+    wt = (torch.randn(c, 3, 3, c, generator=g) * 0.05).to(dev)
+    y = torch.empty(n, h, w, c, device=dev)
+    ops.conv2d(img(x), wt, None, img(y), 3, 1)                 # leaves max|y| on the tensor y
+    assert getattr(y, "_df_amax", None) is not None and getattr(img(y), "_amax", None) is not None
+    y.mul_(1.0e6)                                              # torch writes y: version counter moves
+    assert getattr(img(y), "_amax", None) is None
+    z = torch.empty_like(y)
+    ops.conv2d(img(y), wt, None, img(z), 3, 1)
+    torch.cuda.synchronize()
+    want = F.conv2d(y.cpu().permute(0, 3, 1, 2).double(), wt.cpu().permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(z).all()
+    check("conv after in-place write", z, want.float(), 2e-6)
+
+
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
 def test_wgrad_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w):
     """df_conv2d_wgrad_x3 (wgrad3_x3_kernel): the fp32 weight gradient from three bf16 planes per operand against float64 on the
