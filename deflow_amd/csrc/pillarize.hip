@@ -778,14 +778,40 @@ __global__ void cell_order_kernel(const int32_t* __restrict__ cell_rng, int64_t 
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncells) return;
   const int s = cell_rng[2 * c], e = cell_rng[2 * c + 1];
-  for (int i = s + 1; i < e; ++i) {
-    const uint32_t v = idx_sorted[i];
-    int j = i - 1;
-    while (j >= s && idx_sorted[j] > v) {
-      idx_sorted[j + 1] = idx_sorted[j];
-      --j;
+  const int n = e - s;
+  uint32_t* a = idx_sorted + s;
+  if (n <= 16) {                      // the usual case (a few points per cell): insertion sort
+    for (int i = 1; i < n; ++i) {
+      const uint32_t v = a[i];
+      int j = i - 1;
+      while (j >= 0 && a[j] > v) {
+        a[j + 1] = a[j];
+        --j;
+      }
+      a[j + 1] = v;
     }
-    idx_sorted[j + 1] = v;
+    return;
+  }
+  // a long run (thousands of points in one cell are possible: the caller chooses the cells): heapsort, O(n log n) whatever the
+  // arrival order -- the insertion sort took minutes on a 75 000-element run
+  auto sift = [&](int root, int end) {
+    const uint32_t v = a[root];
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && a[child + 1] > a[child]) ++child;
+      if (a[child] <= v) break;
+      a[root] = a[child];
+      root = child;
+    }
+    a[root] = v;
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+  for (int end = n - 1; end > 0; --end) {
+    const uint32_t t = a[0];
+    a[0] = a[end];
+    a[end] = t;
+    sift(0, end);
   }
 }
 

@@ -1075,6 +1075,62 @@ def test_conv_h2_dynamic_range(dev, monkeypatch, kind):
         assert a <= max(2e-6, 4 * b), res
 
 
+@pytest.mark.parametrize("shape,view", [((3, 7, 64, 32), "whole"), ((2, 5, 32, 128), "pair"), ((1, 1, 1152, 64), "whole"), ((2, 9, 16, 96), "slice")])
+def test_absmax_kernel(dev, shape, view):
+    """df_absmax (the bound every fp16x2 operand is scaled by) against torch on whole tensors, on the 2B-image pair view of a
+    channel-concatenated buffer and on a channel slice; ONE element far above the rest (a first version of the kernel dropped
+    three of every four lanes -- a compiler bug around bit-casting float4 elements -- which only a lone maximum shows), then a
+    second call accumulating into the same slot, and an all-zero tensor"""
+    from deflow_amd._lib import img, img_pair, call, ptr, stream
+    g = torch.Generator().manual_seed(sum(shape))
+    t = torch.randn(*shape, generator=g) * 1e-2
+    for flat in (5, t.numel() // 2 + 3, t.numel() - 2):
+        t.view(-1)[flat] = -37.5 - flat * 1e-3
+        td = t.to(dev)
+        if view == "whole":
+            d, sub = img(td), t
+        elif view == "pair":
+            d, sub = img_pair(td, shape[3] // 2), t
+        else:
+            d, sub = img(td, 32, 32), t[..., 32:64]
+        a = torch.zeros(1, device=dev)
+        call("df_absmax", d, ptr(a), stream())
+        torch.cuda.synchronize()
+        assert float(a) == float(sub.abs().max()), (flat, float(a), float(sub.abs().max()))
+        t.view(-1)[flat] = 0.0
+    big = torch.full((1, 1, 4, 32), 3.0, device=dev)
+    call("df_absmax", img(big), ptr(a), stream())            # accumulates: the slot keeps the larger value
+    z = torch.zeros(1, device=dev)
+    call("df_absmax", img(torch.zeros(2, 3, 8, 32, device=dev)), ptr(z), stream())
+    torch.cuda.synchronize()
+    assert float(a) >= 3.0 and float(z) == 0.0
+
+
+@pytest.mark.parametrize("n,ncells", [(1, 7), (1000, 64), (50000, 4096), (300000, 16 * 256 * 256)])
+def test_cell_sort_is_a_stable_sort(dev, n, ncells):
+    """df_cell_sort (in-tree counting sort of the stand-alone decoder head's cells; replaced the rocPRIM radix sort in round 3):
+    indices grouped by key, ascending inside a group = torch's stable sort; dense [start, end) table; keys >= ncells dropped"""
+    from deflow_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(n)
+    key = torch.randint(0, ncells + max(1, ncells // 8), (n,), generator=g, dtype=torch.int64)      # some beyond ncells: dropped
+    if n > 100:
+        key[: n // 4] = key[0] % ncells                                                             # one very long run
+    kd = key.to(torch.int32).to(dev)
+    idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    rng = torch.full((ncells, 2), -7, dtype=torch.int32, device=dev)
+    ws = torch.empty(call("df_cell_sort_ws_bytes", ncells), dtype=torch.uint8, device=dev)
+    call("df_cell_sort", ptr(kd), n, ncells, ptr(idx), ptr(rng), ptr(ws), stream())
+    torch.cuda.synchronize()
+    valid = key < ncells
+    order = torch.sort(key[valid], stable=True).indices
+    want_idx = torch.nonzero(valid).view(-1)[order]
+    m = int(valid.sum())
+    assert torch.equal(idx[:m].cpu().long(), want_idx)
+    cnt = torch.bincount(key[valid], minlength=ncells)
+    end = torch.cumsum(cnt, 0)
+    assert torch.equal(rng.cpu().long(), torch.stack([end - cnt, end], 1))
+
+
 def test_h2_bound_is_dropped_after_an_inplace_write(dev):
     """the fp16x2 kernels scale an operand by a bound of max|x| that the PRODUCING kernel left on the tensor object; a torch
     in-place write after that (here: x 1e6) must invalidate it -- with the stale bound the scaled operand overflows fp16"""

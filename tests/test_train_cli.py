@@ -94,3 +94,26 @@ def test_epe_metrics_use_scene_file_labels():
     m = evaluate_batch(res, batch)
     assert m["n"] == 39 and m["EPE_FD"] == 1.0 and m["EPE_FS"] == 0.0 and m["EPE_BS"] == 0.0
     assert abs(m["EPE_3way"] - 1 / 3) < 1e-9 and abs(m["EPE"] - 9 / 39) < 1e-6
+
+
+def test_amax_slot_pool_and_version_guard():
+    """host side of the fp16x2 bound bookkeeping (no kernels): slots are distinct zero-filled views of a pool that is renewed when
+    it runs out or on amax_pool_reset(); a bound left on a tensor is handed to descriptors only while nobody wrote the tensor"""
+    import torch
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    ops.amax_pool_reset()
+    a, b = ops.amax_slot("cpu"), ops.amax_slot("cpu")
+    assert a.shape == (1,) and float(a) == 0.0 and a.data_ptr() != b.data_ptr() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    a.fill_(5.0)
+    ops.amax_pool_reset()
+    c = ops.amax_slot("cpu")
+    assert float(c) == 0.0 and c.untyped_storage().data_ptr() != a.untyped_storage().data_ptr() and float(a) == 5.0
+    for _ in range(ops._AMAX_POOL_N + 3):          # running out of slots renews the pool, old slots stay valid
+        d = ops.amax_slot("cpu")
+    assert float(d) == 0.0 and float(c) == 0.0
+    t = torch.zeros(1, 2, 4, 8)
+    t._df_amax = (a, t._version)
+    assert img(t)._amax is a and not hasattr(img(t, 4, 4), "_src") and img(t)._src is t
+    t.add_(1.0)                                     # an in-place torch write: the bound no longer describes the tensor
+    assert not hasattr(img(t), "_amax")
