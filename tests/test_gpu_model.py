@@ -513,6 +513,51 @@ def test_trainer_learns_and_cli_runs(dev, tmp_path):
     assert all(torch.isfinite(v).all() for v in sd["state_dict"].values() if v.dtype.is_floating_point)
 
 
+def test_fp32_trajectory_on_the_16bit_pipe_kernels(dev):
+    """six Adam steps of the DEFAULT fp32 trainer on a 256 x 256 grid -- large enough that the 3x3 convolutions and weight gradients
+    run as the fp16x2 kernels and the GRU decoder as bf16x2 (asserted by kernel name) -- against the fp32 oracle stepping
+    torch.optim.Adam on the same batches: the loss trajectory within 1e-3 relative step by step (the small-grid trajectory test
+    above never reaches these kernels: its layers are narrower than their tiles), the loss must go down"""
+    import deflow_amd
+    from oracle import ref_torch as O
+    from deflow_amd import ops
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+    cfg = dict(voxel_size=[0.4, 0.4, 6], point_cloud_range=[-51.2, -51.2, -3, 51.2, 51.2, 3], grid_feature_size=[256, 256], num_iters=2)
+    torch.manual_seed(77)
+    ref = O.DeFlow(**cfg).train()
+    mine = deflow_amd.DeFlow(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).train()
+    tr = Trainer(mine, lr=2e-4)
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-4)
+    batches = [synth_batch(2, 20000, seed=900 + 7 * i) for i in range(2)]
+    got, want = [], []
+    for i in range(6):
+        b = batches[i % 2]
+        if i == 0:
+            ops.PROFILER = prof = ops.KernelProfiler()
+        try:
+            got.append(float(tr.step(to_dev(b, dev))))
+        finally:
+            ops.PROFILER = None
+        opt.zero_grad()
+        l = O.training_loss(ref(b), b)
+        l.backward()
+        opt.step()
+        want.append(float(l.detach()))
+    names = {r[0] for r in prof.records}
+    assert any(n.startswith("conv_halo_x3_kernel") and n.endswith(",2>") for n in names) and "wgrad3_x3_kernel<2>" in names, names
+    assert deflow_amd.decoder.ConvGRUDecoder._x2_on()
+    print("[parity] fp32 trajectory on the 16-bit-pipe kernels:", [f"{g:.5f}/{w:.5f}" for g, w in zip(got, want)])
+    import parity
+    for i, (g, w) in enumerate(zip(got, want)):
+        e = abs(g - w) / abs(w)
+        parity.record("fp32_16bit_pipe_train", f"loss step {i}", err_vs_fp32_oracle=e, bound=1e-3, ok=e <= 1e-3)
+        assert e <= 1e-3, (i, g, w)
+    assert got[4] < got[0] and got[5] < got[1]
+
+
 def test_edge_cases_empty_ragged_and_big_grid(dev):
     """SURVEY 8(c) edge cases: a sample with no valid point, pc0/pc1 padded to different lengths, and the 1024x1024 grid
     (BASELINE config 5 shape, voxel 0.1 m, 160k points) through the whole engine."""
