@@ -1027,7 +1027,7 @@ def test_training_from_scene_files(dev, tmp_path, capsys):
         if k == 3:
             break
     T.main(["model=deflow", "lr=2e-4", "epochs=1", "batch_size=4", "loss_fn=deflowLoss", "model.target.num_iters=2",
-            "voxel_size=[0.4, 0.4, 6]", f"train_data={root}", f"val_data={root}", "num_workers=2",
+            "voxel_size=[0.4, 0.4, 6]", f"train_data={root}", f"val_data={root}", "num_workers=1",
             f"stage_dir={tmp_path / 'scratch'}", "log_every=1", f"save_checkpoint={tmp_path / 'm.ckpt'}"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     steps = [l for l in lines if "trainer/loss" in l]
