@@ -70,6 +70,7 @@ _SIGS = {
     "df_split_h2": [P, P, P, L, P],
     "df_conv2d_h2": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_amax": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
+    "df_conv2d_h2f": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],

@@ -429,9 +429,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 // offset of a stage is wave-uniform and rides in soffset (SGPR), so per stage a thread only recomputes validity.
 constexpr unsigned DMA_BAD = 0xFFFFFFFFu - (8u << 20);  // + soffset (< 8 MB) never wraps, always out of range
 
-template <int BM, int BN, int WM, int WN, bool BF = false>
+// H2 (fp32 training / inference, round 3; df_conv2d_h2f): fp32 tiles as in the fp32 form, every fragment split in REGISTERS into
+// two scaled fp16 planes (df_h2_split: 22 significant bits) and multiplied as three v_mfma_f32_32x32x16_f16 (hi.hi' in one
+// accumulator, the cross terms in a second one) instead of eight v_mfma_f32_32x32x2_f32 -- the 1x1 and stride-2 convolutions,
+// whose im2col tiles have no halo to share, on the 16-bit matrix pipe.  The split costs ~6 VALU per element and fragment (the
+// kernel becomes VALU-bound: ~1.8x the fp32-MFMA form on the stride-2 layers; the 1x1 layers are HBM-bound either way).
+template <int BM, int BN, int WM, int WN, bool BF = false, bool H2 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
+  static_assert(!(BF && H2), "one operand format");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NW = WM * WN, RP = 8 * NW;       // waves; tile rows one DMA pass of the whole workgroup covers
   constexpr int RA = BM / RP, RB = BN / RP;
@@ -543,6 +549,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x16 acc1[H2 ? TM : 1][H2 ? TN : 1];           // H2: the cross terms (hi lo' + lo hi'), scaled by 2048
+  float sx = 1.f, sw = 1.f;
+  if constexpr (H2) {
+    sx = df_h2_scale(*p.amax_x);
+    sw = df_h2_scale(*p.amax_w);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[i][j][e] = 0.f;
+  }
 
   const int nst = nky * nkx * KC;
   load_stage(0);
@@ -553,6 +571,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
     if (st + 1 < nst) load_stage(buf ^ 1);   // buf^1 was last read in stage st-1; every wave has passed that barrier
     const float* a = As + buf * BM * LDT + (wm * TM * 32 + li) * LDT;
     const float* b = Bs + buf * BN * LDT + (wn * TN * 32 + li) * LDT;
+    if constexpr (H2) {
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+        f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+        auto split = [&](const float* row, float sc, f16x8_t& hi, f16x8_t& lo) {
+          const f32x4 v0 = ld4(row + rslot[2 * q]), v1 = ld4(row + rslot[2 * q + 1]);
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          df_h2_split(v, sc, hi, lo);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split(a + i * 32 * LDT, sx, ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) split(b + j * 32 * LDT, sw, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
     if constexpr (BF) {
       // bf16 operands: k groups (2 q, 2 q + 1) of a lane = 8 k values = one operand of v_mfma_f32_32x32x16_bf16
 #pragma unroll
@@ -597,6 +641,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for the next stage has landed
     __syncthreads();                                     // ... and everyone's
+  }
+  if constexpr (H2) {   // fold the cross terms in and take the two power-of-two scales out (exact multiplications)
+    const float ix = 1.f / sx, iw = 1.f / sw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, m_end, n0, tile_m);
 #endif
@@ -1388,6 +1441,12 @@ static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
   if (p.bf16) {
     DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, true>), (int)lds_bytes);
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
+  if (p.amax_x && p.amax_w) {   // df_conv2d_h2f: fp16x2 on the fragments
+    DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, false, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
     DF_CHECK_LAUNCH();
     return DF_OK;
   }
@@ -2779,6 +2838,17 @@ extern "C" int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const
                      stream, w2, x_amax, w_amax, y_amax);
 }
 
+// fp16x2 for the convolutions WITHOUT a haloed form (1x1, stride 2; conv_dma_kernel<.., H2>): fp32 weights as they are (the
+// fragments are split in registers), x_amax / w_amax as for df_conv2d_h2.  Shapes the 8-wave DMA kernels do not cover run the fp32
+// kernels of df_conv2d (same result class, no error).
+extern "C" int df_conv2d_h2f(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y,
+                             int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift,
+                             float* stats_partial, int accumulate, float* y_amax, void* stream) {
+  DF_REQUIRE(x_amax && w_amax, DF_E_ARG);
+  return conv2d_impl(x, w, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false, stream,
+                     nullptr, x_amax, w_amax, y_amax);
+}
+
 // df_conv2d (fp32 MFMA kernels, any supported shape) that also leaves max |y| in *y_amax (zero-initialised by the caller; see
 // df_absmax): the 1x1 and stride-2 convolutions whose output an fp16x2 convolution reads next
 extern "C" int df_conv2d_amax(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
@@ -2854,7 +2924,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
   p.bf16 = mfma_bf16 != 0;
   p.stats_mul = 1;
-  p.amax_x = p.amax_w = nullptr;
+  p.amax_x = h2_amax_x;      // (used by the fp16x2 forms only: conv_halo_x3_kernel<NP = 2> below, conv_dma_kernel<.., H2>)
+  p.amax_w = h2_amax_w;
   p.amax_y = reinterpret_cast<unsigned*>(y_amax);
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;

@@ -257,12 +257,22 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         src = getattr(y, "_src", None)      # the descriptor covers a whole tensor: descriptors made of it later inherit the bound
         if src is not None:
             src._df_amax = (ya, src._version)
+    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt == 0 and (ks == 1 or stride == 2) and x.c % 64 == 0
+           and getattr(x, "_amax", None) is not None and os.environ.get("DF_CONV_H2F", "1") != "0")
     if h2:
         # fp32-accurate product from TWO fp16 planes per operand with per-tensor power-of-two scales (conv_halo_x3_kernel<NP = 2>:
         # three MFMAs per operand pair instead of six)
         w2, wa = _split_h2(w_ohwi)
         call("df_conv2d_h2", x, ptr(w2), ptr(amax_of(x, w_ohwi.device)), ptr(wa), ptr(bias), y, ks, stride, ks // 2, mode, epi,
              ptr(scale), ptr(shift), ptr(stats), int(accumulate), ptr(ya), stream())
+    elif h2f:
+        # 1x1 / stride-2 convolutions whose input already carries a bound: fp16x2 on the fragments of the DMA-tile kernel
+        wa = W_AMAX
+        if wa is None:
+            wa = amax_slot(w_ohwi.device)
+            call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
+        call("df_conv2d_h2f", x, ptr(w_ohwi), ptr(x._amax), ptr(wa), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift),
+             ptr(stats), int(accumulate), ptr(ya), stream())
     elif ya is not None and not x3:
         call("df_conv2d_amax", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
              int(accumulate), ptr(ya), stream())
@@ -288,7 +298,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
         tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n} {'fb'[x.elt]}{'fb'[y.elt]}"
-        name = _conv_variant(x, y, ks, stride, mode, epi)
+        name = _conv_variant(x, y, ks, stride, mode, epi) + ("/h2" if (h2f and "conv_dma_kernel<128," in _conv_variant(x, y, ks, stride, mode, epi)) else "")
         if x3:   # mirrors conv2d_impl's dispatch of the bf16x3 forms (BM, BN, WM, WN, SEG, DB)
             bn = 128 if y.c % 128 == 0 else 64
             seg = 1 if y.w % 128 == 0 else 2

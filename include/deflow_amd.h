@@ -205,6 +205,11 @@ int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const float* w_a
                  int accumulate, float* y_amax, void* stream);
 int df_conv2d_amax(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad, int mode, int epi,
                    const float* scale, const float* shift, float* stats_partial, int accumulate, float* y_amax, void* stream);
+/* fp16x2 for the convolutions without a haloed form (1x1, stride 2: conv_dma_kernel<.., H2>): the fp32 weights as they are,
+ * fragments split in registers; bounds as for df_conv2d_h2 */
+int df_conv2d_h2f(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y, int ksize,
+                  int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                  int accumulate, float* y_amax, void* stream);
 int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);

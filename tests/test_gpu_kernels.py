@@ -1005,6 +1005,60 @@ def test_conv_h2_wide_tiles(dev, cin, cout, n, h, w, kname, mode):
         check("wide-tile stats sumsq", p1.sum(0)[:, 1], p0.sum(0)[:, 1].cpu(), 2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride,n,h,w,mode", [
+    (64, 128, 3, 2, 4, 128, 128, "fwd_stats"), (128, 256, 3, 2, 4, 128, 128, "fwd_bias"), (128, 64, 3, 2, 4, 64, 64, "dgrad"),
+    (256, 128, 1, 1, 2, 64, 128, "fwd_bias"), (128, 128, 1, 1, 2, 64, 128, "dgrad_acc"), (64, 64, 1, 1, 2, 96, 128, "fwd_bias")])
+def test_conv_h2f_fragments(dev, monkeypatch, cin, cout, ks, stride, n, h, w, mode):
+    """df_conv2d_h2f (conv_dma_kernel<.., H2>: the 1x1 and stride-2 convolutions with their fp32 fragments split into two scaled
+    fp16 planes in registers) against float64: <= 2e-6 of the largest output, the fp32-MFMA kernel beside it; the form is taken
+    only when the input descriptor already carries a bound of max|x| (asserted through the profiler's kernel name)"""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img
+    g = torch.Generator().manual_seed(cin + cout + ks + h)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (ks * ks * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    w_ohwi = ops.ohwi(wt.to(dev).contiguous(memory_format=torch.channels_last))
+    pad = ks // 2
+    if mode.startswith("fwd"):
+        x = torch.randn(n, h, w, cin, generator=g)
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+        wk, bk, conv_mode = w_ohwi, bias.to(dev), ops.CONV_FWD
+        epi = ops.EPI_STATS if mode == "fwd_stats" else ops.EPI_BIAS
+    else:
+        x = torch.randn(n, h, w, cout, generator=g)                       # dy of a conv whose input was [n, h*stride, w*stride, cin]
+        want = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), stride=stride, padding=pad,
+                                  output_padding=stride - 1).permute(0, 2, 3, 1)
+        wk, bk, conv_mode, epi = ops.weight_transpose(w_ohwi), None, ops.CONV_DGRAD, ops.EPI_BIAS
+    oh, ow, oc = want.shape[1], want.shape[2], want.shape[3]
+    xd = x.to(dev)
+    res = {}
+    for form in ("h2f", "fp32"):
+        monkeypatch.setenv("DF_CONV_H2F", "1" if form == "h2f" else "0")
+        y = torch.zeros(n, oh, ow, oc, device=dev)
+        base = None
+        if mode == "dgrad_acc":
+            base = torch.randn(n, oh, ow, oc, generator=torch.Generator().manual_seed(5))
+            y.copy_(base.to(dev))
+        rows = n * oh * ow
+        partial = torch.zeros(rows // ops.conv_tile_m(rows, oc), oc, 2, device=dev) if epi == ops.EPI_STATS else None
+        xi = img(xd)
+        ops.amax_of(xi, dev)                     # the producer's bound (here: measured)
+        ops.PROFILER = prof = ops.KernelProfiler()
+        try:
+            ops.conv2d(xi, wk, bk, img(y), ks, stride, mode=conv_mode, epi=epi, stats=partial, accumulate=mode == "dgrad_acc")
+        finally:
+            ops.PROFILER = None
+        torch.cuda.synchronize()
+        assert prof.records[0][0].endswith("/h2") == (form == "h2f"), prof.records[0][0]
+        ref = want + (base.double() if base is not None else 0.0)
+        res[form] = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        if partial is not None:
+            check(f"{form} stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
+    print(f"[parity] conv h2f {mode} {cin}->{cout} k{ks} s{stride}: fp16x2-on-fragments {res['h2f']:.2e} | fp32-MFMA {res['fp32']:.2e} (vs float64)")
+    assert res["h2f"] <= 2e-6, res
+
+
 def _wide_range(shape, kind, g):
     """test tensors for the fp16x2 kernels' per-tensor scale: tiny / huge magnitudes, a log-normal spread over ~2^40, one outlier
     2^20 above everything else (the elements far below the maximum are where two scaled fp16 planes could lose bits)"""
