@@ -17,7 +17,7 @@ _ERR = {-1: "DF_E_SHAPE", -2: "DF_E_ALIGN", -3: "DF_E_ARG", -4: "DF_E_WORKSPACE"
 class DfImg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
                 ("ld", C.c_int32), ("grp_size", C.c_int32), ("img_stride", C.c_int64), ("grp_off", C.c_int64),
-                ("elt", C.c_int32), ("reserved", C.c_int32)]   # elt: 0 = float32, 1 = bfloat16 (bf16-storage training)
+                ("elt", C.c_int32), ("reserved", C.c_int32)]   # elt: 0 = float32, 1 = bfloat16 (bf16-storage training), 2 = pre-split fp16x2 planes ("h2", round 4)
 
 
 class DfGeom(C.Structure):
@@ -71,6 +71,19 @@ _SIGS = {
     "df_conv2d_h2": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_amax": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2f": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
+    "df_conv2d_h2p": [DfImg, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P, P],
+    "df_conv2d_h2p_ok": [DfImg, DfImg, I, I, I, I],
+    "df_conv2d_yh2": [DfImg, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P],
+    "df_conv2d_wgrad_h2p": [DfImg, DfImg, P, P, I, I, I, P, I, P, P],
+    "df_conv2d_wgrad_h2p_ok": [DfImg, DfImg, I, I],
+    "df_conv2d_wgrad_h2p_splits": [DfImg, DfImg],
+    "df_bn_finalize2": [P, I, I, I, L, P, P, F, F, P, P, P, P, I, P, P, P],
+    "df_bn_bwd_finalize2": [P, I, I, I, L, P, P, P, P, P, P, P, P],
+    "df_upsample2x_h2": [DfImg, DfImg, I, P, P],
+    "df_h2_pack": [DfImg, P, DfImg, P],
+    "df_h2_unpack": [DfImg, P, DfImg, P],
+    "df_rows_l1max": [P, I, I, P, I, P, P, P],
+    "df_h2_bound": [P, P, P, P, P, F, P],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],
@@ -118,7 +131,7 @@ _SIGS = {
     "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
 _RESTYPE = {"df_cell_sort_ws_bytes": C.c_int64}
-_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_h2p_ok", "df_conv2d_wgrad_h2p_ok", "df_conv2d_wgrad_h2p_splits", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 
@@ -174,6 +187,12 @@ def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
     assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2), (t.shape, t.stride())
     n, h, w, cc = t.shape
     c = cc - c_off if c is None else c
+    h2 = getattr(t, "_df_h2", None)     # h2 tensor (ops.h2_empty): float32 storage holding [hi | lo] fp16 lines; _df_h2 = the bound that defines its scale
+    if h2 is not None:
+        assert c % 32 == 0 and c_off % 32 == 0 and t.stride(2) % 32 == 0, "h2 images are addressed in whole 32-channel chunks"
+        d = DfImg(t.data_ptr() + 4 * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, 2, 0)
+        d._amax = h2
+        return d
     d = DfImg(t.data_ptr() + t.element_size() * c_off, n, h, w, c, t.stride(2), n, t.stride(0), 0, _elt(t), 0)
     # max |t| measured by the kernel that wrote t (ops.bn_gelu_bwd, ops.conv2d): a bound for any view of it -- as long as nobody
     # has written t since (the kernels write through raw pointers and leave torch's version counter alone; an in-place torch op
@@ -191,4 +210,5 @@ def img_pair(t: torch.Tensor, c: int) -> DfImg:
     This is how the shared encoder reads/writes torch.cat((pc0_x, pc1_x), dim=1) without a copy."""
     assert t.dim() == 4 and t.shape[3] == 2 * c and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
     n, h, w, _ = t.shape
+    assert getattr(t, "_df_h2", None) is None
     return DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c, _elt(t), 0)

@@ -84,6 +84,7 @@ struct ConvParams {
   const float* amax_x;   // fp16x2 form (conv_halo_x3_kernel<.., NP = 2>): upper bounds of max|x| and max|w| (device scalars) that
   const float* amax_w;   // set the power-of-two scales of the two fp16 planes
   unsigned* amax_y;      // optional: the epilogue leaves max |y| there (bit pattern, atomic max) for an fp16x2 consumer of y
+  const float* bound_y;  // y.elt == 2 (pre-split output): the bound of max |y| that defines the output's power-of-two scale
 };
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
@@ -139,9 +140,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // statistics are taken from the ROUNDED values, i.e. of the tensor the normalisation pass will actually read.
     constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
-    auto body = [&](auto y16_tag) {
-      constexpr bool Y16 = decltype(y16_tag)::value;
+    // YH2 (p.y.elt == 2, round 4): y is written PRE-SPLIT for an fp16x2 consumer -- per pixel and 32-channel chunk one 128-byte line
+    // [32 fp16 hi | 32 fp16 lo] of y s, s = df_h2_scale(*p.bound_y) (a bound of max |y| the caller knows before the launch).  A lane
+    // owns one channel of the chunk (li): lanes exchange halves with their neighbour (one DPP move) so that every lane still stores
+    // ONE dword per element -- even lanes the hi pair (channels li, li + 1), odd lanes the lo pair (li - 1, li).
+    auto body = [&](auto y_tag) {
+      constexpr int YT = decltype(y_tag)::value;
+      constexpr bool Y16 = YT == 1, YH2 = YT == 2;
       constexpr int ESZ = Y16 ? 2 : 4;
+      float sy = 1.f;
+      if constexpr (YH2) sy = df_h2_scale(*p.bound_y);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int co = n0 + (wn * TN + j) * 32 + li;
@@ -158,7 +166,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
+            if constexpr (YH2) ob[e] = off >= 0 ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
+            else ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
           }
           float old[16];
           if (p.accumulate) {
@@ -179,6 +188,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
               const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
               __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], 0, 0);
               v = __builtin_bit_cast(float, (unsigned)h << 16);
+            } else if constexpr (YH2) {
+              const float t = v * sy;
+              const _Float16 hi = (_Float16)t;
+              const _Float16 lo = (_Float16)((t - (float)hi) * H2_LO);
+              const unsigned hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
+              const unsigned send = (li & 1) ? hb : lb;                 // odd lanes hand their hi to the even neighbour, even lanes their lo
+              const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+              const unsigned word = (li & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
+              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], 0, 0);
             } else {
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
             }
@@ -200,8 +218,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         }
       }
     };
-    if (p.y.elt) body(std::true_type{});
-    else body(std::false_type{});
+    if (p.y.elt == 2) body(std::integral_constant<int, 2>{});
+    else if (p.y.elt == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1060,14 +1079,23 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 // rounding over K = 9 Cin terms.
 // NP = 1: ONE bf16 plane -- the bf16-operand training mode (df_conv2d_w16) on this kernel's large tiles; X16: the activations are
 // bfloat16 in memory (bf16-storage training): one 16-byte load per staging item, stored to LDS as it is.
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false>
+// XP (round 4, NP = 2 only; df_conv2d_h2 with x.elt = 2): the activations arrive PRE-SPLIT -- x is an "h2" image (per pixel and
+// 32-channel chunk one 128-byte line [32 fp16 hi | 32 fp16 lo] of x s, s = df_h2_scale(*amax_x), written by the producer with
+// the bound amax_x known before it wrote) -- so the halo goes global -> LDS by DMA like the weights: no staging registers, no
+// split in VALU (3.8 VALU per MFMA in the fp32-input form), no LDS stores.  One op = 16 halo rows x 64 B of one plane; every
+// wave issues the same NAO ops per group (spare slots repeat the first ops: same bytes to the same place) so that the counted
+// waits stay compile-time constants.
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SW = BM / SEG + 2;                     // halo pixels per segment
-  constexpr int HR = (SEG * SW + 3) / 4 * 4;           // halo rows (130 / 132 / 258 used)
+  constexpr int HR = XP ? (SEG * SW + 15) / 16 * 16 : (SEG * SW + 3) / 4 * 4;   // halo rows (130 / 132 / 258 used; XP: whole 16-row DMA ops)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NW = WM * WN, NT = 64 * NW;
-  constexpr int NIT = (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte bf16 slot = 8 floats) per thread
+  constexpr int NIT = XP ? 1 : (SEG * SW * 4 + NT - 1) / NT;    // A staging items (one 16-byte bf16 slot = 8 floats) per thread
+  constexpr int NAOPS = NP * HR / 16;                  // XP: 1-KB DMA ops per halo (both planes)
+  constexpr int NAO = (NAOPS + NW - 1) / NW;           // XP: ... per wave
+  static_assert(!XP || (NP == 2 && !X16), "pre-split input: the fp16x2 form only");
   constexpr int AP = HR * LDH, AB = NP * AP;           // A plane / buffer (floats)
   constexpr int BP = BN * LDH, BSL = NP * BP;          // B plane / ring slot (floats)
   constexpr int PD = DB - 1;                           // prefetch distance of the weight ring (stages)
@@ -1123,7 +1151,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   const int brow = ((wave * 16) % BN) + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);
   const unsigned boff = (unsigned)(((int64_t)(n0 + brow) * 9 * p.K + bslot * 8) * 2);
   const unsigned plane_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2);
-  constexpr int NBW = NP, NFA = (X16 ? 1 : 2) * NIT;  // VMEM operations per wave: per weight stage / per halo fetch
+  constexpr int NBW = NP, NFA = XP ? NAO : (X16 ? 1 : 2) * NIT;  // VMEM operations per wave: per weight stage / per halo fetch
+  // XP: op e of this wave = halo op (wave + e NW) mod NAOPS = plane pl, rows rb 16 .. + 15; lane = (row rb 16 + (lane >> 2),
+  // physical slot lane & 3 <- logical 16-byte quarter (lane & 3) ^ ((row >> 2) & 3) of the chunk's 64-byte plane line)
+  unsigned poff[XP ? NAO : 1];
+  int pseg[XP ? NAO : 1], pdst[XP ? NAO : 1];
+  if constexpr (XP) {
+#pragma unroll
+    for (int e = 0; e < NAO; ++e) {
+      const int jo = (wave + e * NW) % NAOPS;
+      const int pl = jo / (HR / 16), rb = jo - pl * (HR / 16);
+      const int j = rb * 16 + (lane >> 2);
+      const int sg = SEG == 1 ? 0 : min(j / SW, SEG - 1);
+      const int ix = ox0 - 1 + j - sg * SW;
+      const int sl = (lane & 3) ^ ((j >> 2) & 3);
+      pseg[e] = sg;
+      pdst[e] = pl * AP + rb * 16 * LDH;
+      poff[e] = (j < SEG * SW && ix >= 0 && ix < wx)
+                    ? (unsigned)((df_img_base(p.x, n) + ((int64_t)(oy + sg - 1) * wx + ix) * ldx) * 4 + pl * 64 + sl * 16 + p.dshift) : DMA_BAD;
+    }
+  }
 
   // carried scalar offsets (see conv_halo_w16_kernel): halo row / chunk of the NEXT group to fetch, tap (ty, tx, kc) of the next
   // weight stage to issue
@@ -1136,12 +1183,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   const int NG = 3 * KC, NS = 3 * NG;
 
   f32x4 ra[NIT][2];
-  auto fetch_a = [&]() {                              // the next group's halo -> registers, then advance the group cursor
+  auto fetch_a = [&](int abuf) {                      // the next group's halo -> registers (XP: -> LDS buffer abuf by DMA), then advance the group cursor
+    if constexpr (XP) {
+      float* a = As + abuf * AB;
+#pragma unroll
+      for (int e = 0; e < NAO; ++e) {
+        const unsigned v = (unsigned)(oy + pseg[e] - 1 + ty_next) < (unsigned)hx ? poff[e] : DMA_BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + pdst[e]), 16, v, sa_next, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
       const unsigned v = (unsigned)(oy + aseg[e] - 1 + ty_next) < (unsigned)hx ? aoff[e] : DMA_BAD;
       ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, sa_next, 0));
       if constexpr (!X16) ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, sa_next, 0));
+    }
     }
     if (++kc_next == KC) {
       kc_next = 0;
@@ -1152,6 +1208,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     }
   };
   auto stash_a = [&](int abuf) {                      // registers -> three bf16 (two fp16 / one bf16) planes -> LDS
+    if constexpr (XP) return;                         // (the DMA wrote the planes)
     float* a = As + abuf * AB;
 #pragma unroll
     for (int e = 0; e < NIT; ++e) {
@@ -1229,10 +1286,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     constexpr bool MAIN = decltype(main_c)::value;
     const float* a0 = As + (g & 1) * AB + (wm * TM * 32 + li) * LDH;
     if constexpr (MAIN) {
-      if (tx == 0) fetch_a();
+      if (tx == 0) fetch_a((g + 1) & 1);
       issue_b();
     } else {
-      if (tx == 0 && g + 1 < NG) fetch_a();
+      if (tx == 0 && g + 1 < NG) fetch_a((g + 1) & 1);
       if (s + PD < NS) issue_b();
     }
     const float* b0 = Bs + cur_slot * BSL + (wn * TN * 32 + li) * LDH;
@@ -1334,7 +1391,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   };
 
   // prologue: halo of group 0, weight stages 0 .. PD - 1 (NS = 27 KC >= PD)
-  fetch_a();
+  fetch_a(0);
 #pragma unroll
   for (int d = 0; d < PD; ++d) issue_b();
   DF_VMCNT(PD * NBW);                                  // the halo loads were issued first
@@ -1380,12 +1437,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false>
 static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
-  constexpr int HR = (SEG * (BM / SEG + 2) + 3) / 4 * 4;
+  constexpr int HR = XP ? (SEG * (BM / SEG + 2) + 15) / 16 * 16 : (SEG * (BM / SEG + 2) + 3) / 4 * 4;
   const size_t lds_bytes = (size_t)(2 * NP * HR + DB * NP * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -2602,6 +2659,263 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
 #endif
 }
 
+// ---- 3x3 stride-1 weight gradient of PRE-SPLIT fp16x2 tensors (round 4; df_conv2d_wgrad_h2p) ------------------------------
+// wgrad3_x3_kernel<2> splits every staged fp32 element in registers (global -> registers -> ~7 VALU per element -> LDS, 5.9
+// VALU + 1.9 LDS instructions per MFMA, the matrix pipe 47 % busy).  Here BOTH operands arrive split: x and dy are "h2" images
+// (df_img.elt = 2) -- per pixel and 32-channel chunk one 128-byte line [32 x fp16 hi | 32 x fp16 lo], the same bytes as the
+// fp32 tensor, written by the producing kernel (BatchNorm + GELU passes, conv epilogues, upsample) with the power-of-two scale
+// of a bound known BEFORE it writes -- so the stage is pure LDS-DMA (no staging registers, no VALU) through a four-deep ring
+// as in wgrad3_tr_kernel, and the loop is transposing reads + MFMAs only.  A 16-byte DMA slot = 8 channels of one plane of one
+// pixel; the LDS image per plane is wgrad3_tr_kernel's ([half][pixel][64 B]: dY 4 KB, X 2 x 3 x 34 x 64 B padded to 13 KB),
+// two planes per stage = 34 one-KB ops over 12 waves = 3 per wave (the two spare slots repeat ops 0 / 1: same bytes to the same
+// place, so that every wave issues the same count and the waits are compile-time constants).
+template <int D>
+__global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 32, XW = P + 2, LC = 64;
+  constexpr int YB = 2 * P * 64;                        // dY image bytes of one plane: [2 halves][32 px][64 B]   = 4096
+  constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows x 34 px][64 B]                     = 6528
+  constexpr int NYO = YB / 1024, NXO = (2 * XH + 1023) / 1024;   // 1-KB DMA ops per plane: 4 + 13
+  constexpr int PLB = (NYO + NXO) * 1024;               // plane stride inside a stage (17408)
+  constexpr int STG = 2 * PLB;                          // stage bytes (34816)
+  constexpr int NOPS = 2 * (NYO + NXO);                 // 34 real ops per stage; 12 waves x 3
+  static_assert(D >= 2 && D <= 4 && NOPS <= 36 && PLB == 17408, "ring");
+  const float sx = df_h2_scale(*p.amax_x), sdy = df_h2_scale(*p.amax_dy);
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int quad = wave & 3, ky = wave >> 2;
+  const int wci = quad & 1, wco = quad >> 1;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {   // all (ci, co) tiles of a split on one XCD: they read the same x / dy tiles (see wgrad3_ring_kernel)
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * LC, co0 = by * LC;
+  const bool do_bias = p.bias_ws && bx == 0;
+  float bsum = 0.f;
+
+  f32x16 acc[3], acc1[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[t][e] = 0.f; acc1[t][e] = 0.f; }
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+
+  // DMA ops of this wave: op j = (wave + 12 i) mod 34 -> plane j / 17, op-in-plane r = j % 17 (r < 4: dY, else X); lane-constant
+  // source bytes relative to the stage's row / segment base, wave-uniform cursor for the rest (no divisions in the loop)
+  bool op_y[3];
+  unsigned loff[3];
+  int lpx[3], lqy[3], ldst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = (wave + 12 * i) % NOPS;
+    const int pl = j / (NYO + NXO), r = j - pl * (NYO + NXO);
+    op_y[i] = r < NYO;
+    ldst[i] = pl * PLB + r * 1024;
+    if (r < NYO) {
+      const int s = r * 64 + lane;                       // 16-byte slot of the dY image: [half][px][4]
+      const int h = s >> 7, px = (s & 127) >> 2, q = s & 3;
+      lpx[i] = px;
+      lqy[i] = 0;
+      loff[i] = (unsigned)((px * p.dy.ld + co0 + 32 * h) * 4 + pl * 64 + q * 16);
+    } else {
+      const int s = (r - NYO) * 64 + lane;               // slot of the X image: [half][row qy][xi][4 slots]
+      const int h = s / (3 * XW * 4), rr = (s - h * 3 * XW * 4) >> 2, q = s & 3;
+      const int qy = rr / XW, xi = rr - qy * XW;
+      const bool on = h < 2 && (ci0 + 32 * h) < p.K;
+      lpx[i] = xi - 1;
+      lqy[i] = on ? qy - 1 : (1 << 28);
+      loff[i] = (unsigned)((((qy - 1) * wx + xi - 1) * p.x.ld + ci0 + 32 * h) * 4 + pl * 64 + q * 16);
+    }
+  }
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wx * p.x.ld) * 4);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 4), xrow_step = (unsigned)(wx * p.x.ld * 4);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 4), xseg_step = (unsigned)(P * p.x.ld * 4);
+  auto issue = [&](int buf) {   // loads the cursor's chunk into ring slot `buf`, then advances the cursor
+    char* slot = ldsb + buf * STG;
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (op_y[i]) {                                     // (wave-uniform)
+        const bool ok = ox0 + lpx[i] < wy;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(slot + ldst[i]), 16, ok ? ybase + loff[i] : DMA_BAD, 0, 0, 0);
+      } else {
+        const bool ok = (unsigned)(cur_oy + lqy[i]) < (unsigned)hx && (unsigned)(ox0 + lpx[i]) < (unsigned)wx;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst[i]), 16, ok ? xbase + loff[i] : DMA_BAD, 0, 0, 0);
+      }
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {   // next image: its base need not follow the previous one
+        cur_oy = 0;
+        ++cur_n;
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
+      }
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+  const int tr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // (see wgrad3_tr_kernel)
+  const unsigned a_base = lds0 + wco * (P * 64) + (8 * kh) * 64 + tr_lane;
+  const unsigned b_base = lds0 + YB + wci * XH + (ky * XW + 8 * kh) * 64 + tr_lane;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto op8 = [](u32x2_t lo, u32x2_t hi) -> f16x8_t {
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < nst) issue(d);
+  for (int i = 0; i < nst; ++i) {
+    // this wave's DMA share of stage i has landed (the ops of up to D - 2 later stages may still be in flight) ...
+    switch (min(D - 2, nst - 1 - i)) {
+      case 2: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D (raw barrier: see wgrad3_tr_kernel)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + D - 1 < nst) issue((i + D - 1) % D);
+    const unsigned so = (unsigned)((i % D) * STG);
+    // The reads of BOTH 16-pixel steps are issued before the first product (two steps x (dY + 3 taps of x) x (hi, lo) x 2 halves of
+    // the 8-deep operand = 32 transposing reads; lgkmcnt is a 4-bit counter, so the first step's 16 + 12 of the second go out, the
+    // wait lgkmcnt(12) covers the first step -- LDS returns in order -- and the last 4 follow): the second step's reads land under
+    // the first step's products -- one exposed LDS latency per stage instead of eight.  The waits carry the registers as
+    // read-write operands so that the compiler cannot move a product in front of the wait that covers its operands.
+    u32x2_t fr[2][16];
+    const unsigned aa0 = a_base + so, ba0 = b_base + so, aa1 = aa0 + 16 * 64, ba1 = ba0 + 16 * 64;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16\n\t"
+        "ds_read_b64_tr_b16 %1, %16 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:17408\n\t"
+        "ds_read_b64_tr_b16 %3, %16 offset:17664\n\t"
+        "ds_read_b64_tr_b16 %4, %17\n\t"
+        "ds_read_b64_tr_b16 %5, %17 offset:256\n\t"
+        "ds_read_b64_tr_b16 %6, %17 offset:17408\n\t"
+        "ds_read_b64_tr_b16 %7, %17 offset:17664\n\t"
+        "ds_read_b64_tr_b16 %8, %17 offset:64\n\t"
+        "ds_read_b64_tr_b16 %9, %17 offset:320\n\t"
+        "ds_read_b64_tr_b16 %10, %17 offset:17472\n\t"
+        "ds_read_b64_tr_b16 %11, %17 offset:17728\n\t"
+        "ds_read_b64_tr_b16 %12, %17 offset:128\n\t"
+        "ds_read_b64_tr_b16 %13, %17 offset:384\n\t"
+        "ds_read_b64_tr_b16 %14, %17 offset:17536\n\t"
+        "ds_read_b64_tr_b16 %15, %17 offset:17792"
+        : "=&v"(fr[0][0]), "=&v"(fr[0][1]), "=&v"(fr[0][2]), "=&v"(fr[0][3]), "=&v"(fr[0][4]), "=&v"(fr[0][5]), "=&v"(fr[0][6]),
+          "=&v"(fr[0][7]), "=&v"(fr[0][8]), "=&v"(fr[0][9]), "=&v"(fr[0][10]), "=&v"(fr[0][11]), "=&v"(fr[0][12]),
+          "=&v"(fr[0][13]), "=&v"(fr[0][14]), "=&v"(fr[0][15])
+        : "v"(aa0), "v"(ba0)
+        : "memory");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12\n\t"
+        "ds_read_b64_tr_b16 %1, %12 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %12 offset:17408\n\t"
+        "ds_read_b64_tr_b16 %3, %12 offset:17664\n\t"
+        "ds_read_b64_tr_b16 %4, %13\n\t"
+        "ds_read_b64_tr_b16 %5, %13 offset:256\n\t"
+        "ds_read_b64_tr_b16 %6, %13 offset:17408\n\t"
+        "ds_read_b64_tr_b16 %7, %13 offset:17664\n\t"
+        "ds_read_b64_tr_b16 %8, %13 offset:64\n\t"
+        "ds_read_b64_tr_b16 %9, %13 offset:320\n\t"
+        "ds_read_b64_tr_b16 %10, %13 offset:17472\n\t"
+        "ds_read_b64_tr_b16 %11, %13 offset:17728"
+        : "=&v"(fr[1][0]), "=&v"(fr[1][1]), "=&v"(fr[1][2]), "=&v"(fr[1][3]), "=&v"(fr[1][4]), "=&v"(fr[1][5]), "=&v"(fr[1][6]),
+          "=&v"(fr[1][7]), "=&v"(fr[1][8]), "=&v"(fr[1][9]), "=&v"(fr[1][10]), "=&v"(fr[1][11])
+        : "v"(aa1), "v"(ba1)
+        : "memory");
+    asm volatile("s_waitcnt lgkmcnt(12)"
+                 : "+v"(fr[0][0]), "+v"(fr[0][1]), "+v"(fr[0][2]), "+v"(fr[0][3]), "+v"(fr[0][4]), "+v"(fr[0][5]), "+v"(fr[0][6]), "+v"(fr[0][7]),
+                   "+v"(fr[0][8]), "+v"(fr[0][9]), "+v"(fr[0][10]), "+v"(fr[0][11]), "+v"(fr[0][12]), "+v"(fr[0][13]), "+v"(fr[0][14]),
+                   "+v"(fr[0][15])
+                 :: "memory");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4 offset:128\n\t"
+        "ds_read_b64_tr_b16 %1, %4 offset:384\n\t"
+        "ds_read_b64_tr_b16 %2, %4 offset:17536\n\t"
+        "ds_read_b64_tr_b16 %3, %4 offset:17792"
+        : "=&v"(fr[1][12]), "=&v"(fr[1][13]), "=&v"(fr[1][14]), "=&v"(fr[1][15])
+        : "v"(ba1)
+        : "memory");
+#pragma unroll
+    for (int ks = 0; ks < P / 16; ++ks) {
+      if (ks == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fr[1][0]), "+v"(fr[1][1]), "+v"(fr[1][2]), "+v"(fr[1][3]), "+v"(fr[1][4]), "+v"(fr[1][5]), "+v"(fr[1][6]), "+v"(fr[1][7]),
+                       "+v"(fr[1][8]), "+v"(fr[1][9]), "+v"(fr[1][10]), "+v"(fr[1][11]), "+v"(fr[1][12]), "+v"(fr[1][13]), "+v"(fr[1][14]),
+                       "+v"(fr[1][15])
+                     :: "memory");
+      }
+      const f16x8_t ah = op8(fr[ks][0], fr[ks][1]), al = op8(fr[ks][2], fr[ks][3]);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f16x8_t bh = op8(fr[ks][4 + 4 * kx], fr[ks][5 + 4 * kx]), bl = op8(fr[ks][6 + 4 * kx], fr[ks][7 + 4 * kx]);
+        acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[kx], 0, 0, 0);
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[kx], 0, 0, 0);
+        acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[kx], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6 (8 groups of 4 pixels): value = hi + lo / 2048 (scaled)
+      const char* stp = ldsb + (i % D) * STG;
+      const int c = tid & 63;
+#pragma unroll
+      for (int j = 0; j < P / 8; ++j) {
+        const int el = (c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31);
+        bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+      }
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (tid < 512) red[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[64 * w + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t * (1.f / sdy);
+    }
+  }
+  if ((ci0 + wci * 32) < p.K) {
+    float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+    const float ix = 1.f / sx, iy = 1.f / sdy;      // exact powers of two
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = (acc[kx][e] + acc1[kx][e] * H2_LO_INV) * ix * iy;
+      }
+  }
+#endif
+}
+
 template <int CIT>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2742,9 +3056,10 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 }
 
 // any16: the caller accepts bfloat16 elements too (then 16-byte alignment is 8 elements)
+// (elt = 2, the pre-split fp16x2 "h2" layout of round 4, has the geometry of the fp32 tensor: 4 bytes per element)
 bool img_ok(const df_img& d, bool any16 = false) {
   const int a = d.elt == 1 ? 8 : 4;
-  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.grp_size > 0 && (d.elt == 0 || (any16 && d.elt == 1)) &&
+  return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.grp_size > 0 && (d.elt == 0 || (any16 && (d.elt == 1 || d.elt == 2))) &&
          (d.n % d.grp_size) == 0 && (d.ld % a) == 0 && (d.img_stride % a) == 0 && (d.grp_off % a) == 0;
 }
 
@@ -2791,7 +3106,8 @@ extern "C" int df_conv2d(df_img x, const float* w, const float* bias, df_img y, 
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr,
-                       const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr);
+                       const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr,
+                       const float* y_bound = nullptr);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -2836,6 +3152,37 @@ extern "C" int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const
   DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax, DF_E_ALIGN);
   return conv2d_impl(x, nullptr, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false,
                      stream, w2, x_amax, w_amax, y_amax);
+}
+
+// ... with PRE-SPLIT tensors (round 4): x may be an h2 image (x.elt = 2, scale = df_h2_scale(*x_amax): x_amax is then the bound
+// that DEFINED the planes, not merely an upper bound) and / or y may be written as one (y.elt = 2, scale from *y_bound, a device
+// scalar >= max |y| the caller knows before the launch; no accumulate).  df_conv2d_h2p_ok answers whether the pre-split-input
+// tile forms exist for a shape (256 x 128 / 512 x 64 tiles: what BASELINE's layers run on).
+extern "C" int df_conv2d_h2p(df_img x, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y,
+                             const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
+                             const float* shift, float* stats_partial, int accumulate, float* y_amax, void* stream) {
+  DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax, DF_E_ALIGN);
+  return conv2d_impl(x, nullptr, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false,
+                     stream, w2, x_amax, w_amax, y_amax, y_bound);
+}
+
+extern "C" int df_conv2d_h2p_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi) {
+  static const int on = getenv("DF_CONV_X3") ? atoi(getenv("DF_CONV_X3")) : 1;
+  if (!on || ksize != 3 || stride != 1) return 0;
+  const float* any = reinterpret_cast<const float*>(x.ptr);
+  const int r = conv2d_impl(x, nullptr, nullptr, nullptr, y, ksize, stride, 1, mode, epi, any, any, const_cast<float*>(any), 0, 0, true,
+                            nullptr, x.ptr, any, any, nullptr, any);
+  return r == 1 ? 1 : 0;
+}
+
+// the fp32-input kernels of df_conv2d_mp / df_conv2d_h2f / df_conv2d_amax with an h2 OUTPUT (y.elt = 2, scale from *y_bound): the
+// 1x1 convolutions that write a half of a pre-split concatenation, the 1x1 data gradients that feed a pre-split 3x3 layer
+extern "C" int df_conv2d_yh2(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y,
+                             const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
+                             const float* shift, float* stats_partial, int accumulate, void* stream) {
+  DF_REQUIRE(y.elt == 2 && y_bound, DF_E_ARG);
+  return conv2d_impl(x, w, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false, stream,
+                     nullptr, x_amax, w_amax, nullptr, y_bound);
 }
 
 // fp16x2 for the convolutions WITHOUT a haloed form (1x1, stride 2; conv_dma_kernel<.., H2>): fp32 weights as they are (the
@@ -2901,12 +3248,19 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3, const float* h2_amax_x,
-                       const float* h2_amax_w, float* y_amax) {
+                       const float* h2_amax_w, float* y_amax, const float* y_bound) {
   if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
-  DF_REQUIRE(img_ok(x, w16 != nullptr) && img_ok(y, true) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
-  const int xes = x.elt ? 2 : 4, yes = y.elt ? 2 : 4;
+  DF_REQUIRE(img_ok(x, w16 != nullptr || (w3 && h2_amax_x)) && img_ok(y, true) && (w16 || (w && df_aligned16(w))), DF_E_ALIGN);
+  DF_REQUIRE((x.elt != 2 || (w3 && h2_amax_x)) && (x.elt != 1 || w16), DF_E_ARG);      // h2 input: the fp16x2 haloed form only
+  // h2 output: a bound, no accumulation (the planes of two scales do not add), whole 32-channel chunks at 128-byte lines
+  if (y.elt == 2)
+    DF_REQUIRE((query || y_bound) && !accumulate && (y.ld % 32) == 0 && (y.img_stride % 32) == 0 && (y.grp_off % 32) == 0 &&
+               (((uintptr_t)y.ptr) & 127) == 0, DF_E_ARG);
+  if (x.elt == 2)
+    DF_REQUIRE((x.ld % 32) == 0 && (x.img_stride % 32) == 0 && (x.grp_off % 32) == 0 && (((uintptr_t)x.ptr) & 127) == 0, DF_E_ARG);
+  const int xes = x.elt == 1 ? 2 : 4, yes = y.elt == 1 ? 2 : 4;
   DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
   DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
   DF_REQUIRE(mode == DF_CONV_FWD || mode == DF_CONV_DGRAD, DF_E_ARG);
@@ -2927,6 +3281,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.amax_x = h2_amax_x;      // (used by the fp16x2 forms only: conv_halo_x3_kernel<NP = 2> below, conv_dma_kernel<.., H2>)
   p.amax_w = h2_amax_w;
   p.amax_y = reinterpret_cast<unsigned*>(y_amax);
+  p.bound_y = y_bound;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -2981,11 +3336,21 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   if (w3) {    // df_conv2d_x3: fp32-accurate product from three bf16 planes per operand (W % 128 == 0, or W == 64 as row pairs)
     const bool two = p.x_bytes && ksize == 3 && stride == 1 && p.cls_tiles == 0 && y.w == 64 && (y.h % 2) == 0 && x.w == y.w &&
                      x.h == y.h && (var == 128128 || var == 128064);
-    const bool ok = (halo_ok || two) && (p.K % BK) == 0 && x.elt == 0 && y.elt == 0;
+    const bool h2 = h2_amax_x != nullptr;        // two fp16 planes (df_conv2d_h2) instead of three bf16 ones
+    const bool xp = x.elt == 2;                  // pre-split input (h2 image): the 256 x 128 / 512 x 64 tile forms below only
+    bool ok = (halo_ok || two) && (p.K % BK) == 0 && (x.elt == 0 || (xp && h2)) && (y.elt == 0 || (y.elt == 2 && h2));
+    if (ok && xp) {
+      const int seg_ = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
+      const int seg64_ = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;
+      const bool big128 = var == 128128 && seg_ && (y.h % seg_) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+                          M / 256 * p.tiles_n >= 512;
+      const bool big64 = var != 128128 && !two && seg64_ && (y.h % seg64_) == 0 && (M % 512) == 0 &&
+                         (epi != DF_EPI_STATS || rows_per_group % 512 == 0) && M / 512 >= 512;
+      ok = big128 || big64;
+    }
     if (query) return ok ? 1 : 0;
     DF_REQUIRE(ok, DF_E_SHAPE);
     p.w = reinterpret_cast<const float*>(w3);
-    const bool h2 = h2_amax_x != nullptr;        // two fp16 planes (df_conv2d_h2) instead of three bf16 ones
     p.w_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2 * (h2 ? 2 : 3));
     p.bf16 = 0;
     p.amax_x = h2_amax_x;
@@ -3007,6 +3372,11 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
           M / 256 * p.tiles_n >= 512) {
         p.tiles_m = (int)(M / 256);
         p.stats_mul = 2;
+        if (xp) {
+          if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2, false, true>(p, s);
+          if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 4, 2, false, true>(p, s);
+          return launch_conv_halo_x3<256, 128, 4, 2, 4, 4, 2, false, true>(p, s);
+        }
         if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2>(p, s);
         if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 4, 2>(p, s);
         return launch_conv_halo_x3<256, 128, 4, 2, 4, 4, 2>(p, s);
@@ -3017,8 +3387,10 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
           M / 512 >= 512) {
         p.tiles_m = (int)(M / 512);
         p.stats_mul = 4;
+        if (xp) return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2, false, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2, false, true>(p, s);
         return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2>(p, s);
       }
+      DF_REQUIRE(!xp, DF_E_SHAPE);
       if (two) return var == 128128 ? launch_conv_halo_x3<128, 128, 2, 4, 2, 4, 2>(p, s) : launch_conv_halo_x3<128, 64, 4, 2, 2, 8, 2>(p, s);
       if (var == 128128) return launch_conv_halo_x3<128, 128, 2, 4, 1, 4, 2>(p, s);
       if (wide) return launch_conv_halo_x3<256, 64, 4, 2, 1, 4, 2>(p, s);
@@ -3283,6 +3655,60 @@ static int wgrad_x3_impl(df_img x, df_img dy, const float* x_amax, const float* 
   p.xcd_map = xcd_map;
   if (x_amax) return launch_wgrad_dma(wgrad3_x3_kernel<2>, grid, 2 * 2 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
   return launch_wgrad_dma(wgrad3_x3_kernel<3>, grid, 2 * 3 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
+}
+
+// PRE-SPLIT fp16x2 tensors (round 4): x and dy are h2 images (df_img.elt = 2: per pixel and 32-channel chunk one 128-byte line
+// [32 fp16 hi | 32 fp16 lo] of the value scaled by df_h2_scale(bound)); x_bound / dy_bound = the device scalars that DEFINED those
+// scales (the producers' bounds).  Shapes as df_conv2d_wgrad_x3 (3x3, stride 1, W % 32 == 0); splits / workspace / reduce as
+// df_conv2d_wgrad_mp.  DF_WGRAD_H2P_DEPTH = ring depth (2..4, default 4).
+extern "C" int df_conv2d_wgrad_h2p_ok(df_img x, df_img dy, int ksize, int stride) {
+  if (x.elt != 2 || dy.elt != 2) return 0;
+  df_img xf = x, yf = dy;
+  xf.elt = yf.elt = 0;                    // (geometry and extents are those of the fp32 tensor: 4 bytes per element)
+  return df_conv2d_wgrad_x3_ok(xf, yf, ksize, stride) == 1 && (x.ld % 32) == 0 && (dy.ld % 32) == 0 && (x.img_stride % 32) == 0 &&
+         (dy.img_stride % 32) == 0 && (x.grp_off % 32) == 0 && (dy.grp_off % 32) == 0 && (((uintptr_t)x.ptr | (uintptr_t)dy.ptr) & 127) == 0;
+}
+
+// split-K count for df_conv2d_wgrad_h2p: its 144 KB ring leaves ONE 12-wave workgroup per CU, so one resident round is 256
+// workgroups (DF_WGRAD_H2P_BLOCKS); every split non-empty
+extern "C" int df_conv2d_wgrad_h2p_splits(df_img x, df_img dy) {
+  static const int target = getenv("DF_WGRAD_H2P_BLOCKS") ? atoi(getenv("DF_WGRAD_H2P_BLOCKS")) : 256;
+  const int tiles = ((x.c + 63) / 64) * (dy.c / 64);
+  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + 31) / 32);
+  int64_t splits = (target + tiles - 1) / tiles;
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  const int64_t cps = (chunks + splits - 1) / splits;
+  return (int)((chunks + cps - 1) / cps);
+}
+
+extern "C" int df_conv2d_wgrad_h2p(df_img x, df_img dy, const float* x_bound, const float* dy_bound, int ksize, int stride, int pad,
+                                   float* ws, int splits, float* bias_ws, void* stream) {
+  DF_REQUIRE(x_bound && dy_bound && ws && df_aligned16(ws), DF_E_ARG);
+  DF_REQUIRE(pad == 1 && df_conv2d_wgrad_h2p_ok(x, dy, ksize, stride) == 1, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
+  p.amax_x = x_bound; p.amax_dy = dy_bound;
+  p.stride = 1; p.pad = 1; p.K = x.c; p.N = dy.c;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  p.x_bytes = (unsigned)extent(x);
+  p.dy_bytes = (unsigned)extent(dy);
+  p.chunks_per_row = dy.w / 32;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static const int depth = getenv("DF_WGRAD_H2P_DEPTH") ? atoi(getenv("DF_WGRAD_H2P_DEPTH")) : 4;
+  const size_t stage = 2 * 17408;
+  if (depth == 2) return launch_wgrad_dma(wgrad3_h2p_kernel<2>, grid, 2 * stage, s, p, 768);
+  if (depth == 3) return launch_wgrad_dma(wgrad3_h2p_kernel<3>, grid, 3 * stage, s, p, 768);
+  return launch_wgrad_dma(wgrad3_h2p_kernel<4>, grid, 4 * stage, s, p, 768);
 }
 
 // bf16-STORAGE training: 3x3 stride-1 weight gradient of bfloat16 x and dy (wgrad3_tr_kernel); splits / workspace / reduce as

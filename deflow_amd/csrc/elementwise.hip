@@ -39,6 +39,89 @@ __device__ __forceinline__ void stx4(void* base, int64_t idx, f32x4 v) {
   }
 }
 
+// ---- "h2" images (df_img.elt = 2, round 4): a tensor PRE-SPLIT for the fp16x2 convolution / weight-gradient kernels
+// (conv.hip: conv_halo_x3_kernel<.., XP>, wgrad3_h2p_kernel).  Geometry of the fp32 tensor (4 bytes per element, same ld / strides);
+// per pixel and 32-channel chunk ONE 128-byte line [32 x fp16 hi | 32 x fp16 lo] with  x s = hi + lo / 2048,  s = the power of two
+// that puts a BOUND of max |x| into [2^14, 2^15) (df_h2_scale: the bound is a device scalar the producer knows before it writes
+// -- BatchNorm statistics, weight norms -- so nothing synchronises and no second pass is needed).  Any bound within ~2^10 of the
+// true maximum keeps 22 significant bits for every element that matters (see conv.hip); looser ones degrade gracefully: the
+// ABSOLUTE error stays below 2^-36 of the bound.  Requires whole chunks: c, ld, img_stride, grp_off % 32 == 0, 128-byte base.
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float df_h2_scale(float amax) {   // (conv.hip's)
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
+  const int f = min(max(268 - e, 1), 254);
+  return __builtin_bit_cast(float, (unsigned)f << 23);
+}
+// idx = element index of 4 consecutive channels (idx % 4 == 0) inside the image whose base is 128-byte aligned
+__device__ __forceinline__ void st_h2x4(void* base, int64_t idx, f32x4 v, float s) {
+  f16x4_t hi, lo;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = v[k] * s;
+    hi[k] = (_Float16)t;
+    lo[k] = (_Float16)((t - (float)hi[k]) * 2048.f);
+  }
+  char* b = reinterpret_cast<char*>(base) + (idx & ~31ll) * 4 + (idx & 31) * 2;
+  *reinterpret_cast<f16x4_t*>(b) = hi;
+  *reinterpret_cast<f16x4_t*>(b + 64) = lo;
+}
+__device__ __forceinline__ f32x4 ld_h2x4(const void* base, int64_t idx, float inv_s) {
+  const char* b = reinterpret_cast<const char*>(base) + (idx & ~31ll) * 4 + (idx & 31) * 2;
+  const f16x4_t hi = *reinterpret_cast<const f16x4_t*>(b), lo = *reinterpret_cast<const f16x4_t*>(b + 64);
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = ((float)hi[k] + (float)lo[k] * (1.f / 2048.f)) * inv_s;
+  return r;
+}
+__device__ __forceinline__ void df_atomic_amax(unsigned* slot, float v) {   // v >= 0: bit patterns order like the values
+  const unsigned m = __builtin_bit_cast(unsigned, v);
+  if (m > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, m);
+}
+
+// fp32 image -> h2 image (tests, and any producer without a fused form) and back
+__global__ __launch_bounds__(256) void h2_pack_kernel(df_img x, df_img y, const float* __restrict__ bound, int64_t total4, int unpack) {
+  const int C4 = x.c >> 2;
+  const int hw = x.h * x.w;
+  const float s = df_h2_scale(*bound), inv_s = 1.f / s;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    const int64_t xi = df_img_base(x, n) + (int64_t)pix * x.ld + c, yi = df_img_base(y, n) + (int64_t)pix * y.ld + c;
+    if (unpack) st4(reinterpret_cast<float*>(y.ptr) + yi, ld_h2x4(x.ptr, xi, inv_s));
+    else st_h2x4(y.ptr, yi, ld4(reinterpret_cast<const float*>(x.ptr) + xi), s);
+  }
+}
+
+// max over rows of sum |w[row, :]| (and max |bias|): the a-priori bound  max |conv(x)| <= max|x| * max_row ||w_row||_1 + max |b|
+// of a convolution output that is written pre-split.  One block per row; integer atomic max of the bit pattern (exact, order-free).
+__global__ __launch_bounds__(256) void rows_l1max_kernel(const float* __restrict__ w, int row_len, const float* __restrict__ bias, int nbias,
+                                                         unsigned* __restrict__ l1max, unsigned* __restrict__ bmax) {
+  __shared__ float red[4];
+  const float* r = w + (int64_t)blockIdx.x * row_len;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < row_len; i += 256) a += fabsf(r[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    df_atomic_amax(l1max, (red[0] + red[1]) + (red[2] + red[3]));
+    if (bias && bmax && blockIdx.x == 0) {
+      float b = 0.f;
+      for (int i = 0; i < nbias; ++i) b = fmaxf(b, fabsf(bias[i]));
+      df_atomic_amax(bmax, b);
+    }
+  }
+}
+
+// out = max(other, a * l1 * slack + b)   (nulls: other = 0, l1 = 1, b = 0): the bound of a pre-split conv output / concatenation
+__global__ void h2_bound_kernel(float* __restrict__ out, const float* a, const float* l1, const float* b, const float* other, float slack) {
+  float v = *a * (l1 ? *l1 : 1.f) * slack + (b ? *b : 0.f);
+  if (other) v = fmaxf(v, *other);
+  *out = v;
+}
+
 // ------------------------------------------------------------------ BN finalize ---------
 // Stage A (large layers): block (channel block, group, split) sums its range of per-tile partials in double and
 // leaves [sum, sum of squares] per channel in scratch[g][split][2][C] -- the biggest layer has 32768 tiles per group,
@@ -79,7 +162,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const void* __restric
                                                           int groups, int C, double count, const float* gamma,
                                                           const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
-                                                          float* __restrict__ bn_ss) {
+                                                          float* __restrict__ bn_ss, const float* __restrict__ y_amax,
+                                                          unsigned* __restrict__ z_bound) {
   __shared__ double red[2][32][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -116,6 +200,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const void* __restric
       o[1 * C + c] = (float)(be - mean * ga * invstd);
       o[2 * C + c] = (float)mean;
       o[3 * C + c] = (float)invstd;
+      // z = gelu(y scale + shift), |gelu(v)| <= |v|:  max |z| <= max_c |scale_c| max|y| + |shift_c|  -- the bound that scales the
+      // pre-split z the apply pass writes next (y_amax: the conv epilogue's measurement, complete before this launch)
+      if (z_bound) df_atomic_amax(z_bound, fabsf(o[0 * C + c]) * *y_amax + fabsf(o[1 * C + c]));
       if (running_mean) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
@@ -134,6 +221,9 @@ __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restri
   const int C4 = z.c >> 2;
   const int hw = z.h * z.w;
   float mf = 0.f;
+  // ZE == 2: z is written pre-split (h2 image); `amax` is then an INPUT -- the bound of max |z| (df_bn_finalize2) that sets the scale
+  float zs = 1.f;
+  if constexpr (ZE == 2) zs = df_h2_scale(__builtin_bit_cast(float, *amax));
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / C4;
     const int c = (int)(i - m * C4) * 4;
@@ -143,10 +233,15 @@ __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restri
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = df_gelu(v[k] * sc[k] + sh[k]);
-    stx4<ZE>(z.ptr, df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
-    mf = df_amax4(mf, o);
+    if constexpr (ZE == 2) {
+      st_h2x4(z.ptr, df_img_base(z, n) + (int64_t)pix * z.ld + c, o, zs);
+    } else {
+      stx4<ZE>(z.ptr, df_img_base(z, n) + (int64_t)pix * z.ld + c, o);
+      mf = df_amax4(mf, o);
+    }
   }
-  if (amax) df_block_amax(mf, amax);      // max |z| for the fp16x2 convolution that reads z next (uniform branch)
+  if constexpr (ZE != 2)
+    if (amax) df_block_amax(mf, amax);      // max |z| for the fp16x2 convolution that reads z next (uniform branch)
 }
 
 // block layout shared by the row-partitioned channel reductions: C/4 channel lanes x 256/(C/4) row lanes
@@ -222,7 +317,9 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk_per_group,
                                                                int groups, int C, double count, float* dgamma,
-                                                               float* dbeta, float* __restrict__ coef) {
+                                                               float* dbeta, float* __restrict__ coef,
+                                                               const float* __restrict__ bn_ss, const float* __restrict__ dz_amax,
+                                                               const float* __restrict__ y_amax, unsigned* __restrict__ dy_bound) {
   __shared__ double red[2][32][32];
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -245,6 +342,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
       }
       coef[((int64_t)g * 2 + 0) * C + c] = (float)(s1 / count);
       coef[((int64_t)g * 2 + 1) * C + c] = (float)(s2 / count);
+      if (dy_bound) {
+        // dy = scale (dz gelu'(v) - c1 - xhat c2), |gelu'| <= 1.13, |xhat| <= (max|y| + |mean|) invstd: the bound that scales the
+        // pre-split dy the apply pass writes next
+        const float* ss = bn_ss + (int64_t)g * 4 * C;
+        const float xh = (*y_amax + fabsf(ss[2 * C + c])) * ss[3 * C + c];
+        df_atomic_amax(dy_bound, fabsf(ss[c]) * (1.13f * *dz_amax + fabsf((float)(s1 / count)) + xh * fabsf((float)(s2 / count))));
+      }
       tb += s1;
       tg += s2;
     }
@@ -267,6 +371,9 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
                                                                 int64_t rows, int64_t rows_per_blk, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4];
   float mf = 0.f;
+  // DE == 2: dy is written pre-split (a contiguous h2 image [rows][C]); `amax` is then an INPUT, the bound of max |dy| (df_bn_bwd_finalize2)
+  float ds = 1.f;
+  if constexpr (DE == 2) ds = df_h2_scale(__builtin_bit_cast(float, *amax));
   const int C = dz.c, hw = dz.h * dz.w;
   const RowPart rp = row_part(C);
   const void* __restrict__ dzp = dz.ptr;
@@ -292,11 +399,16 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
         if constexpr (DE == 1) o[k] = (float)(__bf16)o[k];
         acc[0][k] += o[k];
       }
-      stx4<DE>(dy, m * C + rp.c, o);
-      mf = df_amax4(mf, o);
+      if constexpr (DE == 2) {
+        st_h2x4(dy, m * C + rp.c, o, ds);
+      } else {
+        stx4<DE>(dy, m * C + rp.c, o);
+        mf = df_amax4(mf, o);
+      }
     }
   }
-  if (amax) df_block_amax(mf, amax);      // max |dy| for the fp16x2 data- / weight-gradient kernels (uniform branch)
+  if constexpr (DE != 2)
+    if (amax) df_block_amax(mf, amax);      // max |dy| for the fp16x2 data- / weight-gradient kernels (uniform branch)
   if (dbias_partial) {
     block_reduce_rows<1>(acc, rp, lds);
     if (rp.row_lane == 0) st4(dbias_partial + (int64_t)blockIdx.x * C + rp.c, acc[0]);
@@ -367,7 +479,9 @@ __device__ __forceinline__ Lerp lerp_src(int dst, int in, int out, int align_cor
 
 // YE = 1: bfloat16 output (bf16-storage training: the upsampled half of an UpsampleSkip concatenation); the input stays fp32
 template <int YE = 0>
-__global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int align_corners, int64_t total4) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int align_corners, int64_t total4, const float* __restrict__ y_bound) {
+  float ys = 1.f;
+  if constexpr (YE == 2) ys = df_h2_scale(*y_bound);      // pre-split output (the upsampled half of an h2 concatenation)
   const int C4 = y.c >> 2;
   const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -381,7 +495,8 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
     const f32x4 v00 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld), v01 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld);
     const f32x4 v10 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i0) * x.ld), v11 = ld4(b + ((int64_t)ly.i1 * x.w + lx.i1) * x.ld);
     const f32x4 o = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
-    stx4<YE>(y.ptr, df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o);
+    if constexpr (YE == 2) st_h2x4(y.ptr, df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o, ys);
+    else stx4<YE>(y.ptr, df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c, o);
   }
 }
 
@@ -460,6 +575,11 @@ bool img_ok(const df_img& d, bool any16 = false) {
          (d.elt == 0 || (any16 && d.elt == 1)) &&
          (d.n % d.grp_size) == 0 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 && (d.grp_off % 4) == 0;
 }
+// h2 image (elt = 2): whole 32-channel chunks at 128-byte lines
+bool h2_ok(const df_img& d) {
+  return d.elt == 2 && d.ptr && (((uintptr_t)d.ptr) & 127) == 0 && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && (d.c % 32) == 0 &&
+         d.grp_size > 0 && (d.n % d.grp_size) == 0 && (d.ld % 32) == 0 && (d.img_stride % 32) == 0 && (d.grp_off % 32) == 0;
+}
 bool rowpart_ok(int C) { return C >= 4 && C <= 1024 && (C % 4) == 0 && (256 % (C / 4)) == 0; }
 unsigned grid_for(int64_t total, int per_block = 256, unsigned cap = 256 * 16) {
   int64_t g = (total + per_block - 1) / per_block;
@@ -473,6 +593,16 @@ unsigned grid_for(int64_t total, int per_block = 256, unsigned cap = 256 * 16) {
 extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* bn_ss, double* scratch, int splits, void* stream) {
+  return df_bn_finalize2(partial, tiles_per_group, groups, C, count_per_group, gamma, beta, eps, momentum, running_mean, running_var,
+                         bn_ss, scratch, splits, nullptr, nullptr, stream);
+}
+
+extern "C" int df_bn_finalize2(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* bn_ss, double* scratch, int splits, const float* y_amax, float* z_bound_,
+                               void* stream) {
+  unsigned* z_bound = reinterpret_cast<unsigned*>(z_bound_);
+  DF_REQUIRE(!z_bound || y_amax, DF_E_ARG);
   DF_REQUIRE(partial && bn_ss && tiles_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, DF_E_ARG);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (scratch && splits > 1) {
@@ -480,11 +610,11 @@ extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int gro
                        tiles_per_group, C, splits, scratch);
     DF_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((C + 31) / 32), dim3(1024), 0, s, (const void*)scratch, splits,
-                       groups, C, (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, bn_ss);
+                       groups, C, (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, bn_ss, y_amax, z_bound);
   } else {
     hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, s, (const void*)partial,
                        tiles_per_group, groups, C, (double)count_per_group, gamma, beta, eps, momentum, running_mean,
-                       running_var, bn_ss);
+                       running_var, bn_ss, y_amax, z_bound);
   }
   DF_CHECK_LAUNCH();
   return DF_OK;
@@ -493,11 +623,13 @@ extern "C" int df_bn_finalize(const float* partial, int tiles_per_group, int gro
 extern "C" int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, int imgs_per_group, df_img z, float* z_amax,
                                   void* stream) {
   unsigned* amax = reinterpret_cast<unsigned*>(z_amax);
-  DF_REQUIRE(y && bn_ss && img_ok(z, true) && df_aligned16(y) && imgs_per_group > 0 && (y_elt == 0 || y_elt == 1), DF_E_ARG);
+  DF_REQUIRE(y && bn_ss && (img_ok(z, true) || (h2_ok(z) && y_elt == 0 && z_amax)) && df_aligned16(y) && imgs_per_group > 0 &&
+                 (y_elt == 0 || y_elt == 1), DF_E_ARG);
   const int64_t total4 = (int64_t)z.n * z.h * z.w * (z.c / 4);
   const dim3 grid(grid_for(total4));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  if (z.elt == 2) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 2>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  else if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else if (y_elt == 1 && z.elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
@@ -535,9 +667,17 @@ extern "C" int df_bn_gelu_bwd_reduce(df_img dz, const float* y, const float* bn_
 
 extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
                                   float* dgamma, float* dbeta, float* coef, void* stream) {
-  DF_REQUIRE(partial && coef && nblk_per_group > 0 && groups > 0, DF_E_ARG);
+  return df_bn_bwd_finalize2(partial, nblk_per_group, groups, C, count_per_group, dgamma, dbeta, coef, nullptr, nullptr, nullptr, nullptr,
+                             stream);
+}
+
+extern "C" int df_bn_bwd_finalize2(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
+                                   float* dgamma, float* dbeta, float* coef, const float* bn_ss, const float* dz_amax,
+                                   const float* y_amax, float* dy_bound, void* stream) {
+  DF_REQUIRE(partial && coef && nblk_per_group > 0 && groups > 0 && (!dy_bound || (bn_ss && dz_amax && y_amax)), DF_E_ARG);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     partial, nblk_per_group, groups, C, (double)count_per_group, dgamma, dbeta, coef);
+                     partial, nblk_per_group, groups, C, (double)count_per_group, dgamma, dbeta, coef, bn_ss, dz_amax, y_amax,
+                     reinterpret_cast<unsigned*>(dy_bound));
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -547,7 +687,8 @@ extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const
                                       void* stream) {
   unsigned* amax = reinterpret_cast<unsigned*>(dy_amax);
   DF_REQUIRE(img_ok(dz, true) && y && bn_ss && coef && dy && nblk > 0 && rowpart_ok(dz.c) && (y_elt == 0 || y_elt == 1) &&
-                 (dy_elt == 0 || dy_elt == 1), DF_E_ARG);
+                 (dy_elt == 0 || dy_elt == 1 || (dy_elt == 2 && dz.elt == 0 && y_elt == 0 && dy_amax && (dz.c % 32) == 0 &&
+                                                 (((uintptr_t)dy) & 127) == 0)), DF_E_ARG);
   const int64_t rows = (int64_t)dz.n * dz.h * dz.w;
   const int64_t rows_per_group = (int64_t)imgs_per_group * dz.h * dz.w;
   DF_REQUIRE(rows % nblk == 0, DF_E_SHAPE);
@@ -556,8 +697,9 @@ extern "C" int df_bn_gelu_bwd_apply_t(df_img dz, const void* y, int y_elt, const
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DF_BWD_APPLY(G, Y, D) \
   hipLaunchKernelGGL((bn_gelu_bwd_apply_kernel<G, Y, D>), dim3(nblk), dim3(256), 0, s, dz, y, bn_ss, coef, imgs_per_group, dy, dbias_partial, rows, rpb, amax)
-  const int key = dz.elt * 4 + y_elt * 2 + dy_elt;
+  const int key = dy_elt == 2 ? 8 : dz.elt * 4 + y_elt * 2 + dy_elt;
   switch (key) {
+    case 8: DF_BWD_APPLY(0, 0, 2); break;
     case 0: DF_BWD_APPLY(0, 0, 0); break;
     case 1: DF_BWD_APPLY(0, 0, 1); break;
     case 2: DF_BWD_APPLY(0, 1, 0); break;
@@ -611,9 +753,55 @@ extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
   if (y.elt) hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                                y, align_corners, total4);
+                                y, align_corners, total4, nullptr);
   else hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                          y, align_corners, total4);
+                          y, align_corners, total4, nullptr);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// ---- pre-split ("h2") tensors, round 4 (layout: top of this file; consumers: df_conv2d_h2p, df_conv2d_wgrad_h2p) ----------------
+// bilinear x2 into an h2 image (y.elt = 2), scale from *y_bound (>= max |x|: the outputs are convex combinations)
+extern "C" int df_upsample2x_h2(df_img x, df_img y, int align_corners, const float* y_bound, void* stream) {
+  DF_REQUIRE(img_ok(x) && h2_ok(y) && y_bound, DF_E_ARG);
+  DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
+  const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+                     align_corners, total4, y_bound);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// fp32 image -> h2 image with the scale of *bound (>= max |x|), and back (exact to 22 bits): tests / producers without a fused form
+extern "C" int df_h2_pack(df_img x, const float* bound, df_img y, void* stream) {
+  DF_REQUIRE(img_ok(x) && h2_ok(y) && bound && x.n == y.n && x.h == y.h && x.w == y.w && x.c == y.c, DF_E_ARG);
+  const int64_t total4 = (int64_t)x.n * x.h * x.w * (x.c / 4);
+  hipLaunchKernelGGL(h2_pack_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, bound, total4, 0);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+extern "C" int df_h2_unpack(df_img x, const float* bound, df_img y, void* stream) {
+  DF_REQUIRE(h2_ok(x) && img_ok(y) && bound && x.n == y.n && x.h == y.h && x.w == y.w && x.c == y.c, DF_E_ARG);
+  const int64_t total4 = (int64_t)x.n * x.h * x.w * (x.c / 4);
+  hipLaunchKernelGGL(h2_pack_kernel, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, bound, total4, 1);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// *l1max <- max(*l1max, max_row sum |w[row, :]|), *bmax <- max(*bmax, max |bias|)  (slots zero-initialised by the caller; bias / bmax
+// optional): the weight side of the a-priori bound of a pre-split convolution output
+extern "C" int df_rows_l1max(const float* w, int rows, int row_len, const float* bias, int nbias, float* l1max, float* bmax, void* stream) {
+  DF_REQUIRE(w && rows > 0 && row_len > 0 && l1max && (!bias || nbias > 0), DF_E_ARG);
+  hipLaunchKernelGGL(rows_l1max_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, row_len, bias, nbias,
+                     reinterpret_cast<unsigned*>(l1max), reinterpret_cast<unsigned*>(bmax));
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// *out = max(other ? *other : 0, *a * (l1 ? *l1 : 1) * slack + (b ? *b : 0)): one thread; bounds of pre-split conv outputs / concatenations
+extern "C" int df_h2_bound(float* out, const float* a, const float* l1, const float* b, const float* other, float slack, void* stream) {
+  DF_REQUIRE(out && a && slack > 0.f, DF_E_ARG);
+  hipLaunchKernelGGL(h2_bound_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), out, a, l1, b, other, slack);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

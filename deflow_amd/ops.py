@@ -218,6 +218,62 @@ def _h2_on() -> bool:
     return os.environ.get("DF_CONV_H2", "1") != "0"
 
 
+# ---- PRE-SPLIT ("h2") tensors, round 4 (include/deflow_amd.h "PRE-SPLIT tensors"; csrc/elementwise.hip) -------------------------
+# An activation / gradient whose only consumers are the fp16x2 3x3 convolution and weight-gradient kernels is stored by its PRODUCER as
+# two scaled fp16 planes (the bytes of the fp32 tensor), with the scale taken from a bound of max |x| that is known before the producer
+# writes: BatchNorm + GELU outputs from the statistics (df_bn_finalize2 / df_bn_bwd_finalize2), plain convolution outputs from
+# max |input| x the largest L1 norm of a weight row (+ max |bias|).  The consumers then fetch their operands by LDS-DMA with no
+# in-kernel split (conv_halo_x3_kernel<.., XP>, wgrad3_h2p_kernel).  DF_H2P=0 keeps every tensor fp32 (round 3's data flow).
+def h2p_on() -> bool:
+    return h2_active() and os.environ.get("DF_H2P", "1") != "0"
+
+
+def h2_empty(shape, device, bound: torch.Tensor) -> torch.Tensor:
+    """storage of an h2 image [N,H,W,C] (C % 32 == 0): float32-typed memory holding per pixel and 32-channel chunk [32 fp16 hi | 32
+    fp16 lo]; `bound` = the device scalar that defines its power-of-two scale (every producer and consumer takes THIS tensor)."""
+    assert shape[-1] % 32 == 0
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    t._df_h2 = bound
+    return t
+
+
+def h2_unpack(t: torch.Tensor) -> torch.Tensor:
+    """fp32 copy of an h2 tensor (tests / debugging)"""
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    call("df_h2_unpack", img(t), ptr(t._df_h2), img(out), stream())
+    return out
+
+
+def h2_pack(x: torch.Tensor, bound: torch.Tensor) -> torch.Tensor:
+    t = h2_empty(x.shape, x.device, bound)
+    call("df_h2_pack", img(x), ptr(bound), img(t), stream())
+    return t
+
+
+def rows_l1max(w2d_rows: int, row_len: int, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """-> (max_row sum |w[row, :]|, max |bias| or None) as device scalars: the weight side of a conv output's a-priori bound"""
+    l1 = amax_slot(w.device)
+    bm = amax_slot(w.device) if bias is not None else None
+    call("df_rows_l1max", ptr(w), w2d_rows, row_len, ptr(bias), 0 if bias is None else bias.numel(), ptr(l1), ptr(bm), stream())
+    return l1, bm
+
+
+def h2_bound(a: torch.Tensor, l1: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
+             other: Optional[torch.Tensor] = None, slack: float = 1.001) -> torch.Tensor:
+    """device scalar max(other, a * l1 * slack + b)"""
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    call("df_h2_bound", ptr(out), ptr(a), ptr(l1), ptr(b), ptr(other), float(slack), stream())
+    return out
+
+
+def conv_out_bound(x: DfImg, w_rows: torch.Tensor, bias: Optional[torch.Tensor], device, other: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bound of max |conv(x; w) + bias| for the kernel operand `w_rows` ([rows = output channels][taps x input channels] memory:
+    the OHWI weights of a forward conv, the transposed ones of a data gradient):  max|x| x max_row ||w_row||_1 + max |bias|"""
+    rows = w_rows.shape[0]
+    l1, bm = rows_l1max(rows, w_rows.numel() // rows, w_rows, bias)
+    return h2_bound(amax_of(x, device), l1, bm, other)
+
+
 def h2_active() -> bool:
     """are the fp32-mode 3x3 stride-1 convolutions on the fp16x2 kernels (so that producers should measure max |x|)?"""
     return (not MFMA_BF16) and _h2_on() and os.environ.get("DF_CONV_X3", "1") != "0"
@@ -245,21 +301,43 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e0.record()
     w16 = (MFMA_BF16 and ks == 3 and stride == 1 and os.environ.get("DF_CONV_W16", "1") != "0"
            and call("df_conv2d_w16_ok", x, y, ks, stride, mode, epi) == 1)
-    x3 = (not MFMA_BF16 and not w16 and ks == 3 and stride == 1 and x.elt == 0 and y.elt == 0
-          and call("df_conv2d_x3_ok", x, y, ks, stride, mode, epi) == 1)
+    pre = x.elt == 2 or y.elt == 2     # pre-split input and / or output (h2 images; their bounds ride on the descriptors)
+    if pre:
+        assert not MFMA_BF16 and _h2_on() and not accumulate
+        if ks == 3 and stride == 1:
+            assert call("df_conv2d_h2p_ok", x, y, ks, stride, mode, epi) == 1, "no pre-split tile form for this shape (ask df_conv2d_h2p_ok first)"
+        else:
+            assert x.elt == 0, "1x1 / stride-2 convolutions read fp32"
+    x3 = (not MFMA_BF16 and not w16 and ks == 3 and stride == 1 and ((x.elt == 0 and y.elt == 0) or pre)
+          and (pre or call("df_conv2d_x3_ok", x, y, ks, stride, mode, epi) == 1))
     h2 = x3 and _h2_on()
     # fp32 mode with the fp16x2 kernels on: every fp32 conv output carries its max |y| for a possible fp16x2 consumer (measured by
     # the epilogue; outputs that go through BatchNorm + GELU first get theirs from that pass instead)
     ya = None
-    if h2_active() and y.elt == 0 and epi != EPI_STATS and not w16:
+    if h2_active() and y.elt == 0 and epi == EPI_STATS and amax_out is not None and not w16:
+        ya = amax_out          # max |y| of a conv output that BatchNorm + GELU follow: the bounds of the pre-split z / dy come from it
+    elif h2_active() and y.elt == 0 and epi != EPI_STATS and not w16:
         ya = amax_out if amax_out is not None else amax_slot(w_ohwi.device)
         y._amax = ya
         src = getattr(y, "_src", None)      # the descriptor covers a whole tensor: descriptors made of it later inherit the bound
         if src is not None:
             src._df_amax = (ya, src._version)
-    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt == 0 and (ks == 1 or stride == 2) and x.c % 64 == 0
+    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2) and x.c % 64 == 0
            and getattr(x, "_amax", None) is not None and os.environ.get("DF_CONV_H2F", "1") != "0")
-    if h2:
+    if h2 and pre:
+        w2, wa = _split_h2(w_ohwi)
+        call("df_conv2d_h2p", x, ptr(w2), ptr(amax_of(x, w_ohwi.device)), ptr(wa), ptr(bias), y, ptr(y._amax) if y.elt == 2 else None,
+             ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats), 0, ptr(ya), stream())
+    elif pre:      # 1x1 (or stride-2) convolution with a pre-split OUTPUT: the fp32-input kernels, fp16x2 on the fragments when x has a bound
+        wa = None
+        if h2f:
+            wa = W_AMAX
+            if wa is None:
+                wa = amax_slot(w_ohwi.device)
+                call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
+        call("df_conv2d_yh2", x, ptr(w_ohwi), ptr(x._amax) if h2f else None, ptr(wa), ptr(bias), y, ptr(y._amax), ks, stride, ks // 2, mode, epi,
+             ptr(scale), ptr(shift), ptr(stats), 0, stream())
+    elif h2:
         # fp32-accurate product from TWO fp16 planes per operand with per-tensor power-of-two scales (conv_halo_x3_kernel<NP = 2>:
         # three MFMAs per operand pair instead of six)
         w2, wa = _split_h2(w_ohwi)
@@ -297,7 +375,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         e1.record()
         small = y if mode == CONV_FWD else x  # the conv-output-sized grid
         flops = 2.0 * small.n * small.h * small.w * ks * ks * x.c * y.c
-        tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n} {'fb'[x.elt]}{'fb'[y.elt]}"
+        tag = f"{'fwd' if mode == CONV_FWD else 'dgrad'} {ks}x{ks} s{stride} {x.c}->{y.c} @{small.h}x{small.w} x{small.n} {'fbh'[x.elt]}{'fbh'[y.elt]}"
         name = _conv_variant(x, y, ks, stride, mode, epi) + ("/h2" if (h2f and "conv_dma_kernel<128," in _conv_variant(x, y, ks, stride, mode, epi)) else "")
         if x3:   # mirrors conv2d_impl's dispatch of the bf16x3 forms (BM, BN, WM, WN, SEG, DB)
             bn = 128 if y.c % 128 == 0 else 64
@@ -314,6 +392,8 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             if (h2 and bn == 64 and seg64 and y.h % seg64 == 0 and m_rows % 512 == 0 and (epi != EPI_STATS or rpg % 512 == 0)
                     and m_rows // 512 >= 512 and os.environ.get("DF_CONV_H2_BM256", "1") != "0"):
                 name = f"conv_halo_x3_kernel<512,64,8,1,{seg64},3,2>"
+            if x.elt == 2:
+                name = name[:-1] + ",xp>"        # pre-split input: halo by LDS-DMA (template argument XP)
         if w16:
             bn = 128 if y.c % 128 == 0 else 64
             name = f"conv_halo_w16_kernel<{bn},{2 if bn == 128 else 4},{4 if bn == 128 else 2},{1 if y.w % 128 == 0 else 2}>"
@@ -372,7 +452,9 @@ class SyncBN:
 SYNC: Optional[SyncBN] = None   # set by optim.Trainer(sync_bn=True) on a multi-rank process group
 
 
-def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss):
+def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, momentum, rmean, rvar, bn_ss, y_amax=None, z_bound=None):
+    """y_amax / z_bound (both or neither): max |y| as the conv epilogue measured it, and the zero-initialised slot that receives the
+    bound of max |gelu(bn(y))| -- the scale of the pre-split z the apply pass writes next"""
     PARAM_GEN[0] += 1  # running statistics change under any cached eval-mode fold
     if SYNC is not None:
         red = SYNC.sum(partial.view(groups, tiles_per_group, C, 2).to(torch.float64).sum(1))      # [groups, C, 2], all ranks
@@ -389,11 +471,13 @@ def bn_finalize(partial, tiles_per_group, groups, C, count, gamma, beta, eps, mo
                 unb = var * (cnt / (cnt - 1.0)) if cnt > 1 else var
                 rmean.mul_(1.0 - momentum).add_((momentum * mean).float())
                 rvar.mul_(1.0 - momentum).add_((momentum * unb).float())
+        if z_bound is not None:
+            z_bound.copy_((out[:, 0].abs() * y_amax + out[:, 1].abs()).max().reshape(1))
         return
     splits = min(64, tiles_per_group // 64)  # two-stage reduction once a group has thousands of tile partials
     scratch = torch.empty(groups * splits * 2 * C, dtype=torch.float64, device=partial.device) if splits > 1 else None
-    call("df_bn_finalize", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,
-         ptr(rmean), ptr(rvar), ptr(bn_ss), ptr(scratch), splits, stream())
+    call("df_bn_finalize2", ptr(partial), tiles_per_group, groups, C, count, ptr(gamma), ptr(beta), eps, momentum,
+         ptr(rmean), ptr(rvar), ptr(bn_ss), ptr(scratch), splits, ptr(y_amax), ptr(z_bound), stream())
 
 
 def _elt(t: torch.Tensor) -> int:
@@ -401,7 +485,10 @@ def _elt(t: torch.Tensor) -> int:
 
 
 def bn_gelu_apply(y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, z: DfImg):
-    with timed("bn_gelu_apply", bytes=(y.element_size() + (2.0 if z.elt else 4.0)) * y.numel()):          # read y, write z
+    with timed("bn_gelu_apply", bytes=(y.element_size() + (2.0 if z.elt == 1 else 4.0)) * y.numel()):          # read y, write z
+        if z.elt == 2:      # pre-split z: its bound (df_bn_finalize2) is an INPUT here
+            call("df_bn_gelu_apply_t", ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, z, ptr(z._amax), stream())
+            return
         a = amax_slot(y.device) if (h2_active() and z.elt == 0) else None     # max |z| for the fp16x2 convolution that reads z
         call("df_bn_gelu_apply_t", ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, z, ptr(a), stream())
         if a is not None:
@@ -417,8 +504,11 @@ def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
 
 
 def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True,
-                frozen: bool = False, dy_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                frozen: bool = False, dy_dtype: torch.dtype = torch.float32, dy_h2: bool = False,
+                y_amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> dy [n,h,w,C] (dy_dtype: float32, or bfloat16 in the bf16-storage mode), dgamma [C], dbeta [C], dbias [C].
+    dy_h2 (with y_amax = max |y| from the forward's conv epilogue): dy is written pre-split (ops.h2_empty) with the scale of the
+    bound the finalisation derives from max |dz|, max |y| and the statistics.
     frozen: eval-mode BatchNorm (running statistics are constants): the batch-statistic terms of the data gradient
     vanish (coef = 0), dgamma / dbeta keep their form, and the conv bias gradient is no longer cancelled."""
     dev = y.device
@@ -430,24 +520,37 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
     gb = 2.0 if dz.elt else 4.0
     with timed("bn_gelu_bwd_reduce", bytes=(gb + y.element_size()) * y.numel()):     # read dz, y
         call("df_bn_gelu_bwd_reduce_t", dz, ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
+    dy_bound = None
+    if dy_h2:
+        assert y_amax is not None and dy_dtype == torch.float32 and dz.elt == 0 and y.dtype == torch.float32
+        dy_bound = amax_slot(dev)
+        dz_amax = amax_of(dz, dev)
     if SYNC is not None and not frozen:
         red = partial.view(groups, nbg, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
         dbeta, dgamma = red[:, :, 0].sum(0).float(), red[:, :, 1].sum(0).float()
         glob = SYNC.sum(red.clone()) / (float(rows_per_group) * SYNC.world)
         coef = glob.permute(0, 2, 1).contiguous().float()                        # [groups, 2, C]
+        if dy_h2:
+            ss = bn_ss.view(groups, 4, C)
+            xh = (y_amax + ss[:, 2].abs()) * ss[:, 3]
+            dy_bound.copy_((ss[:, 0].abs() * (1.13 * dz_amax + coef[:, 0].abs() + xh * coef[:, 1].abs())).max().reshape(1))
     else:
         dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
         coef = _f32(groups, 2, C, device=dev)
-        call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
+        if dy_h2:
+            call("df_bn_bwd_finalize2", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(bn_ss),
+                 ptr(dz_amax), ptr(y_amax), ptr(dy_bound), stream())
+        else:
+            call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
         if frozen:
             coef.zero_()
-    dy = torch.empty(y.shape, dtype=dy_dtype, device=dev)
+    dy = h2_empty(y.shape, dev, dy_bound) if dy_h2 else torch.empty(y.shape, dtype=dy_dtype, device=dev)
     dbp = _f32(nblk, C, device=dev)
     with timed("bn_gelu_bwd_apply", bytes=(gb + y.element_size() + dy.element_size()) * y.numel()):     # read dz, y; write dy
-        a = amax_slot(dev) if (h2_active() and dy_dtype == torch.float32) else None     # max |dy| for the fp16x2 dgrad / wgrad
-        call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), _elt(dy), ptr(dbp), nblk,
+        a = dy_bound if dy_h2 else amax_slot(dev) if (h2_active() and dy_dtype == torch.float32) else None     # max |dy| for the fp16x2 dgrad / wgrad
+        call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), 2 if dy_h2 else _elt(dy), ptr(dbp), nblk,
              ptr(a), stream())
-        if a is not None:
+        if a is not None and not dy_h2:
             dy._df_amax = (a, dy._version)          # _lib.img() hands it on to the descriptors made of this tensor
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
@@ -485,7 +588,11 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     """dw (float memory [Cout][taps][Cin] with row pitch ld_co, starting dw_off elements in) (+)= dy^T x.
     want_bias: also return the bias gradient sum_p dy[p, :] (fused: the kernel already stages every dy tile)."""
     dev = dw.device
-    splits = call("df_conv2d_wgrad_splits", x, dy, ks, stride)
+    pre = x.elt == 2 and dy.elt == 2       # both operands pre-split (h2 images): wgrad3_h2p_kernel
+    assert pre or (x.elt != 2 and dy.elt != 2), "a pre-split tensor meets an fp32 one in a weight gradient: unpack it (ops.h2_unpack) or keep both split"
+    if pre:
+        assert ks == 3 and stride == 1 and row_counts is None and call("df_conv2d_wgrad_h2p_ok", x, dy, ks, stride) == 1
+    splits = call("df_conv2d_wgrad_h2p_splits", x, dy) if pre else call("df_conv2d_wgrad_splits", x, dy, ks, stride)
     taps = ks * ks
     ws = _f32(splits * dy.c * taps * x.c, device=dev)
     prof = PROFILER
@@ -493,11 +600,13 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
-    t16 = bool(x.elt and dy.elt)
-    x3 = (not t16 and not MFMA_BF16 and ks == 3 and stride == 1 and row_counts is None
+    t16 = bool(x.elt == 1 and dy.elt == 1)
+    x3 = (not pre and not t16 and not MFMA_BF16 and ks == 3 and stride == 1 and row_counts is None
           and call("df_conv2d_wgrad_x3_ok", x, dy, ks, stride) == 1)
     h2 = x3 and _h2_on()
-    if t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
+    if pre:
+        call("df_conv2d_wgrad_h2p", x, dy, ptr(x._amax), ptr(dy._amax), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
+    elif t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     elif h2:     # fp32 mode: fp32-accurate product from two scaled fp16 planes per operand (wgrad3_x3_kernel<2>)
         call("df_conv2d_wgrad_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws),
@@ -509,10 +618,10 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
              int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = ("wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_h2p_kernel<4>" if pre else "wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
-        tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fb'[x.elt]}{'fb'[dy.elt]}"
+        tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fbh'[x.elt]}{'fbh'[dy.elt]}"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
@@ -524,6 +633,9 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
 
 
 def upsample2x(x: DfImg, y: DfImg, align_corners: bool):
+    if y.elt == 2:      # the upsampled half of a pre-split concatenation: scale from the concatenation's bound (>= max |x|)
+        call("df_upsample2x_h2", x, y, int(align_corners), ptr(y._amax), stream())
+        return
     call("df_upsample2x", x, y, int(align_corners), stream())
 
 

@@ -58,7 +58,7 @@ class UpsampleSkip(nn.Module):
 
 
 def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int, train: bool, tape: Optional[list],
-                 store16: bool = False):
+                 store16: bool = False, h2_stage: bool = False):
     """z = gelu(bn(conv(x))).  train: batch statistics per group (+ running update); else running stats, fused.
     store16 (training, bf16-storage mode): the conv output y is kept as bfloat16 (z's type is the caller's: its descriptor)."""
     dev = m.conv.weight.device
@@ -88,12 +88,18 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     yi = img(y)
     yi.grp_size = ipg  # stat groups are image groups: tile -> group by its first row
     yi.grp_off = ipg * y.stride(0)
-    ops.conv2d(x, w, b, yi, 3, m.stride, epi=ops.EPI_STATS, stats=partial)
+    # pre-split mode (h2_stage: this layer's z and / or the dy its backward produces are h2 images): the epilogue also measures
+    # max |y|, from which the finalisations derive the bounds that scale z (here) and dy (ops.bn_gelu_bwd)
+    ya = ops.amax_slot(dev) if (h2_stage and not store16) else None
+    ops.conv2d(x, w, b, yi, 3, m.stride, epi=ops.EPI_STATS, stats=partial, amax_out=ya)
     bn_ss = torch.empty(groups, 4, C, dtype=torch.float32, device=dev)
+    zb = z._amax if z.elt == 2 else None       # (zero-initialised slot: the h2 tensor was created with it)
     ops.bn_finalize(partial, tiles_pg, groups, C, rows_pg, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
-                    bn.running_mean, bn.running_var, bn_ss)
+                    bn.running_mean, bn.running_var, bn_ss, y_amax=ya if zb is not None else None, z_bound=zb)
     bn.num_batches_tracked.add_(groups)
     ops.bn_gelu_apply(y, bn_ss, ipg, z)
+    if ya is not None:
+        y._df_yamax = ya
     if tape is not None:
         tape.append(("cwn", m, x, y, bn_ss, ipg, groups, False))
 
@@ -107,6 +113,25 @@ def _stage_store16_ok(n: int, h: int, w: int, c: int, dev) -> bool:
     d = DfImg(probe.data_ptr(), n, h, w, c, c, n, h * w * c, 0, 1, 0)
     return (call("df_conv2d_w16_ok", d, d, 3, 1, ops.CONV_FWD, ops.EPI_STATS) == 1
             and call("df_conv2d_w16_ok", d, d, 3, 1, ops.CONV_DGRAD, ops.EPI_BIAS) == 1)
+
+
+def _h2p_ok(n: int, h: int, w: int, cin: int, cout: int, dev) -> bool:
+    """do the pre-split forms (df_conv2d_h2p with an h2 input: forward and data gradient; df_conv2d_wgrad_h2p) exist for an
+    [n,h,w,cin] -> [n,h,w,cout] 3x3 stride-1 layer?  (descriptors of that shape; nothing is launched)"""
+    if cin % 64 or cout % 64 or not ops.h2p_on():
+        return False
+    probe = torch.empty(64, dtype=torch.float32, device=dev)
+    base = (probe.data_ptr() + 127) // 128 * 128
+
+    def d(c, elt):
+        return DfImg(base, n, h, w, c, c, n, h * w * c, 0, elt, 0)
+    return (call("df_conv2d_h2p_ok", d(cin, 2), d(cout, 0), 3, 1, ops.CONV_FWD, ops.EPI_BIAS) == 1
+            and call("df_conv2d_h2p_ok", d(cout, 2), d(cin, 0), 3, 1, ops.CONV_DGRAD, ops.EPI_BIAS) == 1
+            and call("df_conv2d_wgrad_h2p_ok", d(cin, 2), d(cout, 2), 3, 1) == 1)
+
+
+def _is_h2(t) -> bool:
+    return getattr(t, "_df_h2", None) is not None
 
 
 class FastFlow3DUNet(nn.Module):
@@ -147,16 +172,25 @@ class FastFlow3DUNet(nn.Module):
                     # the bf16-tile kernels (W % 128 == 0, or W == 64) every y / z / dz / dy is bfloat16; the stage's input
                     # and its last activation (the skip tensor) stay fp32
                     store16 = bool(train and tape is not None and ops.BF16_STORE and ops.MFMA_BF16 and _stage_store16_ok(2 * B, h, w, m.conv.out_channels, dev))
+                    # pre-split mode (fp32 training on the fp16x2 kernels, round 4): every activation BETWEEN the layers of a stage
+                    # (z of layers 0 .. L-2: read only by the next 3x3 stride-1 conv and its weight gradient) and the dy of layers
+                    # 1 .. L-1 are h2 images; the stage's input, its last activation (the skip tensor), y and dz stay fp32
+                    h2s = bool(train and tape is not None and not store16 and _h2p_ok(2 * B, h, w, m.conv.out_channels, m.conv.out_channels, dev))
                 C = m.conv.out_channels
                 if i == len(stage) - 1:
                     cat = torch.empty(B, h, w, 2 * C, **f32)
                     cats.append(cat)
                     z = img_pair(cat, C)
                     keep = cat
+                elif h2s:
+                    keep = ops.h2_empty((2 * B, h, w, C), dev, ops.amax_slot(dev))
+                    z = img(keep)
                 else:
                     keep = torch.empty(2 * B, h, w, C, dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
                     z = img(keep)
-                _cwn_forward(m, x, z, 2 * B, 2, train, tape, store16)
+                _cwn_forward(m, x, z, 2 * B, 2, train, tape, store16, h2s)
+                if i == len(stage) - 1 and getattr(z, "_amax", None) is not None:
+                    cat._df_amax = (z._amax, cat._version)      # the two clouds' images ARE the skip tensor: its readers inherit the bound
                 alive.append(keep)  # without this a no-tape run would free x's tensor before the next conv reads it
                 if tape is not None:
                     tape.append(("keep", keep))
@@ -191,19 +225,33 @@ class FastFlow3DUNet(nn.Module):
         s16 = bool(train and tape is not None and ops.BF16_STORE and ops.MFMA_BF16
                    and _stage_store16_ok(B, 2 * h, 2 * w, outc, dev) and _stage_store16_ok(B, 2 * h, 2 * w, 2 * lat, dev))
         mid = dict(dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
+        # pre-split mode (round 4): the concatenation and the first 3x3 conv's output are h2 images -- written split by the upsample
+        # kernel / the 1x1 conv's epilogue / the 3x3 conv's epilogue, with scales from a-priori bounds (max |input| x the largest L1
+        # norm of a weight row + max |bias|; the upsampled half: max |t|, measured) -- and read by LDS-DMA
+        h2d = bool(train and tape is not None and not s16 and _h2p_ok(B, 2 * h, 2 * w, 2 * lat, outc, dev)
+                   and _h2p_ok(B, 2 * h, 2 * w, outc, outc, dev))
         t = torch.empty(B, h, w, lat, **f32)
         # fp16x2 mode: ONE max |x| slot for the concatenation -- both 1x1 convolutions accumulate into it (the upsampled half is
         # made of convex combinations of t, so max |t| bounds it)
         cat_amax = ops.amax_slot(dev) if (ops.h2_active() and not s16) else None
         self._conv(m.u1_u2[0], a, img(t), 1, tape, amax=cat_amax)
-        cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **mid)
+        if h2d:
+            w3 = ops.ohwi(m.u3.weight)
+            cat_bound = ops.conv_out_bound(img(b), w3, m.u3.bias.detach(), dev, other=cat_amax)
+            cat = ops.h2_empty((B, 2 * h, 2 * w, 2 * lat), dev, cat_bound)
+        else:
+            cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **mid)
         ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
         if tape is not None:
             tape.append(("up", h, w, lat))
-        self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=cat_amax)
-        if cat_amax is not None:
+        self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=None if h2d else cat_amax)
+        if cat_amax is not None and not h2d:
             cat._df_amax = (cat_amax, cat._version)
-        u4 = torch.empty(B, 2 * h, 2 * w, outc, **mid)
+        if h2d:
+            u4 = ops.h2_empty((B, 2 * h, 2 * w, outc), dev,
+                              ops.conv_out_bound(img(cat), ops.ohwi(m.u4_u5[0].weight), m.u4_u5[0].bias.detach(), dev))
+        else:
+            u4 = torch.empty(B, 2 * h, 2 * w, outc, **mid)
         self._conv(m.u4_u5[0], cat, img(u4), 3, tape)
         u5 = torch.empty(B, 2 * h, 2 * w, outc, **f32)
         self._conv(m.u4_u5[1], u4, img(u5), 3, tape)
@@ -308,11 +356,11 @@ class FastFlow3DUNet(nn.Module):
     # ------------------------------------------------------------------------------ backward ----
     @staticmethod
     def _conv_bwd(m: nn.Conv2d, x: DfImg, dy: DfImg, ks: int, stride: int, dx: Optional[DfImg], acc_dx: bool,
-                  grads: dict, with_bias: bool = True):
+                  grads: dict, with_bias: bool = True, wt: Optional[torch.Tensor] = None):
         w = ops.ohwi(m.weight)
         dev = w.device
         if dx is not None:
-            ops.conv2d(dy, ops.weight_transpose(w), None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
+            ops.conv2d(dy, ops.weight_transpose(w) if wt is None else wt, None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
         fused = with_bias and not _NO_FUSED_BIAS
 
         def wgrad():
@@ -356,19 +404,30 @@ class FastFlow3DUNet(nn.Module):
                 keep.append(t)
             return t
 
-        def plain_conv_bwd(dy: torch.Tensor, dx: Optional[DfImg], acc: bool):
+        def plain_conv_bwd(dy: torch.Tensor, dx: Optional[DfImg], acc: bool, wt=None):
             _, m, x, ks = pop("conv")
-            self._conv_bwd(m, img(x), img(dy), ks, 1, dx, acc, grads)
+            self._conv_bwd(m, img(x), img(dy), ks, 1, dx, acc, grads, wt=wt)
 
         retained = {}
 
-        def upsample_skip_bwd(dout: torch.Tensor, da: DfImg, acc_a: bool, db: Optional[DfImg], acc_b: bool):
+        def grad_like(x: torch.Tensor, dy: torch.Tensor, m: nn.Conv2d):
+            """storage of d(x) for the data gradient of conv m (output gradient dy): pre-split when x was (its consumers are then the
+            pre-split data- and weight-gradient kernels of the layer in front), with the a-priori bound max|dy| x max_row ||w^T row||_1;
+            -> (tensor, transposed weights or None)"""
+            if _is_h2(x):
+                wt = ops.weight_transpose(ops.ohwi(m.weight))
+                return hold(ops.h2_empty(x.shape, dev, ops.conv_out_bound(img(dy), wt, None, dev))), wt
+            return hold(torch.empty_like(x)), None
+
+        def upsample_skip_bwd(dout: torch.Tensor, a_like: Optional[torch.Tensor], db: Optional[DfImg], acc_b: bool):
             # reverse of: u1(a)->t ; up(t)->cat[:lat] ; u3(b)->cat[lat:] ; u4(cat) ; u5(u4)
             # (bf16-storage mode: u4 and cat were bfloat16 -> du4 is bfloat16 as well, so both 3x3 weight gradients see bf16
-            #  x and dy; dcat stays fp32 for the 1x1 / upsample kernels behind it)
+            #  x and dy; dcat stays fp32 for the 1x1 / upsample kernels behind it.  Pre-split mode: the same with h2 images.)
+            # a_like: the tensor whose layout d(a) takes (the u4 of the block in front: bf16 / h2 / fp32), None = fp32
+            # -> d(a) [the block's input gradient: the output gradient of the block in front]
             _, m5, x5, _ = tape[-1]
-            du4 = hold(torch.empty_like(x5))
-            plain_conv_bwd(dout, img(du4), False)
+            du4, wt5 = grad_like(x5, dout, m5)
+            plain_conv_bwd(dout, img(du4), False, wt5)
             _, m4, x4, _ = tape[-1]
             dcat = hold(torch.empty(x4.shape, **f32))
             plain_conv_bwd(du4, img(dcat), False)
@@ -382,22 +441,34 @@ class FastFlow3DUNet(nn.Module):
             dt = hold(torch.empty(B, h, w, lat, **f32))
             ops.upsample2x_bwd(img(dcat, lat, 0), img(dt), self.align_corners)
             _, m1, xa, ks = pop("conv")
-            self._conv_bwd(m1, img(xa), img(dt), 1, 1, da, acc_a, grads)
+            wt1 = None
+            if a_like is not None and _is_h2(a_like):
+                wt1 = ops.weight_transpose(ops.ohwi(m1.weight))
+                dA = hold(ops.h2_empty(xa.shape, dev, ops.conv_out_bound(img(dt), wt1, None, dev)))
+            else:
+                dA = hold(torch.empty(xa.shape, dtype=torch.float32 if a_like is None else a_like.dtype, device=dev))
+            self._conv_bwd(m1, img(xa), img(dt), 1, 1, img(dA), False, grads, wt=wt1)
+            return dA
 
         # the gradient a block receives at its output (du, dT, dS) is bfloat16 when that block kept its u4 in bfloat16 (bf16-
         # storage mode): its two consumers are then the bf16-tile data- and weight-gradient kernels of the block's second conv
-        def dout_dtype(k):      # k-th "conv" entry from the end of the tape: (.., x, ks) with x = that conv's input
+        def conv_x(k):      # input tensor of the k-th "conv" entry from the end of the tape
             convs = [e for e in tape if e[0] == "conv"]
-            return convs[-k][2].dtype
+            return convs[-k][2]
         # decoder_step4
         _, m, xu, _ = tape[-1]
-        du = hold(torch.empty(xu.shape, dtype=dout_dtype(2), device=dev))    # conv entries from the end: step4, step3.u5 (x = u4)
+        u4_3 = conv_x(2)                                           # conv entries from the end: step4, step3.u5 (x = u4)
+        wt4 = ops.weight_transpose(ops.ohwi(m.weight))
+        if _is_h2(u4_3):
+            du = hold(ops.h2_empty(xu.shape, dev, ops.conv_out_bound(img(dv), wt4, None, dev)))
+        else:
+            du = hold(torch.empty(xu.shape, dtype=u4_3.dtype, device=dev))
         if dv_cells is None:
-            plain_conv_bwd(dv, img(du), False)
+            plain_conv_bwd(dv, img(du), False, wt4)
         else:
             _, m, xu, _ = pop("conv")
             w4 = ops.ohwi(m.weight)
-            ops.conv2d(img(dv), ops.weight_transpose(w4), None, img(du), 3, 1, mode=ops.CONV_DGRAD)
+            ops.conv2d(img(dv), wt4, None, img(du), 3, 1, mode=ops.CONV_DGRAD)
             nblk = max(1, 256 // B)
             ws = torch.empty(nblk * B, 64 * 9 * 64, **f32)
             bws = torch.empty(nblk * B, 64, **f32)
@@ -418,14 +489,11 @@ class FastFlow3DUNet(nn.Module):
         else:
             acc_b = True
         # conv entries of a block in tape order: u1, u3, u4, u5 -> from the end: u5 (x = u4), u4, u3, u1
-        dT = hold(torch.empty(B, H // 2, W // 2, 128, dtype=dout_dtype(5), device=dev))      # step4, step3 (4 entries), step2.u5
-        upsample_skip_bwd(du, img(dT), False, None if sparse_input_grad else img(dbstar), acc_b)
+        dT = upsample_skip_bwd(du, conv_x(5), None if sparse_input_grad else img(dbstar), acc_b)   # step3 (4 entries), step2.u5 (x = u4)
         dF = hold(torch.empty(B, H // 2, W // 2, 128, **f32))   # d(fstar)
-        dS = hold(torch.empty(B, H // 4, W // 4, 256, dtype=dout_dtype(5), device=dev))      # (tape shrank by one block) step1.u5
-        upsample_skip_bwd(dT, img(dS), False, img(dF), False)
+        dS = upsample_skip_bwd(dT, conv_x(5), img(dF), False)    # (tape shrank by one block) step1.u5
         dL = hold(torch.empty(B, H // 4, W // 4, 256, **f32))   # d(lstar)
-        dR = hold(torch.empty(B, H // 8, W // 8, 512, **f32))   # d(rstar)
-        upsample_skip_bwd(dS, img(dR), False, img(dL), False)
+        dR = upsample_skip_bwd(dS, None, img(dL), False)         # d(rstar) [B,H/8,W/8,512], fp32: the encoder's BatchNorm backward reads it
         if phase is not None:   # the four decoder steps are complete: their gradients can leave (optim.GradSink)
             phase([p for m in (self.decoder_step1, self.decoder_step2, self.decoder_step3, self.decoder_step4)
                    for p in m.parameters()])
@@ -439,8 +507,12 @@ class FastFlow3DUNet(nn.Module):
                 # bf16-storage stage (y is bfloat16): dy of its stride-1 layers is bfloat16 too, and so is the dx they hand to
                 # the layer in front; the stage's first (stride-2) layer keeps an fp32 dy for the fp32 kernels that consume it
                 s16 = y.dtype == torch.bfloat16 and i > 0
+                # pre-split stage: this layer's input x was an h2 image -> its dy is written as one too (both consumers -- the data
+                # gradient into the layer in front and the weight gradient against x -- are the pre-split kernels)
+                dy_h2 = x.elt == 2 and getattr(y, "_df_yamax", None) is not None
                 dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups, frozen=frozen,
-                                                           dy_dtype=torch.bfloat16 if s16 else torch.float32)
+                                                           dy_dtype=torch.bfloat16 if s16 else torch.float32, dy_h2=dy_h2,
+                                                           y_amax=getattr(y, "_df_yamax", None) if dy_h2 else None)
                 hold(dy)
                 grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
                 if i > 0:

@@ -37,7 +37,8 @@ typedef struct df_img {
   int64_t grp_off;    /* element offset of group g */
   int32_t elt;        /* element type: 0 = float32 (every entry point), 1 = bfloat16 (bf16-STORAGE training, round 3: only the
                          entry points that say so accept it -- df_conv2d_w16 x / y, df_conv2d_mp y, df_bn_gelu_*_t,
-                         df_conv2d_wgrad_bf16; all others return DF_E_ARG).  ld / img_stride / grp_off stay in ELEMENTS */
+                         df_conv2d_wgrad_bf16; all others return DF_E_ARG), 2 = pre-split fp16x2 "h2" image (round 4: see "PRE-SPLIT
+                         tensors" below; only the *_h2p / *_yh2 / *_h2 entry points).  ld / img_stride / grp_off stay in ELEMENTS */
   int32_t reserved;   /* 0 */
 } df_img;
 
@@ -289,6 +290,45 @@ int df_upsample2x_bf16(df_img x, df_img y, int align_corners, void* stream); /* 
 /* bilinear x2 (PyTorch F.interpolate semantics, align_corners selectable), forward and backward */
 int df_upsample2x(df_img x, df_img y, int align_corners, void* stream);
 int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* stream);
+
+/* ---- PRE-SPLIT ("h2") tensors, round 4: the operands of the fp16x2 kernels written split by their PRODUCERS -------------------
+ * df_img.elt = 2: the tensor has the geometry of its fp32 form (4 bytes per element: ld / img_stride / grp_off unchanged), but per
+ * pixel and 32-channel chunk the 128-byte line holds [32 x fp16 hi | 32 x fp16 lo] with  x s = hi + lo / 2048,  s = the power of
+ * two that puts a BOUND of max |x| into [2^14, 2^15).  The bound is a device scalar known BEFORE the producer writes (BatchNorm
+ * statistics, weight norms: below), so nothing synchronises; every consumer takes the SAME scalar.  Requirements: c, ld,
+ * img_stride, grp_off multiples of 32, 128-byte aligned base.  What this replaces in the reference: nothing -- it is the storage
+ * form of the activations / gradients between `ConvWithNorms` / `UpsampleSkip` layers ([REF decoder.py:202-220]) inside this
+ * engine; results stay those of the fp32 tensors to 22 significant bits.
+ *   df_conv2d_h2p        df_conv2d_h2 with x and / or y as h2 images (x_amax = the bound that defined x; y_bound defines y)
+ *   df_conv2d_yh2        the fp32-input kernels (1x1, stride 2; fp32 MFMA or fp16x2-on-fragments when x_amax / w_amax are given)
+ *                        writing an h2 output
+ *   df_conv2d_wgrad_h2p  3x3 stride-1 weight gradient of h2 x and dy (LDS-DMA ring, no in-kernel split)
+ *   df_bn_finalize2 / df_bn_bwd_finalize2   the finalisations, also leaving the bound of the z / dy their apply pass writes next
+ *                        (z_bound / dy_bound: zero-initialised slots, integer atomic max): df_bn_gelu_apply_t with z.elt = 2 and
+ *                        df_bn_gelu_bwd_apply_t with dy_elt = 2 take that scalar in their z_amax / dy_amax argument (an INPUT then)
+ *   df_upsample2x_h2, df_h2_pack / df_h2_unpack, df_rows_l1max, df_h2_bound   helpers (see csrc/elementwise.hip) */
+int df_conv2d_h2p(df_img x, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y, const float* y_bound,
+                  int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                  int accumulate, float* y_amax, void* stream);
+int df_conv2d_h2p_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
+int df_conv2d_yh2(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y, const float* y_bound,
+                  int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
+                  int accumulate, void* stream);
+int df_conv2d_wgrad_h2p(df_img x, df_img dy, const float* x_bound, const float* dy_bound, int ksize, int stride, int pad, float* ws,
+                        int splits, float* bias_ws, void* stream);
+int df_conv2d_wgrad_h2p_ok(df_img x, df_img dy, int ksize, int stride);
+int df_conv2d_wgrad_h2p_splits(df_img x, df_img dy);   /* split-K count for df_conv2d_wgrad_h2p (one resident workgroup per CU) */
+int df_bn_finalize2(const float* partial, int tiles_per_group, int groups, int C, int64_t count_per_group, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* bn_ss,
+                    double* scratch, int splits, const float* y_amax, float* z_bound, void* stream);
+int df_bn_bwd_finalize2(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group, float* dgamma,
+                        float* dbeta, float* coef, const float* bn_ss, const float* dz_amax, const float* y_amax, float* dy_bound,
+                        void* stream);
+int df_upsample2x_h2(df_img x, df_img y, int align_corners, const float* y_bound, void* stream);
+int df_h2_pack(df_img x, const float* bound, df_img y, void* stream);
+int df_h2_unpack(df_img x, const float* bound, df_img y, void* stream);
+int df_rows_l1max(const float* w, int rows, int row_len, const float* bias, int nbias, float* l1max, float* bmax, void* stream);
+int df_h2_bound(float* out, const float* a, const float* l1, const float* b, const float* other, float slack, void* stream);
 
 /* ------------------------------------------------------- point decoder (A6-A10) --------
  * Replaces ConvGRUDecoder / LinearDecoder forward_single ([REF decoder.py:72-199]): integer

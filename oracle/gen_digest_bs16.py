@@ -4,6 +4,13 @@ with no CPU cost (VERDICT r2 next #6b).  Test infrastructure only.
 
     python oracle/gen_digest_bs16.py 256 20000      -> tests/golden/bs16_256_digest.npz
     python oracle/gen_digest_bs16.py 512 80000      -> tests/golden/bs16_512_digest.npz
+    python oracle/gen_digest_bs16.py 1024 160000 --batch 4 --voxel 0.1 --iters 8 --seed 20240116 --init-seed 46
+                                                    -> tests/golden/bs4_1024_it8_digest.npz   (BASELINE configs[4] per GPU:
+                                                       the shape of bench.py's `configs4_shape`; round 4)
+
+The CPU thread count is PINNED (torch.set_num_threads(8), recorded in the file): the fp32 oracle's sums depend on the
+partition of its reductions over threads, and its own error fields (`*.e32_*`) drifted by up to 20 % between regenerations
+when the count was left to the machine.
 
 Per parameter gradient (float64 oracle = the yardstick): max|g|, ||g||_2, NPROJ projections on seeded random sign vectors
 (an error vector e shows up in a projection as N(0, ||e||_2^2): the projections test the rms error without shipping 27 MB of
@@ -82,17 +89,32 @@ class SpillToDisk:
 
 
 def main():
-    grid, n_pts = int(sys.argv[1]), int(sys.argv[2])
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("grid", type=int)
+    ap.add_argument("n_pts", type=int)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--voxel", type=float, default=0.2)
+    ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=4242)
+    ap.add_argument("--init-seed", type=int, default=16)
+    ap.add_argument("--threads", type=int, default=8)
+    a = ap.parse_args()
+    grid, n_pts, B = a.grid, a.n_pts, a.batch
+    torch.set_num_threads(a.threads)
     from deflow_amd.synth import synth_batch
     from oracle import ref_torch as O
-    half = 0.1 * grid
-    cfg = dict(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid])
-    torch.manual_seed(16)
+    half = 0.5 * a.voxel * grid
+    cfg = dict(voxel_size=[a.voxel, a.voxel, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid],
+               num_iters=a.iters)
+    torch.manual_seed(a.init_seed)
     ref = O.DeFlow(**cfg).train()
     sd = copy.deepcopy(ref.state_dict())
     del ref
-    batch = synth_batch(16, n_pts, seed=4242, grid_hw=(grid, grid))
-    d = {"grid": grid, "n_pts": n_pts, "nproj": NPROJ}
+    # (the point spread follows the metric extent of the grid, as synth_batch's grid_hw does for the 0.2 m voxels)
+    batch = synth_batch(B, n_pts, seed=a.seed, grid_hw=(int(round(grid * a.voxel / 0.2)),) * 2)
+    d = {"grid": grid, "n_pts": n_pts, "nproj": NPROJ, "batch": B, "voxel": a.voxel, "iters": a.iters, "seed": a.seed,
+         "init_seed": a.init_seed, "threads": a.threads}
     outs = {}
     spill_root = os.environ.get("DF_DIGEST_SPILL", "/tmp/df_digest_spill")
     for tag in ("32", "64"):                       # one precision at a time, its tape released before the next
@@ -110,7 +132,7 @@ def main():
         print(tag, "loss", outs[tag][2], flush=True)
     (res32, g32, l32), (res64, g64, l64) = outs["32"], outs["64"]
     d["loss32"], d["loss64"] = l32, l64
-    for b in range(16):
+    for b in range(B):
         f64, f32 = res64["flow"][b].detach().double(), res32["flow"][b].detach().double()
         d[f"flow.{b}.count"] = f64.shape[0]
         d[f"flow.{b}.max"] = float(f64.abs().max()) if f64.numel() else 0.0
@@ -127,7 +149,8 @@ def main():
         d[f"grad.{k}.e32_rms"] = float((a - g).norm() / g.norm().clamp_min(1e-300))
         den = float(a.norm() * g.norm())
         d[f"grad.{k}.e32_cos"] = 0.0 if den == 0 else max(0.0, 1.0 - float(torch.dot(a.reshape(-1), g.reshape(-1))) / den)
-    out = os.path.join(ROOT, "tests", "golden", f"bs16_{grid}_digest.npz")
+    name = f"bs16_{grid}_digest.npz" if (B, a.iters) == (16, 4) else f"bs{B}_{grid}_it{a.iters}_digest.npz"
+    out = os.path.join(ROOT, "tests", "golden", name)
     np.savez_compressed(out, **d)
     print("wrote", out, os.path.getsize(out), "bytes")
 
