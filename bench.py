@@ -77,6 +77,41 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def sustained_mfma():
+    """What the 16-bit matrix pipe of THIS chip sustains, measured now (tools/mfma_peak_probe.hip, built by __graft_entry__.build()):
+    register-resident v_mfma_f32_32x32x16_f16 streams, nothing else running -- zero operands (no toggling: the nominal 2.5 PFLOP/s)
+    and random fp16 operands (the chip clocks down to its power budget).  The second figure / 3 is the roof an fp16x2 kernel can
+    reach on real data before it spends a joule on LDS, L2 or VALU."""
+    exe = os.path.join(ROOT, "deflow_amd", "_build", "mfma_peak_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "30000", "2"], capture_output=True, text=True, timeout=120)
+        z = [float(l.split()[-3]) for l in r.stdout.splitlines() if l.startswith("operands zero")]
+        q = [float(l.split()[-3]) for l in r.stdout.splitlines() if l.startswith("operands random")]
+        if not z or not q:
+            return None
+        return {"zero_operands_tflops": statistics.median(z), "random_operands_tflops": statistics.median(q)}
+    except Exception:   # noqa: BLE001 -- a missing figure, never a failed bench
+        return None
+
+
+def strict_leg(env_extra, steps, warmup, batch):
+    """the SAME training step in a fresh process with kernel forms switched by environment variables (the C side reads them once
+    per process): `python bench.py --no-extras --no-cpu-baseline --no-profile` -> (ms_per_step, pairs/s, loss)"""
+    env = dict(os.environ)
+    env.update(env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--no-profile", "--steps", str(steps),
+                            "--warmup", str(warmup), "--batch", str(batch)], capture_output=True, text=True, env=env, timeout=900)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"ms_per_step": d["ms_per_step"], "pairs_per_s": d["value"], "loss": d["config"]["loss"], "env": env_extra}
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300], "env": env_extra}
+
+
 def cpu_baseline(samples: int):
     """The oracle on ONE frame pair of the same workload (bounded sample), all host threads: a full training step and a
     forward-only pass, each the median of `samples` repetitions after 2 warm-ups."""
@@ -286,8 +321,9 @@ def main():
         # convs and weight gradients as two scaled fp16 planes per operand (22 significant bits, three MFMAs: <= 2e-6 vs float64),
         # the GRU decoder's GEMMs as two bf16 planes (16 bits, three MFMAs: <= 2.9e-5 vs float64), everything else fp32 MFMA.
         # DF_CONV_X3=0 DF_WGRAD_X3=0 DF_GRU_X2=0 put every GEMM back on the fp32 MFMA (107 pairs/s, round 2's step)
-        "dtype_note": ("f32 tensors and accumulation; GEMM operands: 3x3 convs fp16x2 (2 scaled fp16 planes, 3 MFMAs), GRU decoder bf16x2 "
-                       "(2 bf16 planes, 3 MFMAs), other layers fp32 MFMA" if (os.environ.get("DF_CONV_X3", "1") != "0" or os.environ.get("DF_GRU_X2", "1") != "0")
+        "dtype_note": ("f32 tensors and accumulation; GEMM operands: 3x3 convs fp16x2 (2 scaled fp16 planes, 3 MFMAs; between 3x3 layers the "
+                       "activations / gradients are STORED as those planes, 4 bytes per element), GRU decoder bf16x2 "
+                       "(2 bf16 planes, 3 MFMAs), other layers fp32 MFMA or fp16x2 on fragments; strict_fp32 / gru_fp32 = the same step with those forms off" if (os.environ.get("DF_CONV_X3", "1") != "0" or os.environ.get("DF_GRU_X2", "1") != "0")
                        else "f32 tensors, accumulation and MFMA operands"),
         "config": {"workload": "deflow train step (deflowLoss, Adam lr=2e-4): BASELINE configs[2] per GPU", "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
@@ -316,7 +352,9 @@ def main():
                         f"{flops / ms_ / 1e9:8.1f} TF/s  {tag}\n")
     if prof is not None:
         summ = prof.summary()
-        conv = {k: v for k, v in summ.items() if k.startswith("conv_")}
+        # dominant kernel = the MFMA kernel (convolutions AND weight gradients; the GRU kernels are priced in roofline_hbm) with the
+        # largest share of the timed region
+        conv = {k: v for k, v in summ.items() if v["flops"] > 0 and not k.startswith("gru_") and (k.startswith("conv_") or k.startswith("wgrad"))}
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -335,8 +373,8 @@ def main():
         # forms (template argument NP = 2, the default since round 3) as THREE fp16 MFMAs per algorithmic multiply -- roof = dense
         # fp16 MFMA peak (= the bf16 one, 2500) / 3 = 833.3 algorithmic TFLOP/s; the bf16x3 forms (DF_CONV_H2=0) as SIX bf16 MFMAs
         # -- roof 416.7.  Neither is the fp32-MFMA peak (157.3) the round-1/2 kernels were priced against, which they exceed.
-        x3 = "_x3_" in dom
-        nmfma = (3 if dom.rstrip(">").endswith(",2") else 6) if x3 else 1
+        x3 = "_x3_" in dom or "wgrad3_h2p" in dom
+        nmfma = (3 if (dom.rstrip(">").endswith(",2") or dom.endswith(",xp>") or "h2p" in dom or dom == "wgrad3_x3_kernel<2>") else 6) if x3 else 1
         peak = PEAK_BF16_MFMA_TFLOPS / nmfma if x3 else PEAK_F32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                            "frac": achieved / peak, "traffic": traffic, "kernel": dom,
@@ -351,6 +389,39 @@ def main():
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
                                                     "ms_per_step": v["ms"] / args.steps,
                                                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in mfma.items()}}
+        # the whole fp16x2 family (every 3x3 stride-1 convolution, data gradient and weight gradient of the step): flop-weighted
+        fam = [v for k, v in mfma.items() if ("_x3_" in k and (k.rstrip(">").endswith(",2") or k.endswith(",xp>"))) or "wgrad3_h2p" in k or k == "wgrad3_x3_kernel<2>"]
+        if fam:
+            ft = sum(v["flops"] for v in fam) / (sum(v["ms"] for v in fam) * 1e-3) / 1e12
+            out["roofline"]["fp16x2_family"] = {"ms_per_step": sum(v["ms"] for v in fam) / args.steps, "tflops": ft,
+                                                "frac": ft / (PEAK_BF16_MFMA_TFLOPS / 3.0),
+                                                "share_of_step": sum(v["ms"] for v in fam) / args.steps / ms}
+        sus = sustained_mfma()
+        if sus is not None:
+            # the chip sustains the nominal 16-bit peak only on operands that toggle nothing; under random operands a PURE MFMA stream
+            # (no LDS, no memory) runs at the power-limited clock: that figure / 3 is the reachable roof of the fp16x2 kernels
+            clk = 2.4 * sus["random_operands_tflops"] / PEAK_BF16_MFMA_TFLOPS
+            out["roofline"]["sustained"] = {
+                "mfma_16bit_tflops_zero_operands": sus["zero_operands_tflops"], "mfma_16bit_tflops_random_operands": sus["random_operands_tflops"],
+                "sustained_clock_ghz": clk, "peak_at_sustained_clock": sus["random_operands_tflops"] / nmfma if x3 else None,
+                "frac_at_sustained_clock": (achieved / (sus["random_operands_tflops"] / nmfma)) if x3 else None,
+                "note": "register-resident v_mfma_f32_32x32x16_f16 stream measured in this run (tools/mfma_peak_probe.hip): the matrix pipe alone, "
+                        "clock = 2.4 GHz x random / 2500"}
+        try:   # worst three-way errors at configs[2] from the committed parity report of this round's GPU test run
+            worst = {}
+            with open(os.path.join(ROOT, "profiles", "r04_parity_report.jsonl")) as f:
+                for line in f:
+                    e = json.loads(line)
+                    if e.get("test") in ("bs16_512", "bs16_512_gru_fp32") and "max_proj_err_over_l2" in e:
+                        w = worst.setdefault(e["test"], {"worst_rms_rel": 0.0, "tensor": "", "bound": e.get("rms_bound")})
+                        if e["max_proj_err_over_l2"] > w["worst_rms_rel"]:
+                            w["worst_rms_rel"], w["tensor"] = e["max_proj_err_over_l2"], e.get("tensor", "")
+            if worst:
+                out["model_error_budget"] = {"workload": "configs[2] (B=16, 512x512, 80k pts) training step vs the float64 oracle digests: worst "
+                                                         "|projection error| / ||g|| over every parameter gradient (a few sigma of the rms-relative error); "
+                                                         "bound 1e-4 x 4.5 sigma", **worst}
+        except Exception:   # noqa: BLE001
+            pass
         # HBM-bound stages and the GRU kernels: algorithmic bytes / measured time / 8 TB/s
         hbm = {}
 
@@ -508,6 +579,11 @@ def main():
             "fp32_ms_per_step": res4["fp32"], "bf16_ms_per_step": res4["bf16"], "bf16_pairs_per_s": 4e3 / res4["bf16"],
             "speedup_vs_fp32": res4["fp32"] / res4["bf16"], "loss": float(l4)}
         del big, bb, tb
+        torch.cuda.empty_cache()
+        # the precision ladder beside the headline: the same step with EVERY GEMM on the fp32 MFMA, and with only the
+        # GRU decoder back on it -- fresh processes, because the library reads its switches once
+        out["strict_fp32"] = strict_leg({"DF_CONV_X3": "0", "DF_WGRAD_X3": "0", "DF_CONV_H2F": "0", "DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
+        out["gru_fp32"] = strict_leg({"DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
     if use_dist:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:

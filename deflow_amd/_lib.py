@@ -73,6 +73,7 @@ _SIGS = {
     "df_conv2d_h2f": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2p": [DfImg, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2p_ok": [DfImg, DfImg, I, I, I, I],
+    "df_conv2d_h2p_dgrad_bn": [DfImg, P, P, P, DfImg, P, P, P, P, P],
     "df_conv2d_yh2": [DfImg, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_wgrad_h2p": [DfImg, DfImg, P, P, I, I, I, P, I, P, P],
     "df_conv2d_wgrad_h2p_ok": [DfImg, DfImg, I, I],
@@ -181,6 +182,12 @@ def _elt(t: torch.Tensor) -> int:
     raise TypeError(f"df_img: unsupported dtype {t.dtype}")
 
 
+def ver(t: torch.Tensor) -> int:
+    """write epoch of a tensor for the max |x| records: torch's version counter; tensors created under torch.inference_mode() do
+    not track one (reading it raises) -- they never carry a record (-1 matches nothing: the consumer measures with df_absmax)"""
+    return -1 if t.is_inference() else t._version
+
+
 def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
     """Descriptor of an NHWC-shaped tensor [N,H,W,C'] (stride(3) == 1); optional channel slice [c_off, c_off+c).
     float32 or bfloat16 (the element type travels in the descriptor; only the bf16-storage entry points accept bfloat16)."""
@@ -198,7 +205,7 @@ def img(t: torch.Tensor, c: Optional[int] = None, c_off: int = 0) -> DfImg:
     # has written t since (the kernels write through raw pointers and leave torch's version counter alone; an in-place torch op
     # bumps it, and the bound is dropped)
     rec = getattr(t, "_df_amax", None)
-    if rec is not None and rec[1] == t._version:
+    if rec is not None and rec[1] == ver(t) and rec[1] >= 0:
         d._amax = rec[0]
     if c_off == 0 and c == cc:
         d._src = t                       # whole-tensor descriptor: a producer may leave the bound on the tensor (ops.conv2d)
@@ -211,4 +218,9 @@ def img_pair(t: torch.Tensor, c: int) -> DfImg:
     assert t.dim() == 4 and t.shape[3] == 2 * c and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
     n, h, w, _ = t.shape
     assert getattr(t, "_df_h2", None) is None
-    return DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c, _elt(t), 0)
+    d = DfImg(t.data_ptr(), 2 * n, h, w, c, t.stride(2), n, t.stride(0), c, _elt(t), 0)
+    rec = getattr(t, "_df_amax", None)      # (the pair view covers the whole tensor: its bound applies)
+    if rec is not None and rec[1] == ver(t) and rec[1] >= 0:
+        d._amax = rec[0]
+    d._src = t
+    return d

@@ -139,6 +139,7 @@ def deflow_backward(model, st: dict, dflow: torch.Tensor, params: List[torch.Ten
             call("df_conv2d_wgrad_reduce", ptr(ws1), nb * B, 64, 9, 32, ptr(dw1), 9 * 32, cloud, stream())
             call("df_pillar_input_grad", ptr(pst.key_sorted), ptr(pst.counts), B, H, W, cloud, ptr(dy1), ptr(w1),
                  img(dcat, lat, lat), ptr(w3), img(dbstar, 32, 32 * cloud), 1, nb, stream())  # one 16-wave workgroup per CU
+        ops.wrote(dbstar)
         grads[bb.encoder_step_1[0].conv.weight] = dw1.permute(0, 3, 1, 2)
         if TAP is not None:
             TAP("canvas_grad", dy1=dy1, dskip=dcat[..., lat:], dbstar=dbstar)

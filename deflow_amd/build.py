@@ -94,5 +94,25 @@ def build(verbose: bool = False, force: bool = False) -> str:
     return LIB
 
 
+def build_probe(verbose: bool = False) -> str:
+    """tools/mfma_peak_probe.hip -> deflow_amd/_build/mfma_peak_probe: the stand-alone measurement of what the 16-bit matrix pipe
+    sustains on this chip (zero / random operands), which bench.py runs beside the training step for `roofline.sustained_*`.
+    A measuring tool, not part of the library."""
+    src = os.path.join(os.path.dirname(HERE), "tools", "mfma_peak_probe.hip")
+    out = os.path.join(BUILD, "mfma_peak_probe")
+    os.makedirs(BUILD, exist_ok=True)
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-w", "-o", out, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed on mfma_peak_probe.hip")
+    return out
+
+
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))
+    print(build_probe(verbose=True))

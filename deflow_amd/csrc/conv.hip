@@ -85,7 +85,15 @@ struct ConvParams {
   const float* amax_w;   // set the power-of-two scales of the two fp16 planes
   unsigned* amax_y;      // optional: the epilogue leaves max |y| there (bit pattern, atomic max) for an fp16x2 consumer of y
   const float* bound_y;  // y.elt == 2 (pre-split output): the bound of max |y| that defines the output's power-of-two scale
+  // DF_EPI_BWD_STATS (round 4; data gradient only): y = dz is the gradient of a BatchNorm + GELU layer's OUTPUT.  bwd_y = that layer's
+  // conv output (fp32, the geometry of y), bwd_ss = its (scale, shift, mean, invstd) per statistic group [groups][4][N]; the
+  // epilogue leaves per tile and channel (sum g, sum g xhat), g = dz gelu'(bn(y)), in `stats` -- the partials of the BatchNorm
+  // backward, which otherwise cost a separate pass over dz and y (bn_gelu_bwd_reduce_kernel)
+  const float* bwd_y;
+  const float* bwd_ss;
 };
+constexpr int DF_EPI_BWD_STATS = 3;
+__host__ __device__ inline bool epi_stats(int epi) { return epi == DF_EPI_STATS || epi == DF_EPI_BWD_STATS; }
 
 // row m of the (possibly class-ordered) GEMM -> image, output y, output x
 struct RowDecode {
@@ -144,6 +152,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // [32 fp16 hi | 32 fp16 lo] of y s, s = df_h2_scale(*p.bound_y) (a bound of max |y| the caller knows before the launch).  A lane
     // owns one channel of the chunk (li): lanes exchange halves with their neighbour (one DPP move) so that every lane still stores
     // ONE dword per element -- even lanes the hi pair (channels li, li + 1), odd lanes the lo pair (li - 1, li).
+    const bool bws = p.epi == DF_EPI_BWD_STATS;
+    const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bws ? p.bwd_y : reinterpret_cast<const float*>(p.y.ptr)), 0,
+                                                                         p.y_bytes, 0x00020000);
+    int bgrp = 0;
+    if (bws) {
+      int n_, oy_, ox_;
+      dec(m0, n_, oy_, ox_);
+      bgrp = n_ / p.y.grp_size;           // statistic group of this tile (a tile never straddles two)
+    }
     auto body = [&](auto y_tag) {
       constexpr int YT = decltype(y_tag)::value;
       constexpr bool Y16 = YT == 1, YH2 = YT == 2;
@@ -160,6 +177,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           sh = p.shift[co];
         }
         float s1 = 0.f, s2 = 0.f;
+        float b_sc = 1.f, b_sh = 0.f, b_mu = 0.f, b_is = 1.f;
+        if (bws) {
+          const float* ss = p.bwd_ss + (int64_t)bgrp * 4 * p.N;
+          b_sc = ss[co]; b_sh = ss[p.N + co]; b_mu = ss[2 * p.N + co]; b_is = ss[3 * p.N + co];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           unsigned ob[16];
@@ -170,6 +192,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             else ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
           }
           float old[16];
+          if (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
+#pragma unroll
+            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], 0, 0));
+          }
           if (p.accumulate) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -201,13 +227,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
             }
             if (ob[e] != ROW_BAD) {
-              s1 += v;
-              s2 += v * v;
+              if (bws) {
+                const float g = v * df_gelu_grad(fmaf(old[e], b_sc, b_sh));
+                s1 += g;
+                s2 += g * ((old[e] - b_mu) * b_is);
+              } else {
+                s1 += v;
+                s2 += v * v;
+              }
               amax_t = fmaxf(amax_t, fabsf(v));
             }
           }
         }
-        if (p.epi == DF_EPI_STATS) {
+        if (epi_stats(p.epi)) {
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
           if (kh == 0) {
@@ -260,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       }
     }
   }
-  if (p.epi == DF_EPI_STATS) {
+  if (epi_stats(p.epi)) {
     __syncthreads();
     if (tid < BN) {
       float s1 = 0.f, s2 = 0.f;
@@ -3069,9 +3101,9 @@ bool img_ok(const df_img& d, bool any16 = false) {
 static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi) {
   if (cout % 64) return 128032;
   static const int force = getenv("DF_CONV_TILE") ? atoi(getenv("DF_CONV_TILE")) : 0;  // A/B experiments only
-  if (force == 128064 && rows > 128 * 256 && (epi != DF_EPI_STATS || rows_per_stat_group % 128 == 0)) return 128064;
+  if (force == 128064 && rows > 128 * 256 && (!epi_stats(epi) || rows_per_stat_group % 128 == 0)) return 128064;
   int bm;
-  if (epi == DF_EPI_STATS) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
+  if (epi_stats(epi)) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
   else {
     static const int small_rows = getenv("DF_CONV_SMALL_ROWS") ? atoi(getenv("DF_CONV_SMALL_ROWS")) : 64 * 128;
     bm = (rows <= small_rows) ? 64 : 128;  // small problems: more tiles to fill 256 CUs (8192 rows measured best at B = 1, 4)
@@ -3080,7 +3112,7 @@ static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int
   if (cout % 128 == 0) return 128128;
   // 64 output channels: 128x64 (48 KB LDS -> 3 workgroups/CU) measured 120 vs 115 TFLOP/s for the 256x64 tile
   static const int use256 = getenv("DF_CONV_TILE") ? atoi(getenv("DF_CONV_TILE")) == 256064 : 0;
-  const bool ok256 = use256 && ((epi == DF_EPI_STATS) ? (rows_per_stat_group % 256 == 0) : (rows >= 256 * 512 && rows % 256 == 0));
+  const bool ok256 = use256 && (epi_stats(epi) ? (rows_per_stat_group % 256 == 0) : (rows >= 256 * 512 && rows % 256 == 0));
   return ok256 ? 256064 : 128064;
 }
 
@@ -3107,7 +3139,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr,
                        const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr,
-                       const float* y_bound = nullptr);
+                       const float* y_bound = nullptr, const float* bwd_y = nullptr, const float* bwd_ss = nullptr);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -3161,9 +3193,21 @@ extern "C" int df_conv2d_h2(df_img x, const void* w2, const float* x_amax, const
 extern "C" int df_conv2d_h2p(df_img x, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y,
                              const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
                              const float* shift, float* stats_partial, int accumulate, float* y_amax, void* stream) {
-  DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax, DF_E_ALIGN);
+  DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax && epi != DF_EPI_BWD_STATS, DF_E_ALIGN);
   return conv2d_impl(x, nullptr, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false,
                      stream, w2, x_amax, w_amax, y_amax, y_bound);
+}
+
+// the 3x3 stride-1 fp16x2 DATA GRADIENT (x = dy: fp32 or pre-split; dz = fp32, contiguous) whose epilogue also leaves the partial
+// sums of the BatchNorm + GELU backward of the layer in front -- per tile and channel (sum g, sum g xhat), g = dz gelu'(bn(y)) --
+// in bwd_partial ([rows / df_conv2d_tile_m][C][2], the layout df_bn_bwd_finalize reads): bn_y = that layer's conv output (the
+// geometry of dz), bn_ss = its statistics per group of dz.grp_size images.  Replaces one full pass over dz and y per layer
+// (df_bn_gelu_bwd_reduce).  [REF decoder.py:202-220]: the backward of `nonlinearity(batchnorm(conv(x)))` meeting the next layer's conv
+extern "C" int df_conv2d_h2p_dgrad_bn(df_img x, const void* w2, const float* x_amax, const float* w_amax, df_img dz, const float* bn_y,
+                                      const float* bn_ss, float* bwd_partial, float* dz_amax, void* stream) {
+  DF_REQUIRE(w2 && df_aligned16(w2) && x_amax && w_amax && bn_y && bn_ss && bwd_partial, DF_E_ALIGN);
+  return conv2d_impl(x, nullptr, nullptr, nullptr, dz, 3, 1, 1, DF_CONV_DGRAD, DF_EPI_BWD_STATS, nullptr, nullptr, bwd_partial, 0, 0, false,
+                     stream, w2, x_amax, w_amax, dz_amax, nullptr, bn_y, bn_ss);
 }
 
 extern "C" int df_conv2d_h2p_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi) {
@@ -3248,7 +3292,7 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3, const float* h2_amax_x,
-                       const float* h2_amax_w, float* y_amax, const float* y_bound) {
+                       const float* h2_amax_w, float* y_amax, const float* y_bound, const float* bwd_y, const float* bwd_ss) {
   if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
@@ -3264,7 +3308,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   DF_REQUIRE(x.n == y.n, DF_E_SHAPE);
   DF_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && pad == ksize / 2, DF_E_SHAPE);
   DF_REQUIRE(mode == DF_CONV_FWD || mode == DF_CONV_DGRAD, DF_E_ARG);
-  DF_REQUIRE(epi >= 0 && epi <= 2, DF_E_ARG);
+  DF_REQUIRE(epi >= 0 && epi <= 3, DF_E_ARG);
   DF_REQUIRE(x.c % BK == 0 && y.c % 32 == 0, DF_E_SHAPE);
   if (mode == DF_CONV_FWD) {
     DF_REQUIRE(y.h == (x.h + 2 * pad - ksize) / stride + 1 && y.w == (x.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
@@ -3272,7 +3316,9 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     DF_REQUIRE(x.h == (y.h + 2 * pad - ksize) / stride + 1 && x.w == (y.w + 2 * pad - ksize) / stride + 1, DF_E_SHAPE);
   }
   if (epi == DF_EPI_BN_GELU) DF_REQUIRE(scale && shift, DF_E_ARG);
-  if (epi == DF_EPI_STATS) DF_REQUIRE(stats_partial, DF_E_ARG);
+  if (epi_stats(epi)) DF_REQUIRE(stats_partial, DF_E_ARG);
+  if (epi == DF_EPI_BWD_STATS)      // fused BatchNorm-backward partials: the fp16x2 data gradient with a plain fp32 output only
+    DF_REQUIRE(mode == DF_CONV_DGRAD && w3 && h2_amax_x && (query || (bwd_y && bwd_ss)) && y.elt == 0 && !accumulate && y.ld == y.c && !bias, DF_E_ARG);
   ConvParams p;
   p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
@@ -3282,6 +3328,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.amax_w = h2_amax_w;
   p.amax_y = reinterpret_cast<unsigned*>(y_amax);
   p.bound_y = y_bound;
+  p.bwd_y = bwd_y;
+  p.bwd_ss = bwd_ss;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -3295,7 +3343,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   if (cls) rows = M / 4;
   int var = pick_variant(rows, rows_per_group, p.N, epi);
   int bm = var / 1000;
-  if (epi == DF_EPI_STATS) DF_REQUIRE(rows_per_group % bm == 0, DF_E_SHAPE);
+  if (epi_stats(epi)) DF_REQUIRE(rows_per_group % bm == 0, DF_E_SHAPE);
   if (cls && rows % bm == 0) {
     p.cls_tiles = (int)(rows / bm);
     p.tiles_m = 4 * p.cls_tiles;
@@ -3342,10 +3390,10 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     if (ok && xp) {
       const int seg_ = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
       const int seg64_ = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;
-      const bool big128 = var == 128128 && seg_ && (y.h % seg_) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+      const bool big128 = var == 128128 && seg_ && (y.h % seg_) == 0 && (M % 256) == 0 && (!epi_stats(epi) || rows_per_group % 256 == 0) &&
                           M / 256 * p.tiles_n >= 512;
       const bool big64 = var != 128128 && !two && seg64_ && (y.h % seg64_) == 0 && (M % 512) == 0 &&
-                         (epi != DF_EPI_STATS || rows_per_group % 512 == 0) && M / 512 >= 512;
+                         (!epi_stats(epi) || rows_per_group % 512 == 0) && M / 512 >= 512;
       ok = big128 || big64;
     }
     if (query) return ok ? 1 : 0;
@@ -3357,7 +3405,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     p.amax_w = h2_amax_w;
     static const int bm256 = getenv("DF_CONV_X3_BM256") ? atoi(getenv("DF_CONV_X3_BM256")) : 1;
     // 64 output channels: 256-pixel row tiles where the image allows (wave tile 64 x 32 instead of 32 x 32)
-    const bool wide = !two && var != 128128 && bm256 && (y.w % 256) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0);
+    const bool wide = !two && var != 128128 && bm256 && (y.w % 256) == 0 && (M % 256) == 0 && (!epi_stats(epi) || rows_per_group % 256 == 0);
     if (wide) {
       p.tiles_m = (int)(M / 256);
       p.stats_mul = 2;
@@ -3368,7 +3416,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
       // rows of a W == 128 image, four of a W == 64 one
       static const int big = getenv("DF_CONV_H2_BM256") ? atoi(getenv("DF_CONV_H2_BM256")) : 1;
       const int seg = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
-      if (big && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+      if (big && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (!epi_stats(epi) || rows_per_group % 256 == 0) &&
           M / 256 * p.tiles_n >= 512) {
         p.tiles_m = (int)(M / 256);
         p.stats_mul = 2;
@@ -3383,7 +3431,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
       }
       // 64 output channels: 512 x 64 tiles (8 x 1 waves of 64 x 64): 512 pixels of one row, or two rows of a W == 256 image
       const int seg64 = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;
-      if (big && var != 128128 && !two && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (epi != DF_EPI_STATS || rows_per_group % 512 == 0) &&
+      if (big && var != 128128 && !two && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (!epi_stats(epi) || rows_per_group % 512 == 0) &&
           M / 512 >= 512) {
         p.tiles_m = (int)(M / 512);
         p.stats_mul = 4;
@@ -3417,7 +3465,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
         // this kernel's register-staged halo costs more than conv_halo_w16_kernel's
       static const int wide = getenv("DF_W16_WIDE") ? atoi(getenv("DF_W16_WIDE")) : 0;
       const int seg = (y.w % 256) == 0 ? 1 : y.w == 128 ? 2 : y.w == 64 ? 4 : 0;
-      if (wide && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (epi != DF_EPI_STATS || rows_per_group % 256 == 0) &&
+      if (wide && var == 128128 && seg && (y.h % seg) == 0 && (M % 256) == 0 && (!epi_stats(epi) || rows_per_group % 256 == 0) &&
           M / 256 * p.tiles_n >= 512) {
         p.tiles_m = (int)(M / 256);
         p.stats_mul = 2;
@@ -3431,7 +3479,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
         return launch_conv_halo_x3<256, 128, 4, 2, 4, 8, 1, false>(p, s);
       }
       const int seg64 = (y.w % 512) == 0 ? 1 : y.w == 256 ? 2 : 0;    // 64 output channels: 512 x 64 tiles, 8 x 1 waves
-      if (wide && var == 128064 && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (epi != DF_EPI_STATS || rows_per_group % 512 == 0) &&
+      if (wide && var == 128064 && seg64 && (y.h % seg64) == 0 && (M % 512) == 0 && (!epi_stats(epi) || rows_per_group % 512 == 0) &&
           M / 512 >= 512) {
         p.tiles_m = (int)(M / 512);
         p.stats_mul = 4;

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import DfImg, call, img, ptr, stream
+from ._lib import DfImg, call, img, ptr, stream, ver
 
 CONV_FWD, CONV_DGRAD = 0, 1
 EPI_BIAS, EPI_STATS, EPI_BN_GELU = 0, 1, 2
@@ -214,6 +214,13 @@ def amax_of(d: DfImg, device) -> torch.Tensor:
     return a
 
 
+def wrote(t: torch.Tensor) -> None:
+    """a kernel wrote (accumulated into) t through a raw pointer, without measuring: whatever bound t carried is no longer one
+    (the kernels leave torch's version counter alone, so the record would otherwise stay 'valid' -- ADVICE r3)"""
+    if getattr(t, "_df_amax", None) is not None:
+        t._df_amax = None
+
+
 def _h2_on() -> bool:
     return os.environ.get("DF_CONV_H2", "1") != "0"
 
@@ -292,9 +299,12 @@ def _split_h2(w_ohwi: torch.Tensor):
 
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
            mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False,
-           amax_out: Optional[torch.Tensor] = None):
+           amax_out: Optional[torch.Tensor] = None, bwd_bn=None):
     """amax_out: the slot the output's max |y| is accumulated into (fp16x2 mode; default: a fresh one) -- several producers of one
-    buffer (the two halves of a concatenation) share a slot"""
+    buffer (the two halves of a concatenation) share a slot.
+    bwd_bn = (y_prev, bn_ss_prev, partial): a 3x3 stride-1 DATA gradient whose output is the gradient of a BatchNorm + GELU layer's
+    output -- the fp16x2 kernel's epilogue then also leaves that layer's backward partial sums in `partial` (df_conv2d_h2p_dgrad_bn).
+    -> True if it did (the caller then skips ops.bn_gelu_bwd's reduce pass); ignored (False) on any other kernel."""
     prof = PROFILER
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -321,10 +331,19 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         y._amax = ya
         src = getattr(y, "_src", None)      # the descriptor covers a whole tensor: descriptors made of it later inherit the bound
         if src is not None:
-            src._df_amax = (ya, src._version)
+            src._df_amax = (ya, ver(src))
+    if ya is None and getattr(y, "_src", None) is not None:
+        wrote(y._src)          # (an unmeasured write into a tensor that carried a bound)
     h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2) and x.c % 64 == 0
            and getattr(x, "_amax", None) is not None and os.environ.get("DF_CONV_H2F", "1") != "0")
-    if h2 and pre:
+    fused_bn = False
+    if (h2 and bwd_bn is not None and mode == CONV_DGRAD and y.elt == 0 and not accumulate and bias is None and y.ld == y.c
+            and os.environ.get("DF_FUSE_BN_BWD", "1") != "0" and call("df_conv2d_h2p_ok", x, y, ks, stride, mode, 3) == 1):
+        w2, wa = _split_h2(w_ohwi)
+        yp, ssp, part = bwd_bn
+        call("df_conv2d_h2p_dgrad_bn", x, ptr(w2), ptr(amax_of(x, w_ohwi.device)), ptr(wa), y, ptr(yp), ptr(ssp), ptr(part), ptr(ya), stream())
+        fused_bn = True
+    elif h2 and pre:
         w2, wa = _split_h2(w_ohwi)
         call("df_conv2d_h2p", x, ptr(w2), ptr(amax_of(x, w_ohwi.device)), ptr(wa), ptr(bias), y, ptr(y._amax) if y.elt == 2 else None,
              ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats), 0, ptr(ya), stream())
@@ -408,6 +427,7 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
                     and m_rows // 512 >= 512):
                 name = f"conv_halo_x3_kernel<512,64,8,1,{seg64},8,1,{'true' if x.elt else 'false'}>"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
+    return fused_bn
 
 
 def conv_tile_m(rows_per_group: int, cout: int) -> int:
@@ -505,7 +525,7 @@ def _pow2_blocks(rows_per_group: int, cap: int = 512) -> int:
 
 def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group: int, groups: int, gamma_grad: bool = True,
                 frozen: bool = False, dy_dtype: torch.dtype = torch.float32, dy_h2: bool = False,
-                y_amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                y_amax: Optional[torch.Tensor] = None, partial_pre=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> dy [n,h,w,C] (dy_dtype: float32, or bfloat16 in the bf16-storage mode), dgamma [C], dbeta [C], dbias [C].
     dy_h2 (with y_amax = max |y| from the forward's conv epilogue): dy is written pre-split (ops.h2_empty) with the scale of the
     bound the finalisation derives from max |dz|, max |y| and the statistics.
@@ -516,17 +536,23 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
     rows_per_group = imgs_per_group * dz.h * dz.w
     nbg = _pow2_blocks(rows_per_group)
     nblk = nbg * groups
-    partial = _f32(nblk, C, 2, device=dev)
     gb = 2.0 if dz.elt else 4.0
-    with timed("bn_gelu_bwd_reduce", bytes=(gb + y.element_size()) * y.numel()):     # read dz, y
-        call("df_bn_gelu_bwd_reduce_t", dz, ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
+    if partial_pre is not None:
+        # the partial sums came out of the epilogue of the data gradient that produced dz (ops.conv2d bwd_bn): [groups * nbp][C][2]
+        partial, nbp = partial_pre
+        nbg_fin = nbp
+    else:
+        partial = _f32(nblk, C, 2, device=dev)
+        nbg_fin = nbg
+        with timed("bn_gelu_bwd_reduce", bytes=(gb + y.element_size()) * y.numel()):     # read dz, y
+            call("df_bn_gelu_bwd_reduce_t", dz, ptr(y), _elt(y), ptr(bn_ss), imgs_per_group, ptr(partial), nblk, stream())
     dy_bound = None
     if dy_h2:
         assert y_amax is not None and dy_dtype == torch.float32 and dz.elt == 0 and y.dtype == torch.float32
         dy_bound = amax_slot(dev)
         dz_amax = amax_of(dz, dev)
     if SYNC is not None and not frozen:
-        red = partial.view(groups, nbg, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
+        red = partial.view(groups, nbg_fin, C, 2).to(torch.float64).sum(1)          # [groups, C, (sum g, sum g * xhat)], this rank
         dbeta, dgamma = red[:, :, 0].sum(0).float(), red[:, :, 1].sum(0).float()
         glob = SYNC.sum(red.clone()) / (float(rows_per_group) * SYNC.world)
         coef = glob.permute(0, 2, 1).contiguous().float()                        # [groups, 2, C]
@@ -538,10 +564,10 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
         dgamma, dbeta = _f32(C, device=dev), _f32(C, device=dev)
         coef = _f32(groups, 2, C, device=dev)
         if dy_h2:
-            call("df_bn_bwd_finalize2", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(bn_ss),
+            call("df_bn_bwd_finalize2", ptr(partial), nbg_fin, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(bn_ss),
                  ptr(dz_amax), ptr(y_amax), ptr(dy_bound), stream())
         else:
-            call("df_bn_bwd_finalize", ptr(partial), nbg, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
+            call("df_bn_bwd_finalize", ptr(partial), nbg_fin, groups, C, rows_per_group, ptr(dgamma), ptr(dbeta), ptr(coef), stream())
         if frozen:
             coef.zero_()
     dy = h2_empty(y.shape, dev, dy_bound) if dy_h2 else torch.empty(y.shape, dtype=dy_dtype, device=dev)
@@ -551,7 +577,7 @@ def bn_gelu_bwd(dz: DfImg, y: torch.Tensor, bn_ss: torch.Tensor, imgs_per_group:
         call("df_bn_gelu_bwd_apply_t", dz, ptr(y), _elt(y), ptr(bn_ss), ptr(coef), imgs_per_group, ptr(dy), 2 if dy_h2 else _elt(dy), ptr(dbp), nblk,
              ptr(a), stream())
         if a is not None and not dy_h2:
-            dy._df_amax = (a, dy._version)          # _lib.img() hands it on to the descriptors made of this tensor
+            dy._df_amax = (a, ver(dy))          # _lib.img() hands it on to the descriptors made of this tensor
     dbias = _f32(C, device=dev)
     call("df_colsum_finalize", ptr(dbp), nblk, C, 1, ptr(dbias), 0, stream())
     return dy, dgamma, dbeta, dbias

@@ -297,7 +297,18 @@ class Trainer:
             if self.sink.delivered:   # bucketed, already in flight; then whatever did not go through the sink
                 rest = sorted(self.sink.slot_of[p.data_ptr()] for p in self.flat.params if not self.sink.was_delivered(p))
                 if rest:
-                    self.sink.all_reduce_runs([(off, off + n) for off, n in rest])
+                    if self.sink.cap is not None:
+                        # capture: these gradients were written into the arena by kernels of the OPEN segment, which `fresh` does not
+                        # know about (only deliver() clears it) -- close the segment before their collective (the
+                        # all-reduce must not be placed in front of the graph that computes its operand)
+                        self.sink.cap.touch()
+                    runs = [[rest[0][0], rest[0][0] + rest[0][1]]]
+                    for off, n in rest[1:]:       # merge adjacent slots (16-byte padding between them), as deliver() does
+                        if off <= runs[-1][1] + 3:
+                            runs[-1][1] = max(runs[-1][1], off + n)
+                        else:
+                            runs.append([off, off + n])
+                    self.sink.all_reduce_runs([(lo, hi) for lo, hi in runs])
             else:
                 self.sink.all_reduce_runs([(0, self.flat.numel)])
             self.sink.finish()

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import DfImg, call, img, img_pair, ptr, stream
+from ._lib import DfImg, call, img, img_pair, ptr, stream, ver
 
 import os
 _NO_FUSED_BIAS = bool(int(os.environ.get("DF_NO_FUSED_BIAS", "0")))  # A/B switch: separate column-sum pass for conv bias grads
@@ -190,7 +190,7 @@ class FastFlow3DUNet(nn.Module):
                     z = img(keep)
                 _cwn_forward(m, x, z, 2 * B, 2, train, tape, store16, h2s)
                 if i == len(stage) - 1 and getattr(z, "_amax", None) is not None:
-                    cat._df_amax = (z._amax, cat._version)      # the two clouds' images ARE the skip tensor: its readers inherit the bound
+                    cat._df_amax = (z._amax, ver(cat))      # the two clouds' images ARE the skip tensor: its readers inherit the bound
                 alive.append(keep)  # without this a no-tape run would free x's tensor before the next conv reads it
                 if tape is not None:
                     tape.append(("keep", keep))
@@ -246,7 +246,7 @@ class FastFlow3DUNet(nn.Module):
             tape.append(("up", h, w, lat))
         self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=None if h2d else cat_amax)
         if cat_amax is not None and not h2d:
-            cat._df_amax = (cat_amax, cat._version)
+            cat._df_amax = (cat_amax, ver(cat))
         if h2d:
             u4 = ops.h2_empty((B, 2 * h, 2 * w, outc), dev,
                               ops.conv_out_bound(img(cat), ops.ohwi(m.u4_u5[0].weight), m.u4_u5[0].bias.detach(), dev))
@@ -356,11 +356,14 @@ class FastFlow3DUNet(nn.Module):
     # ------------------------------------------------------------------------------ backward ----
     @staticmethod
     def _conv_bwd(m: nn.Conv2d, x: DfImg, dy: DfImg, ks: int, stride: int, dx: Optional[DfImg], acc_dx: bool,
-                  grads: dict, with_bias: bool = True, wt: Optional[torch.Tensor] = None):
+                  grads: dict, with_bias: bool = True, wt: Optional[torch.Tensor] = None, bwd_bn=None) -> bool:
+        """-> True if the data gradient's epilogue also produced the BatchNorm-backward partials asked for with bwd_bn"""
         w = ops.ohwi(m.weight)
         dev = w.device
+        fused = False
         if dx is not None:
-            ops.conv2d(dy, ops.weight_transpose(w) if wt is None else wt, None, dx, ks, stride, mode=ops.CONV_DGRAD, accumulate=acc_dx)
+            fused = ops.conv2d(dy, ops.weight_transpose(w) if wt is None else wt, None, dx, ks, stride, mode=ops.CONV_DGRAD,
+                               accumulate=acc_dx, bwd_bn=bwd_bn)
         fused = with_bias and not _NO_FUSED_BIAS
 
         def wgrad():
@@ -375,6 +378,7 @@ class FastFlow3DUNet(nn.Module):
         else:
             with ops.SIDE.fork():
                 wgrad()
+        return fused
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict,
                      phase=None, sparse_input_grad: bool = False, dv_cells=None):
@@ -439,7 +443,12 @@ class FastFlow3DUNet(nn.Module):
                 retained["dskip"] = (dcat, lat)
             _, h, w, lat_ = pop("up")
             dt = hold(torch.empty(B, h, w, lat, **f32))
-            ops.upsample2x_bwd(img(dcat, lat, 0), img(dt), self.align_corners)
+            dci = img(dcat, lat, 0)
+            ops.upsample2x_bwd(dci, img(dt), self.align_corners)
+            if getattr(dci, "_amax", None) is not None:
+                # every input pixel of the bilinear x2 receives a total weight <= 2 per axis (4 in all; 4.5 covers align_corners
+                # = True): max |dt| <= 4.5 max |dcat| -- a bound without a pass over dt, for the 1x1 data / weight gradients behind
+                dt._df_amax = (ops.h2_bound(dci._amax, slack=4.5), ver(dt))
             _, m1, xa, ks = pop("conv")
             wt1 = None
             if a_like is not None and _is_h2(a_like):
@@ -500,6 +509,7 @@ class FastFlow3DUNet(nn.Module):
         # encoder, stages 3..1; dz of a stage's last layer lives in the concatenated gradient buffer
         stage_in_grads = {3: (dL, 128), 2: (dF, 64), 1: (dbstar, 32)}
         dz = img_pair(dR, 256)
+        pre_partial = None      # BatchNorm-backward partials of the layer about to be processed, left by the data gradient behind it
         for sidx, stage in ((3, self.encoder_step_3), (2, self.encoder_step_2), (1, self.encoder_step_1)):
             for i in reversed(range(len(stage))):
                 pop("keep")
@@ -512,12 +522,27 @@ class FastFlow3DUNet(nn.Module):
                 dy_h2 = x.elt == 2 and getattr(y, "_df_yamax", None) is not None
                 dy, dgamma, dbeta, dbias = ops.bn_gelu_bwd(dz, y, bn_ss, ipg, groups, frozen=frozen,
                                                            dy_dtype=torch.bfloat16 if s16 else torch.float32, dy_h2=dy_h2,
-                                                           y_amax=getattr(y, "_df_yamax", None) if dy_h2 else None)
+                                                           y_amax=getattr(y, "_df_yamax", None) if dy_h2 else None,
+                                                           partial_pre=pre_partial)
+                pre_partial = None
                 hold(dy)
                 grads[m.batchnorm.weight], grads[m.batchnorm.bias], grads[m.conv.bias] = dgamma, dbeta, dbias
+                bwd_bn = None
                 if i > 0:
                     dxt = torch.empty(2 * B, x.h, x.w, x.c, dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
                     dx, acc = img(dxt), False
+                    if not s16 and ops.h2_active() and tape[-2][0] == "cwn":
+                        # dz of the layer in front comes out of this layer's data gradient: let its epilogue also sum that layer's
+                        # BatchNorm-backward partials (g, g xhat per tile and channel) -- one pass over dz and y less per layer
+                        _, _, xq, yq, ssq, ipgq, groupsq, _ = tape[-2]
+                        rows_pg = ipgq * x.h * x.w
+                        tm = ops.conv_tile_m(rows_pg, x.c)
+                        if rows_pg % tm == 0 and yq.dtype == torch.float32:
+                            part = torch.empty(groupsq * (rows_pg // tm), x.c, 2, dtype=torch.float32, device=dev)
+                            dx.grp_size = ipgq
+                            dx.grp_off = ipgq * dxt.stride(0)
+                            bwd_bn = (yq, ssq, part)
+                            bwd_nbp = rows_pg // tm
                 elif sidx == 1 and sparse_input_grad:
                     dx, acc = None, False
                     retained["dy1"] = dy
@@ -527,7 +552,9 @@ class FastFlow3DUNet(nn.Module):
                 if sidx == 1 and i == 0 and sparse_input_grad:
                     pass  # neither data nor weight gradient here: the caller evaluates both at occupied pillars only
                 else:
-                    self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False)
+                    fused = self._conv_bwd(m.conv, x, img(dy), 3, m.stride, dx, acc, grads, with_bias=False, bwd_bn=bwd_bn)
+                    if fused:
+                        pre_partial = (bwd_bn[2], bwd_nbp)
                 dz = dx
             if phase is not None:
                 phase(stage.parameters())

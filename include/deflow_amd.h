@@ -311,6 +311,10 @@ int df_conv2d_h2p(df_img x, const void* w2, const float* x_amax, const float* w_
                   int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                   int accumulate, float* y_amax, void* stream);
 int df_conv2d_h2p_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
+/* the 3x3 stride-1 fp16x2 data gradient whose epilogue also leaves the BatchNorm + GELU backward's partial sums of the layer in front
+ * (replaces df_bn_gelu_bwd_reduce's pass over dz and y): see csrc/conv.hip */
+int df_conv2d_h2p_dgrad_bn(df_img x, const void* w2, const float* x_amax, const float* w_amax, df_img dz, const float* bn_y,
+                           const float* bn_ss, float* bwd_partial, float* dz_amax, void* stream);
 int df_conv2d_yh2(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y, const float* y_bound,
                   int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                   int accumulate, void* stream);

@@ -99,22 +99,22 @@ def main():
     ap.add_argument("--seed", type=int, default=4242)
     ap.add_argument("--init-seed", type=int, default=16)
     ap.add_argument("--threads", type=int, default=8)
-    a = ap.parse_args()
-    grid, n_pts, B = a.grid, a.n_pts, a.batch
-    torch.set_num_threads(a.threads)
+    args = ap.parse_args()
+    grid, n_pts, B = args.grid, args.n_pts, args.batch
+    torch.set_num_threads(args.threads)
     from deflow_amd.synth import synth_batch
     from oracle import ref_torch as O
-    half = 0.5 * a.voxel * grid
-    cfg = dict(voxel_size=[a.voxel, a.voxel, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid],
-               num_iters=a.iters)
-    torch.manual_seed(a.init_seed)
+    half = 0.5 * args.voxel * grid
+    cfg = dict(voxel_size=[args.voxel, args.voxel, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid],
+               num_iters=args.iters)
+    torch.manual_seed(args.init_seed)
     ref = O.DeFlow(**cfg).train()
     sd = copy.deepcopy(ref.state_dict())
     del ref
     # (the point spread follows the metric extent of the grid, as synth_batch's grid_hw does for the 0.2 m voxels)
-    batch = synth_batch(B, n_pts, seed=a.seed, grid_hw=(int(round(grid * a.voxel / 0.2)),) * 2)
-    d = {"grid": grid, "n_pts": n_pts, "nproj": NPROJ, "batch": B, "voxel": a.voxel, "iters": a.iters, "seed": a.seed,
-         "init_seed": a.init_seed, "threads": a.threads}
+    batch = synth_batch(B, n_pts, seed=args.seed, grid_hw=(int(round(grid * args.voxel / 0.2)),) * 2)
+    d = {"grid": grid, "n_pts": n_pts, "nproj": NPROJ, "batch": B, "voxel": args.voxel, "iters": args.iters, "seed": args.seed,
+         "init_seed": args.init_seed, "threads": args.threads}
     outs = {}
     spill_root = os.environ.get("DF_DIGEST_SPILL", "/tmp/df_digest_spill")
     for tag in ("32", "64"):                       # one precision at a time, its tape released before the next
@@ -149,7 +149,7 @@ def main():
         d[f"grad.{k}.e32_rms"] = float((a - g).norm() / g.norm().clamp_min(1e-300))
         den = float(a.norm() * g.norm())
         d[f"grad.{k}.e32_cos"] = 0.0 if den == 0 else max(0.0, 1.0 - float(torch.dot(a.reshape(-1), g.reshape(-1))) / den)
-    name = f"bs16_{grid}_digest.npz" if (B, a.iters) == (16, 4) else f"bs{B}_{grid}_it{a.iters}_digest.npz"
+    name = f"bs16_{grid}_digest.npz" if (B, args.iters) == (16, 4) else f"bs{B}_{grid}_it{args.iters}_digest.npz"
     out = os.path.join(ROOT, "tests", "golden", name)
     np.savez_compressed(out, **d)
     print("wrote", out, os.path.getsize(out), "bytes")

@@ -276,6 +276,13 @@ def test_bs16_full_size_train_step_vs_oracle(dev, monkeypatch, golden_dir):
     _bs16_case(dev, monkeypatch, 512, 80000, "bs16_512", golden_dir)
 
 
+def test_bs16_full_size_train_step_gru_fp32_vs_oracle(dev, monkeypatch, golden_dir):
+    """the same configs[2] step with the GRU decoder's GEMMs back on the fp32 MFMA (DF_GRU_X2=0): the second row of the bench
+    line's `model_error_budget` (what the 16-significant-bit bf16x2 decoder spends of the 1e-4 bound)"""
+    monkeypatch.setenv("DF_GRU_X2", "0")
+    _bs16_case(dev, monkeypatch, 512, 80000, "bs16_512_gru_fp32", golden_dir)
+
+
 def test_fastflow3d_train_step_vs_oracle(dev):
     """decoder_option=linear (the fastflow3d head): training step gradients vs the oracle (fp32 and fp64)"""
     from oracle import ref_torch as O
@@ -1357,7 +1364,7 @@ def test_bench_line_contract(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, cwd=root, timeout=600)
+                       capture_output=True, text=True, cwd=root, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -1367,7 +1374,18 @@ def test_bench_line_contract(dev):
     assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert rf["kernel"].startswith("conv_") and rf["avg_launch_ms"] > 0
+    assert (rf["kernel"].startswith("conv_") or rf["kernel"].startswith("wgrad")) and rf["avg_launch_ms"] > 0
+    # round 4: the dominant kernel is chosen among ALL MFMA kernels, the fp16x2 family is priced as a whole, the
+    # sustained 16-bit MFMA rate of this chip is measured in the same run, and the precision ladder stands beside the headline
+    assert rf["kernel"] == max(rf["all_mfma_kernels"], key=lambda k: rf["all_mfma_kernels"][k]["ms_per_step"])
+    assert 0.2 < rf["fp16x2_family"]["frac"] < 1.0 and 0.3 < rf["fp16x2_family"]["share_of_step"] < 0.8
+    su = rf["sustained"]
+    assert 2000 < su["mfma_16bit_tflops_zero_operands"] < 2600 and 1000 < su["mfma_16bit_tflops_random_operands"] < su["mfma_16bit_tflops_zero_operands"]
+    assert 1.2 < su["sustained_clock_ghz"] < 2.45 and rf["frac"] < su["frac_at_sustained_clock"] < 1.0
+    for leg in ("strict_fp32", "gru_fp32"):
+        assert "error" not in d[leg], d[leg]
+        assert d[leg]["ms_per_step"] > d["ms_per_step"] * 0.98 and abs(d[leg]["loss"] - d["config"]["loss"]) <= 1e-4 * abs(d["config"]["loss"])
+    assert d["strict_fp32"]["ms_per_step"] > d["gru_fp32"]["ms_per_step"]
     for k in ("pillarise_fwd", "bn_gelu_apply", "bn_gelu_bwd", "gru_fwd", "gru_bwd", "gru_wgrad", "pillarise_fwd_inference_b16"):
         assert k in d["roofline_hbm"] and 0 < d["roofline_hbm"][k]["frac"] < 1.2, k
     assert d["forward_only"]["ms_per_pair"] > 0 and d["bf16_inference"]["ms_per_pair"] > 0
@@ -1399,7 +1417,7 @@ def test_bench_two_ranks_share_the_gpu(dev):
     assert "allreduce_exposed_ms" in d and math.isfinite(d["allreduce_exposed_ms"])
     assert math.isfinite(d["config"]["loss"]) and math.isfinite(d["bf16_training"]["loss"])
     assert d["bf16_training"]["pairs_per_s"] > 0      # (two ranks SHARING one GPU, the bf16 leg with the kernel profiler on: not a measurement)
-    assert d["roofline"]["kernel"].startswith("conv_") and "cpu_baseline" not in d and "forward_only" not in d
+    assert (d["roofline"]["kernel"].startswith("conv_") or d["roofline"]["kernel"].startswith("wgrad")) and "cpu_baseline" not in d and "forward_only" not in d
     # the captured data-parallel program: graph segments split at the buckets, host cost of a replay
     hg = d["hip_graph"]
     assert "error" not in hg, hg

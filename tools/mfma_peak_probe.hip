@@ -32,7 +32,9 @@ __global__ __launch_bounds__(512) void mfma_stream(const f16x8* __restrict__ ops
   out[t] = s;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // mfma_peak_probe [iters = 100000] [reps = 3]: bench.py runs a short form (30000, 2) for the `roofline.sustained` entries
+  const int iters_arg = argc > 1 ? atoi(argv[1]) : 100000, reps = argc > 2 ? atoi(argv[2]) : 3;
   const int n_ops = 65536;
   std::vector<_Float16> h(n_ops * 8);
   f16x8* d_ops;
@@ -48,8 +50,8 @@ int main() {
     hipMemcpy(d_ops, h.data(), n_ops * sizeof(f16x8), hipMemcpyHostToDevice);
     for (int wps = 1; wps <= 2; ++wps) {
       const int threads = 256 * wps, blocks = 256 * 4;      // 4 blocks per CU resident? no: 1024 blocks queue; each CU runs them in turn
-      const int iters = 100000;
-      for (int rep = 0; rep < 3; ++rep) {
+      const int iters = iters_arg;
+      for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL(mfma_stream, dim3(blocks), dim3(threads), 0, 0, d_ops, d_out, iters);
         hipEventRecord(e1);
