@@ -360,10 +360,10 @@ class FastFlow3DUNet(nn.Module):
         """-> True if the data gradient's epilogue also produced the BatchNorm-backward partials asked for with bwd_bn"""
         w = ops.ohwi(m.weight)
         dev = w.device
-        fused = False
+        fused_bn = False
         if dx is not None:
-            fused = ops.conv2d(dy, ops.weight_transpose(w) if wt is None else wt, None, dx, ks, stride, mode=ops.CONV_DGRAD,
-                               accumulate=acc_dx, bwd_bn=bwd_bn)
+            fused_bn = ops.conv2d(dy, ops.weight_transpose(w) if wt is None else wt, None, dx, ks, stride, mode=ops.CONV_DGRAD,
+                                  accumulate=acc_dx, bwd_bn=bwd_bn)
         fused = with_bias and not _NO_FUSED_BIAS
 
         def wgrad():
@@ -378,7 +378,7 @@ class FastFlow3DUNet(nn.Module):
         else:
             with ops.SIDE.fork():
                 wgrad()
-        return fused
+        return fused_bn
 
     def run_backward(self, bstar: torch.Tensor, tape: list, dv: torch.Tensor, dbstar: Optional[torch.Tensor], grads: dict,
                      phase=None, sparse_input_grad: bool = False, dv_cells=None):
