@@ -155,6 +155,30 @@ def cpu_baseline(samples: int):
                                        f"(min {fw[1]:.2f}, max {fw[2]:.2f})"}}
 
 
+def bind_to_gpu_numa_node(local_rank: int):
+    """First contact with a multi-GPU node: pin this rank's host threads to the NUMA node its GPU hangs off
+    (eight ranks share the node's cores; the loader / Python of one rank should not run on the far socket).  Best effort: -> the
+    node id, or None when sysfs does not say."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def dry_run(args, rank, world):
     """N > 1 start-up without a GPU: process group (gloo), barrier, MAX-reduced timing, all-gathered rank ids, one JSON line."""
     import torch
@@ -202,6 +226,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa = bind_to_gpu_numa_node(local_rank) if (world > 1 and not share_gpu) else None
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
     if use_dist and share_gpu:
@@ -237,6 +262,17 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step(batch)
+    selfcheck = None
+    if use_dist:
+        # RCCL self-check before the timed region: after the arena broadcast and the warm-up steps (each rank on its OWN shard, the
+        # gradients all-reduced) the parameter arena must be BIT-IDENTICAL on every rank -- a wrong scaling curve is then diagnosable
+        # from the one line.  Two 64-bit digests of the arena's bit pattern per rank, all-gathered.
+        bits = trainer.flat.param.view(torch.int32).to(torch.int64)
+        dgst = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev, dtype=torch.int64) % 1000003).sum()])
+        alld = [torch.zeros_like(dgst) for _ in range(world)]
+        dist.all_gather(alld, dgst)
+        selfcheck = {"params_bit_identical_across_ranks_after_warmup": bool(all(torch.equal(a, alld[0]) for a in alld)),
+                     "steps_checked": args.warmup, "numa_node": numa}
     prof = None if args.no_profile else ops.KernelProfiler()
     ops.PROFILER = prof
     dt, dt_local, loss = timed_steps(args.steps)       # THE timed region: exactly --steps steps between barriers
@@ -329,6 +365,8 @@ def main():
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
                    "parallelism": f"dp{world}", "loss": float(loss)},
     }
+    if selfcheck is not None:
+        out["rccl_selfcheck"] = selfcheck
     if per_rank is not None:
         out["rccl_ranks"] = [int(x[1].item()) for x in per_rank]
         out["per_rank_ms_per_step"] = {"min": min(float(x[0]) for x in per_rank), "max": max(float(x[0]) for x in per_rank)}

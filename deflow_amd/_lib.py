@@ -85,6 +85,7 @@ _SIGS = {
     "df_h2_unpack": [DfImg, P, DfImg, P],
     "df_rows_l1max": [P, I, I, P, I, P, P, P],
     "df_h2_bound": [P, P, P, P, P, F, P],
+    "df_weight_prep": [P, P, I, I, P, P, P, P],
     "df_conv2d_variant": [L, L, I, I],
     "df_conv2d_last_dma": [],
     "df_conv2d_bf16": [DfImg, P, P, DfImg, I, I, I, I, P, P, I, P],

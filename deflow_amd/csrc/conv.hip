@@ -115,7 +115,10 @@ struct RowDecode {
   }
 };
 
-template <int BM, int BN, int WM, int WN>
+// BWS (compile time; only the pre-split-input 3x3 data-gradient instances carry it): the DF_EPI_BWD_STATS epilogue -- every other
+// instance keeps the round-3 epilogue byte for byte (a run-time branch here cost the dominant kernels ~5 %: more scalar registers
+// live across the main loop)
+template <int BM, int BN, int WM, int WN, bool BWS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* lds,
                                               const RowDecode& dec, int m0, int m_end, int n0, int tile_m) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -152,11 +155,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // [32 fp16 hi | 32 fp16 lo] of y s, s = df_h2_scale(*p.bound_y) (a bound of max |y| the caller knows before the launch).  A lane
     // owns one channel of the chunk (li): lanes exchange halves with their neighbour (one DPP move) so that every lane still stores
     // ONE dword per element -- even lanes the hi pair (channels li, li + 1), odd lanes the lo pair (li - 1, li).
-    const bool bws = p.epi == DF_EPI_BWD_STATS;
+    constexpr bool bws = BWS;
     const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bws ? p.bwd_y : reinterpret_cast<const float*>(p.y.ptr)), 0,
                                                                          p.y_bytes, 0x00020000);
     int bgrp = 0;
-    if (bws) {
+    if constexpr (bws) {
       int n_, oy_, ox_;
       dec(m0, n_, oy_, ox_);
       bgrp = n_ / p.y.grp_size;           // statistic group of this tile (a tile never straddles two)
@@ -178,7 +181,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         }
         float s1 = 0.f, s2 = 0.f;
         float b_sc = 1.f, b_sh = 0.f, b_mu = 0.f, b_is = 1.f;
-        if (bws) {
+        if constexpr (bws) {
           const float* ss = p.bwd_ss + (int64_t)bgrp * 4 * p.N;
           b_sc = ss[co]; b_sh = ss[p.N + co]; b_mu = ss[2 * p.N + co]; b_is = ss[3 * p.N + co];
         }
@@ -192,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             else ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
           }
           float old[16];
-          if (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
+          if constexpr (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
 #pragma unroll
             for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], 0, 0));
           }
@@ -227,7 +230,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
             }
             if (ob[e] != ROW_BAD) {
-              if (bws) {
+              if constexpr (bws) {
                 const float g = v * df_gelu_grad(fmaf(old[e], b_sc, b_sh));
                 s1 += g;
                 s2 += g * ((old[e] - b_mu) * b_is);
@@ -239,7 +242,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             }
           }
         }
-        if (epi_stats(p.epi)) {
+        if (BWS || p.epi == DF_EPI_STATS) {
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
           if (kh == 0) {
@@ -292,7 +295,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       }
     }
   }
-  if (epi_stats(p.epi)) {
+  if (BWS || p.epi == DF_EPI_STATS) {
     __syncthreads();
     if (tid < BN) {
       float s1 = 0.f, s2 = 0.f;
@@ -1117,7 +1120,7 @@ static int launch_conv_halo_w16(const ConvParams& p, hipStream_t s) {
 // split in VALU (3.8 VALU per MFMA in the fp32-input form), no LDS stores.  One op = 16 halo rows x 64 B of one plane; every
 // wave issues the same NAO ops per group (spare slots repeat the first ops: same bytes to the same place) so that the counted
 // waits stay compile-time constants.
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false, bool BWS = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SW = BM / SEG + 2;                     // halo pixels per segment
@@ -1465,16 +1468,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
   }
-  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, p.M, n0, tile_m);
+  conv_epilogue<BM, BN, WM, WN, BWS>(p, acc, lds, dec, m0, p.M, n0, tile_m);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, int NP = 3, bool X16 = false, bool XP = false, bool BWS = false>
 static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
   constexpr int HR = XP ? (SEG * (BM / SEG + 2) + 15) / 16 * 16 : (SEG * (BM / SEG + 2) + 3) / 4 * 4;
   const size_t lds_bytes = (size_t)(2 * NP * HR + DB * NP * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP>), (int)lds_bytes);
-  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+  DF_SET_LDS_ONCE((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP, BWS>), (int)lds_bytes);
+  hipLaunchKernelGGL((conv_halo_x3_kernel<BM, BN, WM, WN, SEG, DB, NP, X16, XP, BWS>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -3318,7 +3321,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   if (epi == DF_EPI_BN_GELU) DF_REQUIRE(scale && shift, DF_E_ARG);
   if (epi_stats(epi)) DF_REQUIRE(stats_partial, DF_E_ARG);
   if (epi == DF_EPI_BWD_STATS)      // fused BatchNorm-backward partials: the fp16x2 data gradient with a plain fp32 output only
-    DF_REQUIRE(mode == DF_CONV_DGRAD && w3 && h2_amax_x && (query || (bwd_y && bwd_ss)) && y.elt == 0 && !accumulate && y.ld == y.c && !bias, DF_E_ARG);
+    DF_REQUIRE(mode == DF_CONV_DGRAD && w3 && h2_amax_x && x.elt == 2 && (query || (bwd_y && bwd_ss)) && y.elt == 0 && !accumulate && y.ld == y.c &&
+                   !bias, DF_E_ARG);
   ConvParams p;
   p.x = x; p.y = y; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_partial;
   p.ks = ksize; p.stride = stride; p.pad = pad; p.mode = mode; p.epi = epi; p.accumulate = accumulate;
@@ -3420,6 +3424,11 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
           M / 256 * p.tiles_n >= 512) {
         p.tiles_m = (int)(M / 256);
         p.stats_mul = 2;
+        if (xp && epi == DF_EPI_BWD_STATS) {
+          if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2, false, true, true>(p, s);
+          if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 4, 2, false, true, true>(p, s);
+          return launch_conv_halo_x3<256, 128, 4, 2, 4, 4, 2, false, true, true>(p, s);
+        }
         if (xp) {
           if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2, false, true>(p, s);
           if (seg == 2) return launch_conv_halo_x3<256, 128, 4, 2, 2, 4, 2, false, true>(p, s);
@@ -3435,6 +3444,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
           M / 512 >= 512) {
         p.tiles_m = (int)(M / 512);
         p.stats_mul = 4;
+        if (xp && epi == DF_EPI_BWD_STATS)
+          return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2, false, true, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2, false, true, true>(p, s);
         if (xp) return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2, false, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2, false, true>(p, s);
         return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2>(p, s);
       }

@@ -115,6 +115,82 @@ __global__ __launch_bounds__(256) void rows_l1max_kernel(const float* __restrict
   }
 }
 
+// ---- per-step weight preparation of ALL convolution layers in ONE launch (round 4; df_weight_prep) ---------------------------
+// What the fp32 step did per convolution call: weight_transpose (31 launches per step), split_h2 of the weights and of their
+// transpose (39), row L1 norms for the a-priori output bounds (~10).  The parameters change once per optimizer step, so all of
+// it is a function of the parameter arena: one kernel walks a layer table and leaves, per layer,
+//   wt   [Cin][taps][Cout] fp32       the transposed weights (operand of the data gradients)
+//   w2   2 x [Cout][taps][Cin] fp16   [hi | lo] planes of w  s_w   (fp16x2 forward; 3x3 stride-1 layers)
+//   wt2  2 x [Cin][taps][Cout] fp16   ... of the transpose         (fp16x2 data gradient)
+//   l1w, l1wt                         max_row sum |w[row, :]|, max_row sum |wt[row, :]|  (a-priori bounds of pre-split outputs)
+//   bmax                              max |bias|
+// One workgroup per weight ROW (of w: blocks [0, Cout); of wt: blocks [Cout, Cout + Cin)), row sums by a fixed tree and integer
+// atomic max: deterministic.  s_w = df_h2_scale(*w_amax) with w_amax = max |p| over the whole arena (one df_absmax before).
+struct df_wprep_layer {
+  int64_t w_off, b_off;          // element offsets of weight / bias in the parameter arena (b_off < 0: no bias)
+  int64_t wt_off, w2_off, wt2_off;   // element offsets in the output buffer (wt: floats; w2 / wt2: in floats too, 2 x numel halfs = numel floats)
+  int32_t cout, taps, cin, split;    // split: also write the fp16 planes
+  int32_t blk0;                      // first workgroup of this layer
+  int32_t pad;
+};
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ params, const df_wprep_layer* __restrict__ tab, int nlayers,
+                                                          const float* __restrict__ w_amax, float* __restrict__ out,
+                                                          unsigned* __restrict__ norms /* [nlayers][3]: l1w, l1wt, bmax */) {
+  __shared__ float red[4];
+  int L = 0;
+  for (int i = 1; i < nlayers; ++i)
+    if ((int)blockIdx.x >= tab[i].blk0) L = i;      // (a few dozen layers: a linear scan of scalar loads)
+  const df_wprep_layer t = tab[L];
+  const int r = (int)blockIdx.x - t.blk0;
+  const float s = df_h2_scale(*w_amax);
+  const float* w = params + t.w_off;
+  const int64_t numel = (int64_t)t.cout * t.taps * t.cin;
+  float a = 0.f;
+  if (r < t.cout) {                 // a row of w: [taps][cin] contiguous
+    const int len = t.taps * t.cin;
+    const float* row = w + (int64_t)r * len;
+    _Float16* hi = reinterpret_cast<_Float16*>(out + t.w2_off) + (int64_t)r * len;
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const float v = row[i];
+      a += fabsf(v);
+      if (t.split) {
+        const float x = v * s;
+        const _Float16 h = (_Float16)x;
+        hi[i] = h;
+        hi[numel + i] = (_Float16)((x - (float)h) * 2048.f);
+      }
+    }
+  } else {                          // a row of the transpose: wt[ci][tap][co] = w[co][tap][ci]
+    const int ci = r - t.cout, len = t.taps * t.cout;
+    float* wt = out + t.wt_off + (int64_t)ci * len;
+    _Float16* hi = reinterpret_cast<_Float16*>(out + t.wt2_off) + (int64_t)ci * len;
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const int tap = i / t.cout, co = i - tap * t.cout;
+      const float v = w[((int64_t)co * t.taps + tap) * t.cin + ci];
+      a += fabsf(v);
+      wt[i] = v;
+      if (t.split) {
+        const float x = v * s;
+        const _Float16 h = (_Float16)x;
+        hi[i] = h;
+        hi[numel + i] = (_Float16)((x - (float)h) * 2048.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    df_atomic_amax(norms + 3 * L + (r < t.cout ? 0 : 1), (red[0] + red[1]) + (red[2] + red[3]));
+    if (r == 0 && t.b_off >= 0) {
+      float b = 0.f;
+      for (int i = 0; i < t.cout; ++i) b = fmaxf(b, fabsf(params[t.b_off + i]));
+      df_atomic_amax(norms + 3 * L + 2, b);
+    }
+  }
+}
+
 // out = max(other, a * l1 * slack + b)   (nulls: other = 0, l1 = 1, b = 0): the bound of a pre-split conv output / concatenation
 __global__ void h2_bound_kernel(float* __restrict__ out, const float* a, const float* l1, const float* b, const float* other, float slack) {
   float v = *a * (l1 ? *l1 : 1.f) * slack + (b ? *b : 0.f);
@@ -794,6 +870,18 @@ extern "C" int df_rows_l1max(const float* w, int rows, int row_len, const float*
   DF_REQUIRE(w && rows > 0 && row_len > 0 && l1max && (!bias || nbias > 0), DF_E_ARG);
   hipLaunchKernelGGL(rows_l1max_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, row_len, bias, nbias,
                      reinterpret_cast<unsigned*>(l1max), reinterpret_cast<unsigned*>(bmax));
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// every convolution layer's per-step weight forms in one launch (kernel comment above): params = the parameter arena (or any
+// base the table's offsets refer to), table = nlayers device records (df_wprep_layer, include/deflow_amd.h), total_blocks = sum over
+// layers of (cout + cin), out = the output buffer the table's offsets address, norms = [nlayers][3] floats, zero-initialised
+extern "C" int df_weight_prep(const float* params, const void* table, int nlayers, int total_blocks, const float* w_amax, float* out,
+                              float* norms, void* stream) {
+  DF_REQUIRE(params && table && nlayers > 0 && total_blocks > 0 && w_amax && out && norms, DF_E_ARG);
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+                     reinterpret_cast<const df_wprep_layer*>(table), nlayers, w_amax, out, reinterpret_cast<unsigned*>(norms));
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

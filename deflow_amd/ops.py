@@ -257,8 +257,101 @@ def h2_pack(x: torch.Tensor, bound: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class WeightPrep:
+    """Every convolution layer's per-step weight forms from ONE launch (df_weight_prep; round 4): transposed weights, [hi | lo] fp16
+    planes of the weights and of their transpose (3x3 stride-1 layers), row L1 norms and max |bias| (a-priori bounds of pre-split
+    outputs).  optim.Trainer builds one at the top of every step (the parameters change once per step) and installs it as
+    ops.WPREP; ops.weight_transpose / _split_h2 / rows_l1max answer from it when the tensor they are asked about is one of its
+    layers, and fall back to their own launches otherwise (plain autograd users, the decoder head's GEMM weights)."""
+
+    def __init__(self, convs, w_amax: torch.Tensor):
+        import numpy as np
+        self.convs = [m for m in convs if m.weight.dim() == 4]
+        dev = self.convs[0].weight.device
+        ws = [ohwi(m.weight) for m in self.convs]
+        assert all(w.data_ptr() == m.weight.data_ptr() for w, m in zip(ws, self.convs)), "conv weights must be channels_last (OHWI memory)"
+        ptrs = [w.data_ptr() for w in ws] + [m.bias.data_ptr() for m in self.convs if m.bias is not None]
+        self.base = min(ptrs)
+        rec = np.zeros(len(ws), dtype=[("w_off", "<i8"), ("b_off", "<i8"), ("wt_off", "<i8"), ("w2_off", "<i8"), ("wt2_off", "<i8"),
+                                       ("cout", "<i4"), ("taps", "<i4"), ("cin", "<i4"), ("split", "<i4"), ("blk0", "<i4"), ("pad", "<i4")])
+        off, blk = 0, 0
+        self.layer = {}
+        for i, (w, m) in enumerate(zip(ws, self.convs)):
+            co, kh, kw, ci = w.shape
+            n = w.numel()
+            split = int(kh == 3 and m.stride[0] == 1)
+            rec[i] = ((w.data_ptr() - self.base) // 4, (m.bias.data_ptr() - self.base) // 4 if m.bias is not None else -1,
+                      off, off + n, off + 2 * n, co, kh * kw, ci, split, blk, 0)
+            self.layer[w.data_ptr()] = (i, off, n, (co, kh, kw, ci), split)
+            off += 3 * n if split else n
+            blk += co + ci
+        self.total_blocks, self.nl = blk, len(ws)
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self.out = torch.empty(off, dtype=torch.float32, device=dev)
+        self.norms = torch.zeros(self.nl, 3, dtype=torch.float32, device=dev)
+        self.w_amax = w_amax
+        self.by_wt = {}                 # data_ptr of a transposed view -> (layer, plane offset) for _split_h2 of the transpose
+        self.bias_of = {m.bias.data_ptr(): self.layer[w.data_ptr()][0] for w, m in zip(ws, self.convs) if m.bias is not None}
+        self._anchor = torch.empty(0, dtype=torch.float32, device=dev)
+
+    def run(self, w_amax: torch.Tensor):
+        """(re)compute every form for the current parameter values"""
+        import ctypes
+        self.w_amax = w_amax
+        self.norms.zero_()
+        call("df_weight_prep", ctypes.c_void_p(self.base), ptr(self.table), self.nl, self.total_blocks, ptr(w_amax), ptr(self.out), ptr(self.norms),
+             stream())
+
+    def wt(self, w_ohwi: torch.Tensor) -> Optional[torch.Tensor]:
+        e = self.layer.get(w_ohwi.data_ptr())
+        if e is None:
+            return None
+        i, off, n, (co, kh, kw, ci), split = e
+        t = self.out[off:off + n].view(ci, kh, kw, co)
+        self.by_wt[t.data_ptr()] = (i, off + 2 * n, n, split)
+        return t
+
+    def h2(self, w: torch.Tensor):
+        """[hi | lo] planes (a float16 view of 2 x numel) of a layer's weights, or of its transpose as self.wt() returned it"""
+        e = self.layer.get(w.data_ptr())
+        if e is not None and e[4]:
+            _, off, n, _, _ = e
+            return self.out[off + n:off + 2 * n].view(torch.float16), self.w_amax
+        e = self.by_wt.get(w.data_ptr())
+        if e is not None and e[3]:
+            _, o2, n, _ = e
+            return self.out[o2:o2 + n].view(torch.float16), self.w_amax
+        return None
+
+    def l1(self, w: torch.Tensor, bias: Optional[torch.Tensor]):
+        """(max row L1 norm, max |bias| or None) device scalars for a layer's weights or their transpose; None if not one of ours"""
+        e = self.layer.get(w.data_ptr())
+        col = 0
+        if e is None:
+            e2 = self.by_wt.get(w.data_ptr())
+            if e2 is None:
+                return None
+            i, col = e2[0], 1
+        else:
+            i = e[0]
+        bm = None
+        if bias is not None:
+            j = self.bias_of.get(bias.data_ptr())
+            if j is None:
+                return None
+            bm = self.norms[j, 2:3]
+        return self.norms[i, col:col + 1], bm
+
+
+WPREP: Optional[WeightPrep] = None
+
+
 def rows_l1max(w2d_rows: int, row_len: int, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """-> (max_row sum |w[row, :]|, max |bias| or None) as device scalars: the weight side of a conv output's a-priori bound"""
+    if WPREP is not None:
+        hit = WPREP.l1(w, bias)
+        if hit is not None:
+            return hit
     l1 = amax_slot(w.device)
     bm = amax_slot(w.device) if bias is not None else None
     call("df_rows_l1max", ptr(w), w2d_rows, row_len, ptr(bias), 0 if bias is None else bias.numel(), ptr(l1), ptr(bm), stream())
@@ -287,7 +380,12 @@ def h2_active() -> bool:
 
 
 def _split_h2(w_ohwi: torch.Tensor):
-    """weights -> (two fp16 planes, their amax): per call (they change every optimizer step; each conv uses them once per direction)"""
+    """weights -> (two fp16 planes, their amax): per call (they change every optimizer step; each conv uses them once per direction)
+    -- or from the step's WeightPrep when the tensor is one of its layers (or a transpose it handed out)"""
+    if WPREP is not None:
+        hit = WPREP.h2(w_ohwi)
+        if hit is not None:
+            return hit
     wa = W_AMAX
     if wa is None:
         wa = amax_slot(w_ohwi.device)
@@ -595,6 +693,10 @@ def colsum(x: DfImg, device) -> torch.Tensor:
 
 def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
     """[Cout,kh,kw,Cin] -> [Cin,kh,kw,Cout]"""
+    if WPREP is not None:
+        hit = WPREP.wt(w_ohwi)
+        if hit is not None:
+            return hit
     co, kh, kw, ci = w_ohwi.shape
     wt = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=w_ohwi.device)
     call("df_weight_transpose", ptr(w_ohwi), ptr(wt), co, kh * kw, ci, stream())

@@ -433,14 +433,27 @@ class Trainer:
         # tensor -- max |p| over the whole parameter arena (any upper bound serves; the convolutions then need no per-call pass)
         ops.amax_pool_reset()
         ops.W_AMAX = None
+        ops.WPREP = None
         if ops.h2_active() and self.flat.param.is_cuda:
             wa = ops.amax_slot(self.flat.param.device)
             call("df_absmax", img(self.flat.param.view(1, 1, -1, 4)), ptr(wa), stream())       # (numel is a multiple of 4)
             ops.W_AMAX = wa
+            # every conv layer's transposed weights / fp16 planes / row norms of THIS step's parameters in one launch (round 4:
+            # ~80 small launches per step before); DF_WPREP=0: the per-call launches
+            backbone = getattr(model, "backbone", None)
+            if backbone is not None and os.environ.get("DF_WPREP", "1") != "0":
+                wp = getattr(self, "_wprep", None)
+                if wp is None:
+                    convs = [m for m in backbone.modules() if isinstance(m, torch.nn.Conv2d)]
+                    wp = self._wprep = ops.WeightPrep(convs, wa) if convs else False
+                if wp:
+                    wp.run(wa)
+                    ops.WPREP = wp
         try:
             return self._forward_backward_impl(batch)
         finally:
             ops.W_AMAX = None
+            ops.WPREP = None
 
     def _forward_backward_impl(self, batch) -> torch.Tensor:
         model = self.model

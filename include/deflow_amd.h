@@ -333,6 +333,13 @@ int df_h2_pack(df_img x, const float* bound, df_img y, void* stream);
 int df_h2_unpack(df_img x, const float* bound, df_img y, void* stream);
 int df_rows_l1max(const float* w, int rows, int row_len, const float* bias, int nbias, float* l1max, float* bmax, void* stream);
 int df_h2_bound(float* out, const float* a, const float* l1, const float* b, const float* other, float slack, void* stream);
+/* all convolution layers' per-step weight forms in ONE launch: transposed weights, [hi | lo] fp16 planes of both, row L1 norms and
+ * max |bias| for the a-priori bounds (replaces ~80 df_weight_transpose / df_split_h2 / df_rows_l1max launches per training step).
+ * table: nlayers records {int64 w_off, b_off (elements in `params`; b_off < 0: none), wt_off, w2_off, wt2_off (floats in `out`);
+ * int32 cout, taps, cin, split, blk0 (first workgroup of the layer = sum of cout + cin of the layers before), pad};
+ * norms [nlayers][3] = (max row L1 of w, of w^T, max |bias|), zero-initialised by the caller; w_amax = max |p| over the arena */
+int df_weight_prep(const float* params, const void* table, int nlayers, int total_blocks, const float* w_amax, float* out, float* norms,
+                   void* stream);
 
 /* ------------------------------------------------------- point decoder (A6-A10) --------
  * Replaces ConvGRUDecoder / LinearDecoder forward_single ([REF decoder.py:72-199]): integer

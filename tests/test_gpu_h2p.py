@@ -355,3 +355,63 @@ def test_fused_bn_backward_partials_match_the_reduce_pass(dev, monkeypatch):
         worst = max(worst, (e, k))
         assert e <= 2e-6, (k, e)
     print(f"[parity] fused BatchNorm-backward partials vs the reduce pass: worst gradient rms-relative difference {worst[0]:.2e} ({worst[1]})")
+
+
+def test_weight_prep_one_launch_equals_per_call_forms(dev, monkeypatch):
+    """df_weight_prep: every conv layer's transposed weights, [hi | lo] planes (of w and of its transpose), row L1 norms and max |bias|
+    from ONE launch must be bit-identical to the per-call kernels they replace (df_weight_transpose, df_split_h2, df_rows_l1max);
+    and a B = 16 training step with the prep on (default) must give bit-identical gradients to the step without it (DF_WPREP=0)."""
+    import deflow_amd
+    from deflow_amd import ops
+    from deflow_amd._lib import call, img
+    from deflow_amd.unet import FastFlow3DUNet
+    torch.manual_seed(3)
+    net = FastFlow3DUNet().to(dev)
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    with torch.no_grad():
+        for m in convs:
+            m.bias.uniform_(-0.3, 0.3)
+    wa = ops.amax_slot(dev)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    wa.copy_(flat.abs().max().reshape(1))
+    wp = ops.WeightPrep(convs, wa)
+    wp.run(wa)
+    torch.cuda.synchronize()
+    n_split = 0
+    for m in convs:
+        w = ops.ohwi(m.weight)
+        wt_ref = ops.weight_transpose(w)                 # (ops.WPREP is None here: the per-call kernel)
+        wt = wp.wt(w)
+        assert torch.equal(wt, wt_ref)
+        l1, bm = wp.l1(w, m.bias.detach())
+        l1r, bmr = ops.rows_l1max(w.shape[0], w.numel() // w.shape[0], w, m.bias.detach())
+        l1t, _ = wp.l1(wt, None)
+        l1tr, _ = ops.rows_l1max(wt_ref.shape[0], wt_ref.numel() // wt_ref.shape[0], wt_ref, None)
+        assert torch.equal(l1, l1r) and torch.equal(bm, bmr) and torch.equal(l1t, l1tr), m
+        h = wp.h2(w)
+        if m.kernel_size[0] == 3 and m.stride[0] == 1:
+            n_split += 1
+            for src, got in ((w, h[0]), (wt_ref, wp.h2(wt)[0])):
+                ref2 = torch.empty(2 * src.numel(), dtype=torch.float16, device=dev)
+                call("df_split_h2", ops.ptr(src.contiguous()), ops.ptr(wa), ops.ptr(ref2), src.numel(), ops.stream())
+                assert torch.equal(got, ref2)
+        else:
+            assert h is None
+    assert n_split == 20
+    # whole step: same bits with and without
+    from deflow_amd.optim import Trainer
+    from deflow_amd.synth import synth_batch
+    cfg = dict(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-25.6, -25.6, -3, 25.6, 25.6, 3], grid_feature_size=[256, 256])
+    batch = synth_batch(16, 20000, seed=4242, grid_hw=(256, 256), device=dev)
+    arenas = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DF_WPREP", flag)
+        torch.manual_seed(16)
+        m = deflow_amd.DeFlow(**cfg).to(dev).train()
+        tr = Trainer(m, lr=0.0)
+        tr.flat.zero_grad(); tr.sink.begin()
+        tr._forward_backward(batch)
+        torch.cuda.synchronize()
+        assert (getattr(tr, "_wprep", None) is not None) == (flag == "1")
+        arenas[flag] = tr.flat.grad.clone()
+    assert torch.equal(arenas["1"], arenas["0"])
