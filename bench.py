@@ -620,6 +620,15 @@ def main():
         torch.cuda.empty_cache()
         # the precision ladder beside the headline: the same step with EVERY GEMM on the fp32 MFMA, and with only the
         # GRU decoder back on it -- fresh processes, because the library reads its switches once
+        # N2 (the step before the path): the same training step fed by the scene-file loader (h5 scenes of AV2-sized sweeps written at run
+        # time, 4 reader processes) against one resident batch -- is the loader able to feed this step?  (tools/bench_loader.py)
+        for dt_ in ("fp32", "bf16"):
+            try:
+                env = dict(os.environ, DF_LOADER_QUICK="1", DF_LOADER_DTYPE=dt_)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_loader.py")], capture_output=True, text=True, env=env, timeout=600)
+                out.setdefault("loader_fed", {})[dt_] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:   # noqa: BLE001
+                out.setdefault("loader_fed", {})[dt_] = {"error": f"{type(e).__name__}: {e}"[:200]}
         out["strict_fp32"] = strict_leg({"DF_CONV_X3": "0", "DF_WGRAD_X3": "0", "DF_CONV_H2F": "0", "DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
         out["gru_fp32"] = strict_leg({"DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
     if use_dist:

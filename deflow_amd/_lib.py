@@ -119,6 +119,7 @@ _SIGS = {
     "df_gru_decoder_fwd_bf16": [DfImg, DfImg, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
     "df_gru_wgrad_splits": [],
+    "df_gru_head_wgrad": [P, P, P, P, I, I, P, I, P],
     "df_gru_wgrad": [P, P, P, I, I, I, P, I, P],
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
     "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],

@@ -249,7 +249,132 @@ __global__ __launch_bounds__(256, 2) void gru_wgrad_kernel(GruWgradParams p) {
 #endif
 }
 
+// ---- weight gradient of the head's first layer, dW1 [32][192] = dpre1^T [hT | x] over the valid rows (round 4) --------------
+// Was two generic 1x1 weight-gradient GEMMs on the transposed problem (32 input channels: 0.83 ms per step at 20-50 TFLOP/s,
+// 1.5 TB/s) + a transpose.  Here one streaming pass in gru_wgrad_kernel's style: 16-row stages of dpre1 [16][32], hT [16][128] and
+// x [16][64] by LDS-DMA through a 3-deep ring; six waves, wave j owns the 32 x 32 block of columns 32 j of [hT | x]; bf16x2
+// products (two bf16 planes per operand, three MFMAs) as the gate kernel's X2 form.  Partials ws[split][32][192].
+struct GruHeadWgradParams {
+  const float* dpre;   // [B*N][32]
+  const float* hT;     // [B*N][128]   (plane 5 of the save buffer)
+  const float* x;      // [B*N][64]
+  const int32_t* counts;
+  int B, N, nsplit;
+  float* ws;           // [nsplit][32][192]
+};
+
+__global__ __launch_bounds__(384) void gru_head_wgrad_kernel(GruHeadWgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int STG = WP * (32 + 128 + 64);        // floats per stage: G [16][32] | H [16][128] | X [16][64]  (14 KB)
+  constexpr int WD = 3;
+  __shared__ __attribute__((aligned(16))) float ring[WD * STG + 256 * 4];   // + 4 KB: landing zone of the spare DMA slots
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int split = blockIdx.x;
+  int S = 0;
+  for (int b = 0; b < p.B; ++b) S += (p.counts[b] + WP - 1) / WP;
+  const int64_t w0 = (int64_t)S * split / p.nsplit, w1 = (int64_t)S * (split + 1) / p.nsplit;
+  const int nst = (int)(w1 - w0);
+  int ib = 0, ic = (int)w0, inch = 0;
+  if (nst > 0) {
+    for (;; ++ib) {
+      inch = (p.counts[ib] + WP - 1) / WP;
+      if (ic < inch) break;
+      ic -= inch;
+    }
+  }
+  const unsigned rows_b = (unsigned)min((int64_t)p.B * p.N, (int64_t)0x3fffff);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dpre), 0, rows_b * 128u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hT), 0, rows_b * 512u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, rows_b * 256u, 0x00020000);
+  // 14 one-KB DMA ops per stage: 0-1 G (8 rows x 128 B each), 2-9 H (2 rows x 512 B), 10-13 X (4 rows x 256 B); op = wave + 6 e,
+  // e < 3 -- ops 14 .. 17 land in the spare zone (every wave issues exactly three per stage: compile-time wait counts)
+  auto issue = [&](int buf) {
+    float* st = ring + buf * STG;
+    const int cnt = p.counts[ib];
+    const int row0 = ic * WP;
+    const int64_t srow = (int64_t)ib * p.N + row0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int op = wave + 6 * e;
+      if (op < 2) {
+        const int r = 8 * op + (lane >> 3);
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 128 + (lane & 7) * 16) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(st + op * 256), 16, vo, 0, 0, 0);
+      } else if (op < 10) {
+        const int r = 2 * (op - 2) + (lane >> 5);
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 512 + (lane & 31) * 16) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(st + WP * 32 + (op - 2) * 256), 16, vo, 0, 0, 0);
+      } else if (op < 14) {
+        const int r = 4 * (op - 10) + (lane >> 4);
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 256 + (lane & 15) * 16) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(st + WP * 160 + (op - 10) * 256), 16, vo, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(ring + WD * STG + (op - 14) * 256), 16, BAD, 0, 0, 0);
+      }
+    }
+    if (++ic == inch) {
+      ic = 0;
+      do {
+        if (++ib == p.B) { ib = 0; break; }
+        inch = (p.counts[ib] + WP - 1) / WP;
+      } while (inch == 0);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int d = 0; d < WD - 1; ++d)
+    if (d < nst) issue(d);
+  for (int i = 0; i < nst; ++i) {
+    switch (min(WD - 2, nst - 1 - i)) {
+      case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __syncthreads();
+    if (i + WD - 1 < nst) issue((i + WD - 1) % WD);
+    const float* st = ring + (i % WD) * STG;
+    bf16x8_t ah, al, bh, bl;
+    auto split8 = [&](const float* col, int pitch, bf16x8_t& hi, bf16x8_t& lo) {   // rows 8 kh .. 8 kh + 7 of one column
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = col[(8 * kh + k) * pitch];
+        hi[k] = (__bf16)v;
+        lo[k] = (__bf16)(v - (float)hi[k]);
+      }
+    };
+    split8(st + li, 32, ah, al);                                                   // dpre1 column li
+    if (wave < 4) split8(st + WP * 32 + 32 * wave + li, 128, bh, bl);              // hT columns 32 wave + li
+    else split8(st + WP * 160 + 32 * (wave - 4) + li, 64, bh, bl);                 // x columns
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  float* o = p.ws + (int64_t)split * 32 * 192;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = (e & 3) + 8 * (e >> 2) + 4 * kh;
+    o[co * 192 + 32 * wave + li] = acc[e];
+  }
+#endif
+}
+
 }  // namespace
+
+// dW1 partials [nsplit][32][192] of the decoder head's first layer from dpre1 [B*N][32], hT [B*N][128] and x [B*N][64] (valid rows
+// only); df_conv2d_wgrad_reduce(ws, nsplit, 32, 1, 192, ...) sums them.  bf16x2 products (16 significant bits) like mfma_bf16 = 3.
+extern "C" int df_gru_head_wgrad(const float* dpre, const float* hT, const float* x, const int32_t* counts, int B, int N, float* ws,
+                                 int nsplit, void* stream) {
+  DF_REQUIRE(dpre && hT && x && counts && ws && B > 0 && N > 0 && nsplit >= 1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(dpre) && df_aligned16(hT) && df_aligned16(x), DF_E_ALIGN);
+  DF_REQUIRE((int64_t)B * N < (int64_t)0x3fffff, DF_E_SHAPE);      // 32-bit DMA offsets (512 B per hT row)
+  GruHeadWgradParams p;
+  p.dpre = dpre; p.hT = hT; p.x = x; p.counts = counts; p.B = B; p.N = N; p.nsplit = nsplit; p.ws = ws;
+  hipLaunchKernelGGL(gru_head_wgrad_kernel, dim3(nsplit), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
 
 extern "C" int df_gru_wgrad_splits(void) { return 170; }   // 3 gates x 170 = 510 workgroups: one resident wave at 2 per CU
 

@@ -265,13 +265,23 @@ class ConvGRUDecoder(nn.Module):
                 dW_all = torch.empty(384, 192, **f32)
                 call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
                 dW_zr, dW_q = dW_all[:256], dW_all[256:]
-            # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
-            dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
-            dW1t = torch.empty(192, 32, **f32)
-            with ops.mfma_bf16(bool(bf)):   # the head's generic weight gradients follow the forward's mode too
-                ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
-                ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
-            dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
+            if x2 and os.environ.get("DF_GRU_HEAD_WGRAD", "1") != "0":
+                # dW_1 [32,192] = dpre1^T [hT | x] in one streaming pass (round 4: gru_head_wgrad_kernel, bf16x2 products like the gate
+                # kernels; was two generic 1x1 weight-gradient GEMMs on the transposed problem + a transpose: 0.83 ms per step)
+                nsp1 = 128
+                ws1 = torch.empty(nsp1, 32, 192, **f32)
+                with ops.timed("gru_head_wgrad", flops=2.0 * 32 * 192 * B * N, bytes=B * N * 4.0 * (32 + 192)):
+                    call("df_gru_head_wgrad", ptr(dpre1), sv.data_ptr() + 4 * 5 * plane, ptr(xbuf), ptr(ps.counts), B, N, ptr(ws1), nsp1, s)
+                dW1 = torch.empty(32, 192, **f32)
+                call("df_conv2d_wgrad_reduce", ptr(ws1), nsp1, 32, 1, 192, ptr(dW1), 192, 0, s)
+            else:
+                # dW_1^T [192,32] = [hT | x]^T dpre1  (output channels must be a multiple of 64 -> compute the transpose)
+                dpre_img = rows_img(dpre1, 0, 1, 32, 32, BN * 32)
+                dW1t = torch.empty(192, 32, **f32)
+                with ops.mfma_bf16(bool(bf)):   # the head's generic weight gradients follow the forward's mode too
+                    ops.conv2d_wgrad(dpre_img, hT, 1, 1, dW1t, ld_co=32, dw_off=0, **kw)
+                    ops.conv2d_wgrad(dpre_img, x_one, 1, 1, dW1t, ld_co=32, dw_off=128 * 32, **kw)
+                dW1 = ops.weight_transpose(dW1t.view(192, 1, 1, 32)).view(32, 192)
         g = self.gru
         grads[g.convz.weight] = dW_zr[:128].unsqueeze(2)
         grads[g.convr.weight] = dW_zr[128:].unsqueeze(2)

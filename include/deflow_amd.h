@@ -395,6 +395,10 @@ int df_gru_decoder_bwd_mp(const float* dflow, const float* offs, const int32_t* 
  * ws[split][384][192] partial tiles, rows 0..127 dW_z, 128..255 dW_r, 256..383 dW_q, columns [h | x]; sum the splits
  * with df_conv2d_wgrad_reduce(ws, splits, 384, 1, 192, ...).  x = the [B*N,64] offset encoding df_gru_decoder_bwd wrote. */
 int df_gru_wgrad_splits(void);
+/* round 4: the head's first-layer weight gradient dW1 [32][192] = dpre1^T [hT | x] over the valid rows in one streaming pass
+ * (partials ws [nsplit][32][192], summed by df_conv2d_wgrad_reduce); bf16x2 products.  [REF decoder.py:151-153,182] differentiated */
+int df_gru_head_wgrad(const float* dpre, const float* hT, const float* x, const int32_t* counts, int B, int N, float* ws, int nsplit,
+                      void* stream);
 int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,
                  int nsplit, void* stream);
 int df_gru_wgrad_mp(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,

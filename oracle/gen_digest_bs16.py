@@ -4,7 +4,7 @@ with no CPU cost (VERDICT r2 next #6b).  Test infrastructure only.
 
     python oracle/gen_digest_bs16.py 256 20000      -> tests/golden/bs16_256_digest.npz
     python oracle/gen_digest_bs16.py 512 80000      -> tests/golden/bs16_512_digest.npz
-    python oracle/gen_digest_bs16.py 1024 160000 --batch 4 --voxel 0.1 --iters 8 --seed 20240116 --init-seed 46
+    python oracle/gen_digest_bs16.py 1024 160000 --batch 4 --voxel 0.1 --iters 8 --seed 20240116 --init-seed 46 --exact-synth 1
                                                     -> tests/golden/bs4_1024_it8_digest.npz   (BASELINE configs[4] per GPU:
                                                        the shape of bench.py's `configs4_shape`; round 4)
 
@@ -99,6 +99,11 @@ def main():
     ap.add_argument("--seed", type=int, default=4242)
     ap.add_argument("--init-seed", type=int, default=16)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--exact-synth", type=int, default=0,
+                    help="1: the host-independent generator (deflow_amd.synth exact=True: no BLAS / LAPACK in the input pipeline) -- "
+                         "the default generator's pc1 / pose1 / gt flow differ in the last bit between hosts, which is enough to move "
+                         "points across 0.1 m voxel edges (found with the configs[4] digest: deep-layer gradients off by percents on "
+                         "the GPU box although every kernel was right)")
     args = ap.parse_args()
     grid, n_pts, B = args.grid, args.n_pts, args.batch
     torch.set_num_threads(args.threads)
@@ -112,9 +117,10 @@ def main():
     sd = copy.deepcopy(ref.state_dict())
     del ref
     # (the point spread follows the metric extent of the grid, as synth_batch's grid_hw does for the 0.2 m voxels)
-    batch = synth_batch(B, n_pts, seed=args.seed, grid_hw=(int(round(grid * args.voxel / 0.2)),) * 2)
+    batch = synth_batch(B, n_pts, seed=args.seed, grid_hw=(int(round(grid * args.voxel / 0.2)),) * 2,
+                        exact=bool(args.exact_synth))
     d = {"grid": grid, "n_pts": n_pts, "nproj": NPROJ, "batch": B, "voxel": args.voxel, "iters": args.iters, "seed": args.seed,
-         "init_seed": args.init_seed, "threads": args.threads}
+         "init_seed": args.init_seed, "threads": args.threads, "exact_synth": args.exact_synth}
     outs = {}
     spill_root = os.environ.get("DF_DIGEST_SPILL", "/tmp/df_digest_spill")
     for tag in ("32", "64"):                       # one precision at a time, its tape released before the next

@@ -178,7 +178,8 @@ def _bs16_case(dev, monkeypatch, grid, n_pts, tag, golden_dir, digest=None, bf16
     mine = deflow_amd.DeFlow(**cfg)
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(dev).train()
-    batch = synth_batch(B, n_pts, seed=int(dg["seed"]) if "seed" in dg else 4242, grid_hw=(int(round(grid * voxel / 0.2)),) * 2)
+    batch = synth_batch(B, n_pts, seed=int(dg["seed"]) if "seed" in dg else 4242, grid_hw=(int(round(grid * voxel / 0.2)),) * 2,
+                        exact=bool(int(dg["exact_synth"])) if "exact_synth" in dg else False)
     bd = to_dev(batch, dev)
     sums = parity.DyAbsSums(monkeypatch)
     from deflow_amd.optim import Trainer

@@ -36,7 +36,9 @@ tr = Trainer(model, lr=2e-4, dtype=DTYPE)
 print(f"dtype={DTYPE}, host cpu_count={os.cpu_count()}")
 ds = HDF5Dataset(root)
 ds.data_index = ds.data_index * 4              # 640 pairs = 40 steps per epoch: steady state, not worker start-up
-for workers in ((4, 8, 16, 28) if DTYPE == "bf16" else (0, 4, 16)):
+QUICK = os.environ.get("DF_LOADER_QUICK") == "1"        # bench.py's `loader_fed` extra: one worker count, one JSON line at the end
+results = {}
+for workers in ((4,) if QUICK else (4, 8, 16, 28) if DTYPE == "bf16" else (0, 4, 16)):
     sampler = ShardedSampler(len(ds), shuffle=True, seed=1)
     n, t0 = 0, None
     for ep in range(1):
@@ -48,10 +50,16 @@ for workers in ((4, 8, 16, 28) if DTYPE == "bf16" else (0, 4, 16)):
             elif k > 4:
                 n += 16
     torch.cuda.synchronize()
-    print(f"loader-fed, {workers} reader processes: {n / (time.perf_counter() - t0):.1f} pairs/s  (N padded {b['pc0'].shape[1]}, loss {float(loss.detach()):.3f})")
+    results[workers] = n / (time.perf_counter() - t0)
+    print(f"loader-fed, {workers} reader processes: {results[workers]:.1f} pairs/s  (N padded {b['pc0'].shape[1]}, loss {float(loss.detach()):.3f})")
 b = {k: v for k, v in b.items()}
 for _ in range(2): tr.step(b)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): tr.step(b)
 torch.cuda.synchronize()
-print(f"same model, one resident batch: {160 / (time.perf_counter() - t0):.1f} pairs/s")
+resident = 160 / (time.perf_counter() - t0)
+print(f"same model, one resident batch: {resident:.1f} pairs/s")
+if QUICK:
+    import json
+    print(json.dumps({"dtype": DTYPE, "reader_processes": 4, "loader_fed_pairs_per_s": results[4], "resident_pairs_per_s": resident,
+                      "ratio": results[4] / resident, "points_per_sweep": "90-110k (AV2-sized h5 scenes written at run time)"}))

@@ -7,7 +7,7 @@
 #   3. the training step with dtype=bf16 only -> <TAG>_bf16_train_kernel_stats.txt
 #   4. two separate PMC passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only, as the pool requires) -> HBM bytes per launch
 #   5. SQ counter passes of the dominant conv kernel, fp32 and bf16-operand mode -> <TAG>_pmc_conv_{f32,bf16}.txt
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -62,6 +62,9 @@ n, h, cin, cout = 32, 128, 128, 128
 x = torch.randn(n, h, h, cin, device=dev).to(dt); w = torch.randn(cout, 3, 3, cin, device=dev) * 0.05
 y = torch.empty(n, h, h, cout, device=dev, dtype=dt)
 dy = torch.randn(n, h, h, cout, device=dev).to(dt); dw = torch.empty(cout, 3, 3, cin, device=dev)
+if not bf and os.environ.get("DF_H2P", "1") != "0":      # round 4: the fp32 step's layers read PRE-SPLIT planes (conv_halo_x3_kernel<..,XP>, wgrad3_h2p_kernel)
+    xb = torch.tensor([float(x.abs().max()) * 1.5], device=dev); yb = torch.tensor([float(dy.abs().max()) * 1.5], device=dev)
+    x, dy = ops.h2_pack(x, xb), ops.h2_pack(dy, yb)
 with ops.mfma_bf16(bf, bf):
     for _ in range(3):
         ops.conv2d(img(x), w, None, img(y), 3, 1)
