@@ -54,6 +54,7 @@ def parse():
                          "the training launches only)")
     ap.add_argument("--forward-only", action="store_true", help="(kept for compatibility: the forward-only leg now always runs)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--no-loader", action="store_true", help="skip the loader_fed extra (scene files written at run time; ~1 min)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only: gloo, no GPU, no kernels (CPU test of the N > 1 start-up)")
     return ap.parse_args()
@@ -622,7 +623,7 @@ def main():
         # GRU decoder back on it -- fresh processes, because the library reads its switches once
         # N2 (the step before the path): the same training step fed by the scene-file loader (h5 scenes of AV2-sized sweeps written at run
         # time, 4 reader processes) against one resident batch -- is the loader able to feed this step?  (tools/bench_loader.py)
-        for dt_ in ("fp32", "bf16"):
+        for dt_ in (() if args.no_loader else ("fp32", "bf16")):
             try:
                 env = dict(os.environ, DF_LOADER_QUICK="1", DF_LOADER_DTYPE=dt_)
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_loader.py")], capture_output=True, text=True, env=env, timeout=600)

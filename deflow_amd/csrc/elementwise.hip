@@ -578,59 +578,6 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
   }
 }
 
-// Block form of the same resampling (round 4): a thread owns one INPUT pixel's 4 channels and produces the 2 x 2 output pixels
-// (2 yi .. + 1, 2 xi .. + 1) from the 3 x 3 input neighbourhood -- 9 loads per 4 outputs instead of 16, 4 coordinate evaluations
-// instead of 8.  Every output is evaluated with lerp_src's indices / weights and the SAME expression as the gather form above, so the
-// results are bit-identical (whatever align_corners: the rows an output reads are always among yi - 1, yi, yi + 1, picked by index).
-template <int YE = 0>
-__global__ __launch_bounds__(256) void upsample2x_blk_kernel(df_img x, df_img y, int align_corners, int64_t total4, const float* __restrict__ y_bound) {
-  float ys = 1.f;
-  if constexpr (YE == 2) ys = df_h2_scale(*y_bound);
-  const int C4 = x.c >> 2;
-  const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t m = i / C4;
-    const int c = (int)(i - m * C4) * 4;
-    const int xi = (int)(m % x.w);
-    m /= x.w;
-    const int yi = (int)(m % x.h), n = (int)(m / x.h);
-    const int ry[3] = {max(yi - 1, 0), yi, min(yi + 1, x.h - 1)}, rx[3] = {max(xi - 1, 0), xi, min(xi + 1, x.w - 1)};
-    const float* b = xp + df_img_base(x, n) + c;
-    f32x4 v[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) v[a][k] = ld4(b + ((int64_t)ry[a] * x.w + rx[k]) * x.ld);
-    auto pick = [](const int (&r)[3], int idx) { return idx == r[0] ? 0 : (idx == r[1] ? 1 : 2); };
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int Y = 2 * yi + dy;
-      const Lerp ly = lerp_src(Y, x.h, y.h, align_corners);
-      const int a0 = pick(ry, ly.i0), a1 = pick(ry, ly.i1);
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int X = 2 * xi + dx;
-        const Lerp lx = lerp_src(X, x.w, y.w, align_corners);
-        const int k0 = pick(rx, lx.i0), k1 = pick(rx, lx.i1);
-        auto sel = [&](int a, int k) {        // (register-resident 3 x 3: selects, no dynamic indexing)
-          f32x4 r = v[0][0];
-#pragma unroll
-          for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk)
-              if (aa == a && kk == k) r = v[aa][kk];
-          return r;
-        };
-        const f32x4 v00 = sel(a0, k0), v01 = sel(a0, k1), v10 = sel(a1, k0), v11 = sel(a1, k1);
-        const f32x4 o = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
-        const int64_t oi = df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c;
-        if constexpr (YE == 2) st_h2x4(y.ptr, oi, o, ys);
-        else stx4<YE>(y.ptr, oi, o);
-      }
-    }
-  }
-}
-
 // bf16 activations (inference path): the same PyTorch lerp semantics evaluated in fp32, 8 channels (16 bytes) per thread
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void upsample2x_bf16_kernel(df_img x, df_img y, int align_corners, int64_t total8) {
@@ -883,13 +830,10 @@ extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream
   DF_REQUIRE(img_ok(x) && img_ok(y, true), DF_E_ARG);     // y may be bfloat16 (bf16-storage training)
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
-  static const int blk = getenv("DF_UPSAMPLE_BLK") ? atoi(getenv("DF_UPSAMPLE_BLK")) : 1;   // 0: the per-output gather form (A/B; bit-identical)
-  const int64_t in4 = (int64_t)x.n * x.h * x.w * (x.c / 4);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (blk && y.elt) hipLaunchKernelGGL(upsample2x_blk_kernel<1>, dim3(grid_for(in4)), dim3(256), 0, s, x, y, align_corners, in4, nullptr);
-  else if (blk) hipLaunchKernelGGL(upsample2x_blk_kernel<0>, dim3(grid_for(in4)), dim3(256), 0, s, x, y, align_corners, in4, nullptr);
-  else if (y.elt) hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total4)), dim3(256), 0, s, x, y, align_corners, total4, nullptr);
-  else hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total4)), dim3(256), 0, s, x, y, align_corners, total4, nullptr);
+  if (y.elt) hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                                y, align_corners, total4, nullptr);
+  else hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                          y, align_corners, total4, nullptr);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }
@@ -899,11 +843,8 @@ extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream
 extern "C" int df_upsample2x_h2(df_img x, df_img y, int align_corners, const float* y_bound, void* stream) {
   DF_REQUIRE(img_ok(x) && h2_ok(y) && y_bound, DF_E_ARG);
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
-  const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4), in4 = (int64_t)x.n * x.h * x.w * (x.c / 4);
-  static const int blk = getenv("DF_UPSAMPLE_BLK") ? atoi(getenv("DF_UPSAMPLE_BLK")) : 1;
-  if (blk) hipLaunchKernelGGL(upsample2x_blk_kernel<2>, dim3(grid_for(in4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
-                              align_corners, in4, y_bound);
-  else hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+  const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
                      align_corners, total4, y_bound);
   DF_CHECK_LAUNCH();
   return DF_OK;

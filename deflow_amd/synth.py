@@ -21,6 +21,19 @@ def _rigid(p: torch.Tensor, T) -> torch.Tensor:
     return torch.stack([(x * t[i][0] + y * t[i][1]) + (z * t[i][2] + t[i][3]) for i in range(3)], 1)
 
 
+def _sqrt_f32(sq: torch.Tensor) -> torch.Tensor:
+    """correctly rounded fp32 square root on every host: torch.sqrt on CPU is NOT (measured: the build container and the GPU box
+    differ in the last bit for some of 160 000 values -- different vector code paths).  Candidate from the double root, then the
+    choice among it and its two fp32 neighbours by comparing sq with the squared midpoints -- all exact in double (a midpoint has
+    25 significant bits, its square 50)."""
+    sq64 = sq.double()
+    y = torch.sqrt(sq64).float()
+    inf = torch.full_like(y, float("inf"))
+    lo, hi = torch.nextafter(y, -inf), torch.nextafter(y, inf)
+    m1, m2 = (lo.double() + y.double()) * 0.5, (y.double() + hi.double()) * 0.5
+    return torch.where(sq64 < m1 * m1, lo, torch.where(sq64 > m2 * m2, hi, y))
+
+
 def synth_pair(seed: int, n: int, grid_hw=(512, 512), nan_frac: float = 0.02, exact: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> pc0 [n,3], pc1 [n,3], ego motion T (pc0 -> pc1 frame) [4,4], gt flow [n,3] (total, incl. ego motion).
@@ -39,7 +52,7 @@ def synth_pair(seed: int, n: int, grid_hw=(512, 512), nan_frac: float = 0.02, ex
     flow = torch.zeros(n, 3)
     d = torch.randn(n, 3, generator=g)
     if exact:
-        nrm = torch.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).unsqueeze(1)
+        nrm = _sqrt_f32((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).unsqueeze(1)
     else:
         nrm = d.norm(dim=1, keepdim=True)
     d = d / nrm * (torch.rand(n, 1, generator=g) * 2.0)

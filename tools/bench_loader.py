@@ -35,7 +35,7 @@ DTYPE = os.environ.get("DF_LOADER_DTYPE", "fp32")      # bf16: the training step
 tr = Trainer(model, lr=2e-4, dtype=DTYPE)
 print(f"dtype={DTYPE}, host cpu_count={os.cpu_count()}")
 ds = HDF5Dataset(root)
-ds.data_index = ds.data_index * 4              # 640 pairs = 40 steps per epoch: steady state, not worker start-up
+ds.data_index = ds.data_index * (2 if os.environ.get("DF_LOADER_QUICK") == "1" else 4)   # 640 pairs = 40 steps per epoch: steady state, not worker start-up (quick: 20 steps)
 QUICK = os.environ.get("DF_LOADER_QUICK") == "1"        # bench.py's `loader_fed` extra: one worker count, one JSON line at the end
 results = {}
 for workers in ((4,) if QUICK else (4, 8, 16, 28) if DTYPE == "bf16" else (0, 4, 16)):

@@ -8,7 +8,7 @@ out = sys.argv[1]
 cfg = dict(voxel_size=[0.1, 0.1, 6], point_cloud_range=[-51.2, -51.2, -3, 51.2, 51.2, 3], grid_feature_size=[1024, 1024], num_iters=8)
 torch.manual_seed(46)
 ref = O.DeFlow(**cfg).train()
-batch = synth_batch(4, 160000, seed=20240116, grid_hw=(512, 512))
+batch = synth_batch(4, 160000, seed=20240116, grid_hw=(512, 512), exact=True)
 h = lambda t: hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()[:16]
 d = {"threads": torch.get_num_threads(), "cpu": os.cpu_count()}
 for k, v in batch.items():
