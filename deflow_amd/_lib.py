@@ -49,6 +49,7 @@ _SIGS = {
     "df_cell_sort_ws_bytes": [L],
     "df_cell_sort": [P, L, L, P, P, P, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],
+    "df_pfn_bn_finalize2": [P, I, I, P, P, P, F, F, P, P, P, P, DfGeom, P, P],
     "df_pfn_bwd_stats": [P, P, P, P, I, DfGeom, P, P, I, I, DfImg, P, I, P],
     "df_pfn_bwd_finalize": [P, I, I, P, P, P, I, P, P],
     "df_pfn_bwd_weights": [P, P, P, P, I, DfGeom, P, P, I, I, P, DfImg, P, I, P],

@@ -48,9 +48,15 @@ __device__ __forceinline__ void reduce_groups(float (&v)[NV], float* lds /*[256*
 // one workgroup per sample (the feature net is called once per sample: BatchNorm1d statistics are per sample): fp64 sums
 // of the per-band / per-block partials -> bn_ss[b] = (scale, shift, mean, invstd); (mean, unbiased var) of the sample is
 // left in the first partial slot for the running-statistics pass below, which must run in sample order
+// canvas_bound (round 4, optional): an a-priori bound of max |canvas| = max over (sample, channel) of |scale| U_c + |shift| with
+// U_c = sum_j |W[c][j]| fmax_j >= |linear output|: the nine point features are bounded by the geometry (coordinates by the
+// range, offsets to the pillar mean by the voxel size, offsets to the centre by half of it).  It spares the fp16x2 consumers of
+// the canvas (the decoder's 1x1 skip conv writes a pre-split concatenation) one pass over the 1 GB canvas.  Integer atomic max.
 __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(float* __restrict__ partial, int nblk,
                                                                const int32_t* __restrict__ counts, const float* gamma,
-                                                               const float* beta, float eps, float* __restrict__ bn_ss) {
+                                                               const float* beta, float eps, float* __restrict__ bn_ss,
+                                                               const float* __restrict__ w_pfn, df_pillar_geom g,
+                                                               unsigned* __restrict__ canvas_bound) {
   __shared__ double red[2][32][32];
   const int c = threadIdx.x & 31, tl = threadIdx.x >> 5;  // 32 channels x 32 partial lanes
   const int b = blockIdx.x;
@@ -85,6 +91,15 @@ __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(float* __restrict
   o[32 + c] = (float)(be - mean * ga * invstd);
   o[64 + c] = (float)mean;
   o[96 + c] = (float)invstd;
+  if (canvas_bound) {
+    const float fx = fmaxf(fabsf(g.minx), fabsf(g.minx + g.gx * g.vx)), fy = fmaxf(fabsf(g.miny), fabsf(g.miny + g.gy * g.vy)),
+                fz = fmaxf(fabsf(g.minz), fabsf(g.minz + g.gz * g.vz));
+    const float fm[9] = {fx, fy, fz, g.vx, g.vy, g.vz, 0.5f * g.vx, 0.5f * g.vy, 0.5f * g.vz};
+    float U = 0.f;
+    for (int j = 0; j < 9; ++j) U += fabsf(w_pfn[c * 9 + j]) * fm[j];
+    const unsigned bb = __builtin_bit_cast(unsigned, (fabsf(o[c]) * U + fabsf(o[32 + c])) * 1.001f);
+    if (bb > __atomic_load_n(canvas_bound, __ATOMIC_RELAXED)) atomicMax(canvas_bound, bb);
+  }
   mv[0] = (float)mean;
   mv[1] = (float)(cnt > 1 ? var * cnt / (cnt - 1.0) : var);
 }
@@ -850,9 +865,21 @@ extern "C" int df_cell_sort(const uint32_t* key, int64_t n, int64_t ncells, uint
 extern "C" int df_pfn_bn_finalize(float* partial, int B, int nblk_stat, const int32_t* counts,
                                   const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var, float* bn_ss, void* stream) {
-  DF_REQUIRE(partial && counts && bn_ss && B > 0 && nblk_stat > 0, DF_E_ARG);
+  df_pillar_geom g = {};
+  return df_pfn_bn_finalize2(partial, B, nblk_stat, counts, gamma, beta, eps, momentum, running_mean, running_var, bn_ss, nullptr, g, nullptr,
+                             stream);
+}
+
+// ... also leaving an a-priori bound of max |canvas| in *canvas_bound (zero-initialised or holding another cloud's bound: integer
+// atomic max) from the feature net's weights w_pfn [32][9] and the geometry -- see pfn_bn_finalize_kernel
+extern "C" int df_pfn_bn_finalize2(float* partial, int B, int nblk_stat, const int32_t* counts,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* bn_ss, const float* w_pfn, df_pillar_geom g,
+                                   float* canvas_bound, void* stream) {
+  DF_REQUIRE(partial && counts && bn_ss && B > 0 && nblk_stat > 0 && (!canvas_bound || w_pfn), DF_E_ARG);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(B), dim3(1024), 0, s, partial, nblk_stat, counts, gamma, beta, eps, bn_ss);
+  hipLaunchKernelGGL(pfn_bn_finalize_kernel, dim3(B), dim3(1024), 0, s, partial, nblk_stat, counts, gamma, beta, eps, bn_ss, w_pfn, g,
+                     reinterpret_cast<unsigned*>(canvas_bound));
   DF_CHECK_LAUNCH();
   if (running_mean && running_var) {
     hipLaunchKernelGGL(pfn_bn_running_kernel, dim3(1), dim3(32), 0, s, partial, B, nblk_stat, counts, momentum, running_mean,

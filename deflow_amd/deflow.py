@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import DfImg, call, img, ptr, stream
+from ._lib import DfImg, call, img, ptr, stream, ver as _ver
 from .autograd import DeFlowFn
 from .decoder import ConvGRUDecoder, LinearDecoder, PointSet
 from .encoder import DynamicEmbedder, canvas_alloc
@@ -77,6 +77,8 @@ class DeFlow(nn.Module):
         with ops.timed("canvas_zero_fill"):   # (first-generation pillariser only: the band pipeline writes its own zeros)
             bstar = canvas_alloc(B, emb.H, emb.W, 64, device=dev)
         self.timer[1].start("Voxelization")
+        # fp16x2 training: an a-priori bound of max |canvas| comes out of the feature net's BatchNorm finalisation (one slot, both clouds)
+        emb.canvas_bound = ops.amax_slot(dev) if (train and save and ops.h2_active() and ops.SYNC is None) else None
         if not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0":
             # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
             # samples writing the two channel halves of bstar -- half the launches of the ~15-kernel pipeline, which is
@@ -88,6 +90,9 @@ class DeFlow(nn.Module):
             p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save)
             p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save)
         self.timer[1].stop()
+        if emb.canvas_bound is not None:
+            bstar._df_amax = (emb.canvas_bound, _ver(bstar))
+            emb.canvas_bound = None
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None
         if self.inference_dtype == "bf16" and not train and not save:

@@ -114,8 +114,12 @@ class DynamicEmbedder(nn.Module):
                 bn_ss = self._sync_bn_stats(partial, counts)
             else:
                 bn_ss = torch.empty(B, 4, 32, dtype=torch.float32, device=dev)
-                call("df_pfn_bn_finalize", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
-                     bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss), s)
+                # fp16x2 mode: the finalisation also leaves an a-priori bound of max |canvas| (self.canvas_bound: one slot shared by
+                # the clouds of a forward, handed to the canvas tensor by DeFlow._run) -- no pass over the 1 GB canvas for it
+                cb = getattr(self, "canvas_bound", None)
+                call("df_pfn_bn_finalize2", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                     bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss),
+                     ptr(self._lin.weight.detach()) if cb is not None else None, self.geom, ptr(cb), s)
             bn.num_batches_tracked.add_(B)
             ops.PARAM_GEN[0] += 1
             return bn_ss, 128

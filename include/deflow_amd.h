@@ -93,6 +93,11 @@ int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float*
 int df_pfn_bn_finalize(float* partial /* clobbered: slot 0 of every sample is reused as scratch */, int B, int nblk_stat, const int32_t* counts, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                        float* bn_ss, void* stream);
+/* round 4: the same, also leaving an a-priori bound of max |canvas| (from the statistics, the feature net's weights w_pfn [32][9]
+ * and the geometry) in *canvas_bound (integer atomic max: zero-initialise it, or pass one slot for both clouds) */
+int df_pfn_bn_finalize2(float* partial, int B, int nblk_stat, const int32_t* counts, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, float* bn_ss, const float* w_pfn, df_pillar_geom g,
+                        float* canvas_bound, void* stream);
 /* Stable counting sort of caller-supplied cell keys (the stand-alone decoder-head call takes arbitrary voxel_coords
  * [REF decoder.py:185-199], not the pillariser's): idx_sorted [n] u32 = indices of the keys < ncells grouped by key, ascending
  * index inside a group (entries past the number of such keys are not written); cell_rng [ncells, 2] i32 = [start, end) per key,

@@ -415,3 +415,25 @@ def test_weight_prep_one_launch_equals_per_call_forms(dev, monkeypatch):
         assert (getattr(tr, "_wprep", None) is not None) == (flag == "1")
         arenas[flag] = tr.flat.grad.clone()
     assert torch.equal(arenas["1"], arenas["0"])
+
+
+def test_canvas_bound_from_the_feature_net_statistics(dev):
+    """df_pfn_bn_finalize2: the a-priori bound of max |canvas| (BatchNorm1d statistics x the largest reachable linear output: the nine
+    point features are bounded by the geometry) holds and is within 2^10 of the true maximum -- it replaces a df_absmax pass over the
+    1 GB canvas for the fp16x2 consumers of the skip connection."""
+    import deflow_amd
+    from deflow_amd import ops
+    from deflow_amd.synth import synth_batch
+    cfg = dict(voxel_size=[0.2, 0.2, 6], point_cloud_range=[-25.6, -25.6, -3, 25.6, 25.6, 3], grid_feature_size=[256, 256])
+    torch.manual_seed(5)
+    m = deflow_amd.DeFlow(**cfg).to(dev).train()
+    batch = synth_batch(4, 20000, seed=11, grid_hw=(256, 256), device=dev)
+    ops.amax_pool_reset()
+    with torch.no_grad():
+        flow, st = m._run(batch["pc0"].contiguous(), batch["pc1"].contiguous(), True, True)
+    torch.cuda.synchronize()
+    rec = getattr(st["bstar"], "_df_amax", None)
+    assert rec is not None
+    bound, true_max = float(rec[0]), float(st["bstar"].abs().max())
+    print(f"[parity] canvas bound {bound:.3f} = {bound / true_max:.1f} x max |canvas| {true_max:.3f}")
+    assert true_max <= bound <= 1024 * true_max
