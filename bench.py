@@ -435,7 +435,7 @@ def main():
             out["roofline"]["fp16x2_family"] = {"ms_per_step": sum(v["ms"] for v in fam) / args.steps, "tflops": ft,
                                                 "frac": ft / (PEAK_BF16_MFMA_TFLOPS / 3.0),
                                                 "share_of_step": sum(v["ms"] for v in fam) / args.steps / ms}
-        sus = sustained_mfma()
+        sus = None if os.environ.get("DF_BENCH_NO_SUBPROC") == "1" else sustained_mfma()
         if sus is not None:
             # the chip sustains the nominal 16-bit peak only on operands that toggle nothing; under random operands a PURE MFMA stream
             # (no LDS, no memory) runs at the power-limited clock: that figure / 3 is the reachable roof of the fp16x2 kernels
@@ -623,15 +623,17 @@ def main():
         # GRU decoder back on it -- fresh processes, because the library reads its switches once
         # N2 (the step before the path): the same training step fed by the scene-file loader (h5 scenes of AV2-sized sweeps written at run
         # time, 4 reader processes) against one resident batch -- is the loader able to feed this step?  (tools/bench_loader.py)
-        for dt_ in (() if args.no_loader else ("fp32", "bf16")):
+        nosub = os.environ.get("DF_BENCH_NO_SUBPROC") == "1"     # (under rocprofv3: child processes would be traced into the same output)
+        for dt_ in (() if (args.no_loader or nosub) else ("fp32", "bf16")):
             try:
                 env = dict(os.environ, DF_LOADER_QUICK="1", DF_LOADER_DTYPE=dt_)
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_loader.py")], capture_output=True, text=True, env=env, timeout=600)
                 out.setdefault("loader_fed", {})[dt_] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             except Exception as e:   # noqa: BLE001
                 out.setdefault("loader_fed", {})[dt_] = {"error": f"{type(e).__name__}: {e}"[:200]}
-        out["strict_fp32"] = strict_leg({"DF_CONV_X3": "0", "DF_WGRAD_X3": "0", "DF_CONV_H2F": "0", "DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
-        out["gru_fp32"] = strict_leg({"DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
+        if not nosub:
+          out["strict_fp32"] = strict_leg({"DF_CONV_X3": "0", "DF_WGRAD_X3": "0", "DF_CONV_H2F": "0", "DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
+          out["gru_fp32"] = strict_leg({"DF_GRU_X2": "0"}, args.steps, args.warmup, args.batch)
     if use_dist:
         dist.destroy_process_group()
     if world == 1 and not args.no_cpu_baseline:

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 stats() { python $R/tools/rocpd_stats.py $(find $1 -name "*.db" | head -1); }
-rocprofv3 --kernel-trace --stats -d /tmp/kt_full -o kt -- python $R/bench.py > /tmp/kt_full.log 2>&1
+DF_BENCH_NO_SUBPROC=1 rocprofv3 --kernel-trace --stats -d /tmp/kt_full -o kt -- python $R/bench.py --no-loader > /tmp/kt_full.log 2>&1   # (the fresh-process legs -- strict_fp32, gru_fp32, loader_fed, the MFMA probe -- are not traced)
 stats /tmp/kt_full > $O/${TAG}_full_kernel_stats.txt 2>&1
 grep "^{\"metric\"" /tmp/kt_full.log | tail -1 > $O/${TAG}_bench.json
 rocprofv3 --kernel-trace --stats -d /tmp/kt_train -o kt -- python $R/bench.py --no-extras --no-cpu-baseline > /tmp/kt_train.log 2>&1
