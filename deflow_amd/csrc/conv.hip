@@ -91,6 +91,7 @@ struct ConvParams {
   // backward, which otherwise cost a separate pass over dz and y (bn_gelu_bwd_reduce_kernel)
   const float* bwd_y;
   const float* bwd_ss;
+  int rot;  // conv_halo_x3_kernel: rotated tap-row order (see there); env DF_CONV_ROT=0 restores the plain order
 };
 constexpr int DF_EPI_BWD_STATS = 3;
 __host__ __device__ inline bool epi_stats(int epi) { return epi == DF_EPI_STATS || epi == DF_EPI_BWD_STATS; }
@@ -1211,10 +1212,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
   // weight stage to issue
   const unsigned a_row_step = (unsigned)(wx * ldx * XE - KC * BK * XE);
   const int dtap = fwd ? p.K * 2 : -p.K * 2;
-  unsigned sa_next = 0;
-  int ty_next = 0, kc_next = 0;
-  int swb_next = fwd ? 0 : 8 * p.K * 2;                // byte offset of tap (ty, tx = 0), chunk kc of the next weight GROUP
-  int btx = 0, bkc = 0;                                // next weight stage: its tap inside the group, the group's k chunk
+  // ROTATED tap rows (round 4; p.rot): the workgroup walks ty = r, r + 1, r + 2 (mod 3) with r = (1 - oy) mod 3, so that in its
+  // phase ph EVERY workgroup reads the input rows = ph (mod 3).  The 32 workgroups an XCD runs side by side hold 32 consecutive
+  // rows of one image (df_xcd_swizzle); in the plain order row R was fetched by workgroup R + 1 in its first third, by R in its
+  // second and by R - 1 in its last, with 32 x 131 KB of other rows through the 4 MB L2 in between: the 512-wide layers fetched
+  // 2.65x their input from HBM (FETCH_SIZE, round 4).  Rotated, the three readers of a row ask for it in
+  // the same phase.  (The fp32 accumulation order of the taps now depends on oy: deterministic, not the plain order's bits.)
+  // Measured (FETCH_SIZE, profiles/r04_pmc_conv_rot.txt): 512-wide rows 2.84 -> 1.47 GB per launch (64 channels), 1.54 -> 0.86 GB
+  // (128); two-row tiles -10..-25 %; four-row tiles read every row in all three phases either way (+15 %: left in the plain order).
+  // The kernels' times do not move (+-1 %): they were not waiting for these bytes.
+  const int rot = (p.rot && SEG <= 2) ? (1 + 2 * oy) % 3 : 0;
+  const unsigned a_row = (unsigned)(wx * ldx * XE);
+  unsigned sa_next = rot * a_row;
+  int ty_next = rot, kc_next = 0;
+  int swb_next = (fwd ? 0 : 8 * p.K * 2) + rot * 3 * dtap;   // byte offset of tap (ty, tx = 0), chunk kc of the next weight GROUP
+  int btx = 0, bkc = 0, bty = rot;                     // next weight stage: its tap inside the group, the group's k chunk and tap row
   const int NG = 3 * KC, NS = 3 * NG;
 
   f32x4 ra[NIT][2];
@@ -1236,8 +1248,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
     }
     if (++kc_next == KC) {
       kc_next = 0;
-      ++ty_next;
       sa_next += a_row_step + BK * XE;
+      if (++ty_next == 3) {                            // (rotated order: wrap to the first tap row)
+        ty_next = 0;
+        sa_next -= 3 * a_row;
+      }
     } else {
       sa_next += BK * XE;
     }
@@ -1295,6 +1310,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(ConvParams p
       if (++bkc == KC) {
         bkc = 0;
         swb_next += 3 * dtap - KC * BK * 2 + BK * 2;
+        if (++bty == 3) {
+          bty = 0;
+          swb_next -= 9 * dtap;
+        }
       } else {
         swb_next += BK * 2;
       }
@@ -3334,6 +3353,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.bound_y = y_bound;
   p.bwd_y = bwd_y;
   p.bwd_ss = bwd_ss;
+  static const int conv_rot = getenv("DF_CONV_ROT") ? atoi(getenv("DF_CONV_ROT")) : 1;
+  p.rot = conv_rot;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);

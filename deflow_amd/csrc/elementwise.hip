@@ -393,28 +393,52 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
   }
 }
 
+// 8 channels per workgroup x 128 slices of the partial rows: the data-gradient epilogues leave one partial row per workgroup (8192
+// rows at 512 x 512 x 16), and a 32-channel workgroup walked them 256 deep with two to eight workgroups on the chip (77 us average,
+// 250 us at 64 channels: 1.2 ms of the round-4 step).  Fixed summation order: bit-reproducible.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk_per_group,
                                                                int groups, int C, double count, float* dgamma,
                                                                float* dbeta, float* __restrict__ coef,
                                                                const float* __restrict__ bn_ss, const float* __restrict__ dz_amax,
                                                                const float* __restrict__ y_amax, unsigned* __restrict__ dy_bound) {
-  __shared__ double red[2][32][32];
-  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][128][8];
+  const int cl = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < groups; ++g) {
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-      for (int b = tl; b < nblk_per_group; b += 32) {
-        const float* q = partial + (((int64_t)g * nblk_per_group + b) * C + c) * 2;
-        s1 += (double)q[0];
-        s2 += (double)q[1];
+    if (c < C) {
+      const float2* q = reinterpret_cast<const float2*>(partial) + ((int64_t)g * nblk_per_group) * C + c;
+      int b = tl;
+      for (; b + 384 < nblk_per_group; b += 512) {
+        const float2 v0 = q[(int64_t)b * C], v1 = q[(int64_t)(b + 128) * C], v2 = q[(int64_t)(b + 256) * C], v3 = q[(int64_t)(b + 384) * C];
+        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
       }
+      for (; b < nblk_per_group; b += 128) {
+        const float2 v = q[(int64_t)b * C];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+      }
+    }
     red[0][tl][cl] = s1;
     red[1][tl][cl] = s2;
     __syncthreads();
+    if (tl < 8) {
+      s1 = 0.0, s2 = 0.0;
+      for (int k = tl; k < 128; k += 8) {
+        s1 += red[0][k][cl];
+        s2 += red[1][k][cl];
+      }
+    }
+    __syncthreads();
+    if (tl < 8) {
+      red[0][tl][cl] = s1;
+      red[1][tl][cl] = s2;
+    }
+    __syncthreads();
     if (tl == 0 && c < C) {
-      for (int k = 1; k < 32; ++k) {
+      for (int k = 1; k < 8; ++k) {
         s1 += red[0][k][cl];
         s2 += red[1][k][cl];
       }
@@ -752,8 +776,9 @@ extern "C" int df_bn_bwd_finalize(const float* partial, int nblk_per_group, int 
 extern "C" int df_bn_bwd_finalize2(const float* partial, int nblk_per_group, int groups, int C, int64_t count_per_group,
                                    float* dgamma, float* dbeta, float* coef, const float* bn_ss, const float* dz_amax,
                                    const float* y_amax, float* dy_bound, void* stream) {
-  DF_REQUIRE(partial && coef && nblk_per_group > 0 && groups > 0 && (!dy_bound || (bn_ss && dz_amax && y_amax)), DF_E_ARG);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+  DF_REQUIRE(partial && (((uintptr_t)partial) & 7) == 0 && coef && nblk_per_group > 0 && groups > 0 &&
+                 (!dy_bound || (bn_ss && dz_amax && y_amax)), DF_E_ARG);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                      partial, nblk_per_group, groups, C, (double)count_per_group, dgamma, dbeta, coef, bn_ss, dz_amax, y_amax,
                      reinterpret_cast<unsigned*>(dy_bound));
   DF_CHECK_LAUNCH();

@@ -211,6 +211,9 @@ def amax_of(d: DfImg, device) -> torch.Tensor:
         a = amax_slot(device)
         call("df_absmax", d, ptr(a), stream())
         d._amax = a
+        src = getattr(d, "_src", None)
+        if src is not None:               # whole-tensor view: the next descriptor made of the tensor finds the measurement (_lib.img)
+            src._df_amax = (a, ver(src))
     return a
 
 

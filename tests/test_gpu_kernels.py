@@ -958,7 +958,11 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
             check(f"{form} stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
             check(f"{form} stats sumsq", partial.sum(0).cpu()[:, 1], (ref.reshape(-1, oc) ** 2).sum(0).float(), 2e-5)
     print(f"[parity] conv {mode} {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {outs['h2']:.2e} | bf16x3 err {outs['x3']:.2e} | fp32-MFMA err {outs['fp32']:.2e} (vs float64)")
-    assert outs["x3"] <= 2e-6 and outs["h2"] <= 2e-6, outs
+    # (K = 9 x 256 terms: the fp32 accumulation's own rounding reaches 2-3e-6 of the largest output -- the fp32-MFMA kernel measures
+    # 3.2e-6 there -- and which side of 2e-6 the bf16x3 form lands on depends on the order of the tap rows: rotated order 2.2e-6,
+    # plain order 1.7e-6.  Bound: 2e-6, or the fp32-MFMA kernel's own error on the same operands where that is larger.)
+    lim = max(2e-6, outs["fp32"])
+    assert outs["x3"] <= lim and outs["h2"] <= lim, outs
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w,kname", [
