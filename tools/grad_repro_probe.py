@@ -46,6 +46,26 @@ def tap(stage, **kw):
 
 if os.environ.get("DF_PROBE_DEEP") == "1" and not graph:
     AG.TAP = tap
+# DF_STRESS_THREAD=<kind> (round 4): a neighbour THREAD of this process on its own stream (tools/pfn_neighbour.py kinds, DF_NB_ONLY
+# filter) -- is the whole training step bit-reproducible beside it?
+if os.environ.get("DF_STRESS_THREAD"):
+    import threading, time as _t
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pfn_neighbour
+    _stop, _count = threading.Event(), [0]
+
+    def _nb():
+        torch.cuda.set_device(dev)
+        st_ = torch.cuda.Stream()
+        with torch.cuda.stream(st_):
+            step_ = pfn_neighbour.make(os.environ["DF_STRESS_THREAD"], dev)
+            while not _stop.is_set():
+                step_()
+                _count[0] += 1
+                if _count[0] % 8 == 0:
+                    st_.synchronize()
+    threading.Thread(target=_nb, daemon=True).start()
+    _t.sleep(8.0)
 first, bad = None, {}
 for r in range(reps):
     step()
@@ -73,7 +93,11 @@ for r in range(reps):
             if not torch.equal(g[off:off + k], first[off:off + k]):
                 d = float((g[off:off + k] - first[off:off + k]).abs().max() / first[off:off + k].abs().max().clamp_min(1e-30))
                 bad.setdefault(n, []).append((r, d))
-print(f"{dtype} graph={graph} reps={reps}: {len(bad)} parameters with a varying gradient")
+if os.environ.get("DF_STRESS_THREAD"):
+    _stop.set()
+    _t.sleep(0.5)
+print(f"[lib {os.path.basename(os.environ.get('DF_LIB') or 'libdeflow_amd.so')}, thread {os.environ.get('DF_STRESS_THREAD', 'none')} /{os.environ.get('DF_NB_ONLY', '.')}/] "
+      f"{dtype} graph={graph} reps={reps}: {len(bad)} parameters with a varying gradient")
 for n, v in bad.items():
     print(f"   {n}: {len(v)} of {reps - 1} repetitions differ, max rel diff {max(d for _, d in v):.2e}")
 for k, v in tap_bad.items():

@@ -42,7 +42,54 @@ def bwd_one(pst, gout, acc, dW, dgamma, dbeta, tag):
     return {f"{tag}.partial": partial, f"{tag}.coef": coef, f"{tag}.dwp": dwp, f"{tag}.dgamma": dgamma.clone(), f"{tag}.dW": dW.clone()}
 
 
+# DF_STRESS_SIDE=matmul: the bf16-MFMA neighbour INSIDE this process -- a side stream kept busy with bf16 GEMMs (round 4: does the
+# failure need a second PROCESS, i.e. the GPU's time-slicing between contexts, or just a concurrent bf16-MFMA kernel?)
+side = torch.cuda.Stream() if os.environ.get("DF_STRESS_SIDE") else None
+if side is not None:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    kind = os.environ["DF_STRESS_SIDE"]
+    if kind.startswith("poison"):           # poison[:what] -- tools/poison.hip: NaN in 240 VGPRs and all of LDS on every CU
+        import ctypes
+        _pl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libpoison.so"))
+        _what = int(kind.split(":")[1]) if ":" in kind else 7
+        side_step = lambda: _pl.poison_launch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), _what)
+    elif kind.startswith("mfma"):           # mfma:<k> -- tools/pk_mfma_hazard.hip's register-resident MFMA stream (k: 0 = 16x16x32_bf16,
+        import ctypes                       # 1 = 32x32x16_bf16, 2 = 16x16x4_f32, 3 = 16x16x32_f16), ~2 ms per launch on half the chip
+        _hz = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libhazard.so"))
+        _k = int(kind.split(":")[1])
+        side_step = lambda: _hz.hazard_neighbour_launch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), _k, 20000, 512)
+    else:
+        import pfn_neighbour
+        side_step = pfn_neighbour.make({"matmul": "matmul_bf16"}.get(kind, kind), dev)
+    torch.cuda.synchronize()
+# DF_STRESS_THREAD=<kind>: the neighbour as a second host THREAD of this process with its own stream (tools/pfn_neighbour.py kinds).
+# A side stream fed by THIS thread does not overlap with the victim at the small test size: the GPU drains each tiny kernel before
+# the host has enqueued the next, so the two streams alternate.  Two host threads enqueue at the same time, like two processes do.
+if os.environ.get("DF_STRESS_THREAD"):
+    import threading
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pfn_neighbour
+    _stop = threading.Event()
+    _count = [0]
+
+    def _nb():
+        torch.cuda.set_device(dev)
+        st_ = torch.cuda.Stream()
+        with torch.cuda.stream(st_):
+            step_ = pfn_neighbour.make(os.environ["DF_STRESS_THREAD"], dev)
+            while not _stop.is_set():
+                step_()
+                _count[0] += 1
+                if _count[0] % 8 == 0:
+                    st_.synchronize()
+    _th = threading.Thread(target=_nb, daemon=True)
+    _th.start()
+    import time as _t
+    _t.sleep(8.0)
 for r in range(reps):
+    if side is not None:
+        with torch.cuda.stream(side):
+            side_step()                     # (each kind enqueues >= the ~0.3 ms of one repetition: the side stream stays busy)
     dW, dgamma, dbeta = torch.empty(32, 9, device=dev), torch.empty(32, device=dev), torch.empty(32, device=dev)
     inter = bwd_one(st["p0"], img(dbstar, 32, 0), False, dW, dgamma, dbeta, "c0")
     inter.update(bwd_one(st["p1"], img(dbstar, 32, 32), True, dW, dgamma, dbeta, "c1"))
@@ -60,6 +107,9 @@ for r in range(reps):
     elif not torch.equal(cur, first):
         nbad += 1
         worst = max(worst, float((cur - first).abs().max() / first.abs().max()))
-print(f"pfn backward alone: {nbad} of {reps - 1} repetitions differ from the first (worst rel {worst:.2e})")
+print(f"[lib {os.path.basename(os.environ.get('DF_LIB', 'libdeflow_amd.so'))}, side stream {os.environ.get('DF_STRESS_SIDE', 'none')}, thread {os.environ.get('DF_STRESS_THREAD', 'none')}] pfn backward: {nbad} of {reps - 1} repetitions differ from the first (worst rel {worst:.2e})")
+if os.environ.get("DF_STRESS_THREAD"):
+    _stop.set(); _th.join(10.0)
+    print(f"   neighbour thread ran {_count[0]} steps")
 for k, v in stage_bad.items():
     print(f"   {k}: {len(v)} reps differ, e.g. {v[:4]}")
