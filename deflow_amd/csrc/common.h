@@ -50,6 +50,12 @@ __device__ __forceinline__ int df_xcd_swizzle(int bid, int nwg) {
   return start + (bid >> 3);
 }
 
+// Index decode of the streaming kernels: every extent of this model (channels / 4, H W, W, H) is a power of two, and a 64-bit division
+// by a run-time value is ~25-100 VALU instructions -- a quarter of what bn_gelu_apply did per four elements (round 4).  sh =
+// df_pow2_shift(d) once per kernel (scalar), then a shift where d is a power of two and the division elsewhere (uniform branch).
+__device__ __forceinline__ int df_pow2_shift(int d) { return (d > 0 && (d & (d - 1)) == 0) ? __builtin_ctz((unsigned)d) : -1; }
+__device__ __forceinline__ int64_t df_udiv(int64_t x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
+
 // exact-erf GELU [REF decoder.py:209] and its derivative.  erf through Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute,
 // i.e. ~2 ulp of libm's erff at fp32): one v_exp_f32 -- exp(-x^2/2), shared by the erfc tail and the Gaussian of the
 // derivative -- one v_rcp_f32 and a degree-5 Horner form, ~16 VALU instructions instead of libm's erff + expf (~70 with

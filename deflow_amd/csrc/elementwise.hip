@@ -84,11 +84,12 @@ __device__ __forceinline__ void df_atomic_amax(unsigned* slot, float v) {   // v
 __global__ __launch_bounds__(256) void h2_pack_kernel(df_img x, df_img y, const float* __restrict__ bound, int64_t total4, int unpack) {
   const int C4 = x.c >> 2;
   const int hw = x.h * x.w;
+  const int c4s = df_pow2_shift(C4), hws = df_pow2_shift(hw);
   const float s = df_h2_scale(*bound), inv_s = 1.f / s;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / C4;
+    const int64_t m = df_udiv(i, C4, c4s);
     const int c = (int)(i - m * C4) * 4;
-    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
     const int64_t xi = df_img_base(x, n) + (int64_t)pix * x.ld + c, yi = df_img_base(y, n) + (int64_t)pix * y.ld + c;
     if (unpack) st4(reinterpret_cast<float*>(y.ptr) + yi, ld_h2x4(x.ptr, xi, inv_s));
     else st_h2x4(y.ptr, yi, ld4(reinterpret_cast<const float*>(x.ptr) + xi), s);
@@ -298,14 +299,15 @@ __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restri
                                                             unsigned* __restrict__ amax) {
   const int C4 = z.c >> 2;
   const int hw = z.h * z.w;
+  const int c4s = df_pow2_shift(C4), hws = df_pow2_shift(hw);
   float mf = 0.f;
   // ZE == 2: z is written pre-split (h2 image); `amax` is then an INPUT -- the bound of max |z| (df_bn_finalize2) that sets the scale
   float zs = 1.f;
   if constexpr (ZE == 2) zs = df_h2_scale(__builtin_bit_cast(float, *amax));
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / C4;
+    const int64_t m = df_udiv(i, C4, c4s);
     const int c = (int)(i - m * C4) * 4;
-    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
     const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
     const f32x4 v = ldx4<YE>(y, m * z.c + c), sc = ld4(ss + c), sh = ld4(ss + z.c + c);
     f32x4 o;
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
                                                                  int64_t rows_per_blk) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 2];
   const int C = dz.c, hw = dz.h * dz.w;
+  const int hws = df_pow2_shift(hw);
   const RowPart rp = row_part(C);
   const void* __restrict__ dzp = dz.ptr;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_reduce_kernel(df_img dz, cons
     const float* ss = bn_ss + (int64_t)g * 4 * C;
     const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
     for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
-      const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+      const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
       const f32x4 g4 = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
       const f32x4 yv = ldx4<YE>(y, m * C + rp.c);
 #pragma unroll
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
   float ds = 1.f;
   if constexpr (DE == 2) ds = df_h2_scale(__builtin_bit_cast(float, *amax));
   const int C = dz.c, hw = dz.h * dz.w;
+  const int hws = df_pow2_shift(hw);
   const RowPart rp = row_part(C);
   const void* __restrict__ dzp = dz.ptr;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
     const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
     const f32x4 c1 = ld4(coef + ((int64_t)g * 2 + 0) * C + rp.c), c2 = ld4(coef + ((int64_t)g * 2 + 1) * C + rp.c);
     for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
-      const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+      const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
       const f32x4 g4 = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
       const f32x4 yv = ldx4<YE>(y, m * C + rp.c);
       f32x4 o;
@@ -522,13 +526,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(df_img x, float* __
                                                              int64_t rows_per_blk) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4];
   const int C = x.c, hw = x.h * x.w;
+  const int hws = df_pow2_shift(hw);
   const RowPart rp = row_part(C);
   const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
   const int64_t r_end = min(r_begin + rows_per_blk, rows);
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
   for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
-    const int n = (int)(m / hw), pix = (int)(m - (int64_t)n * hw);
+    const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
     acc[0] += ld4(xp + df_img_base(x, n) + (int64_t)pix * x.ld + rp.c);
   }
   block_reduce_rows<1>(acc, rp, lds);
@@ -585,13 +590,14 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
   float ys = 1.f;
   if constexpr (YE == 2) ys = df_h2_scale(*y_bound);      // pre-split output (the upsampled half of an h2 concatenation)
   const int C4 = y.c >> 2;
+  const int c4s = df_pow2_shift(C4), yws = df_pow2_shift(y.w), yhs = df_pow2_shift(y.h);
   const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t m = i / C4;
+    int64_t m = df_udiv(i, C4, c4s);
     const int c = (int)(i - m * C4) * 4;
-    const int X = (int)(m % y.w);
-    m /= y.w;
-    const int Y = (int)(m % y.h), n = (int)(m / y.h);
+    const int64_t mw = df_udiv(m, y.w, yws);
+    const int X = (int)(m - mw * y.w);
+    const int n = (int)df_udiv(mw, y.h, yhs), Y = (int)(mw - (int64_t)n * y.h);
     const Lerp ly = lerp_src(Y, x.h, y.h, align_corners), lx = lerp_src(X, x.w, y.w, align_corners);
     const float* b = xp + df_img_base(x, n) + c;
     const f32x4 v00 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld), v01 = ld4(b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld);
@@ -631,14 +637,15 @@ __global__ __launch_bounds__(256) void upsample2x_bf16_kernel(df_img x, df_img y
 // gather form of the transpose: every input pixel sums the <= 6x6 output pixels that read it
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(df_img dy, df_img dx, int align_corners, int64_t total4) {
   const int C4 = dx.c >> 2;
+  const int c4s = df_pow2_shift(C4), xws = df_pow2_shift(dx.w), xhs = df_pow2_shift(dx.h);
   const float* __restrict__ dyp = reinterpret_cast<const float*>(dy.ptr);
   float* __restrict__ dxp = reinterpret_cast<float*>(dx.ptr);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t m = i / C4;
+    int64_t m = df_udiv(i, C4, c4s);
     const int c = (int)(i - m * C4) * 4;
-    const int xx = (int)(m % dx.w);
-    m /= dx.w;
-    const int yy = (int)(m % dx.h), n = (int)(m / dx.h);
+    const int64_t mw = df_udiv(m, dx.w, xws);
+    const int xx = (int)(m - mw * dx.w);
+    const int n = (int)df_udiv(mw, dx.h, xhs), yy = (int)(mw - (int64_t)n * dx.h);
     float wy[6], wx[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
