@@ -38,6 +38,13 @@ ds = HDF5Dataset(root)
 ds.data_index = ds.data_index * (2 if os.environ.get("DF_LOADER_QUICK") == "1" else 4)   # 640 pairs = 40 steps per epoch: steady state, not worker start-up (quick: 20 steps)
 QUICK = os.environ.get("DF_LOADER_QUICK") == "1"        # bench.py's `loader_fed` extra: one worker count, one JSON line at the end
 results = {}
+if QUICK:      # on a fresh box the reader processes' first imports and file maps page in slowly (measured inside bench.py: 180 loader-fed
+    # against 204 resident pairs/s on the first touch, 204.7 / 204.8 on the second): one short untimed pass with the same readers first
+    for k, b in enumerate(SceneLoader(ds, 16, ShardedSampler(len(ds), shuffle=True, seed=0), device=dev, num_workers=4, prefetch=3)):
+        tr.step(b)
+        if k == 7:
+            break
+    torch.cuda.synchronize()
 for workers in ((4,) if QUICK else (4, 8, 16, 28) if DTYPE == "bf16" else (0, 4, 16)):
     sampler = ShardedSampler(len(ds), shuffle=True, seed=1)
     n, t0 = 0, None
