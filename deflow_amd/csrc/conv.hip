@@ -2288,10 +2288,14 @@ __global__ __launch_bounds__(768) void wgrad3_tr_kernel(WgradParams p) {
   }
   const int ldst0 = op0_y ? wave * 1024 : YB + (wave - NYO) * 1024;
   const int ldst1 = YB + (wave + 12 - NYO) * 1024;
-  int cur_n, cur_oy, cur_seg;
+  int cur_n, cur_oy, cur_seg;      // column-major chunk order (see wgrad3_h2p_kernel): chunk -> (n, segment, oy), oy fastest
   {
-    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
-    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+    const int ch = c_begin < p.total_chunks ? c_begin : 0;
+    const int per_img = p.chunks_per_row * p.dy.h;
+    cur_n = ch / per_img;
+    const int rem = ch - cur_n * per_img;
+    cur_seg = rem / p.dy.h;
+    cur_oy = rem - cur_seg * p.dy.h;
   }
   unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 2);
   unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wx * p.x.ld) * 2);
@@ -2312,16 +2316,16 @@ __global__ __launch_bounds__(768) void wgrad3_tr_kernel(WgradParams p) {
       const bool ok = (unsigned)(cur_oy + lqy[1]) < (unsigned)hx && (unsigned)(ox0 + lpx[1]) < (unsigned)wx;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst1), 16, ok ? xbase + loff[1] : DMA_BAD, 0, 0, 0);
     }
-    if (++cur_seg == p.chunks_per_row) {
-      cur_seg = 0;
-      yrow += yrow_step;
-      xrow += xrow_step;
-      if (++cur_oy == p.dy.h) {   // next image: its base need not follow the previous one
-        cur_oy = 0;
+    yrow += yrow_step;
+    xrow += xrow_step;
+    if (++cur_oy == p.dy.h) {     // next column segment of the image, or the next image
+      cur_oy = 0;
+      if (++cur_seg == p.chunks_per_row) {
+        cur_seg = 0;
         ++cur_n;
-        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 2);
-        xrow = (unsigned)(df_img_base(p.x, cur_n) * 2);
       }
+      yrow = (unsigned)(df_img_base(p.dy, cur_n) * 2);
+      xrow = (unsigned)(df_img_base(p.x, cur_n) * 2);
     }
   };
 
@@ -2795,10 +2799,19 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
       loff[i] = (unsigned)((((qy - 1) * wx + xi - 1) * p.x.ld + ci0 + 32 * h) * 4 + pl * 64 + q * 16);
     }
   }
+  // COLUMN-MAJOR chunk order (round 4): chunk index -> (image n, segment seg, output row oy) with oy running fastest, so that
+  // consecutive stages of a workgroup read the x rows (oy - 1, oy, oy + 1), (oy, oy + 1, oy + 2), ...: two of the three rows of a stage
+  // were fetched one stage earlier and are still in L2.  Walking along the row first (the other weight-gradient kernels' order) put a
+  // whole row walk -- 16 stages x 35 KB x 32 workgroups per XCD -- between the three uses of a row: x came from HBM three times
+  // (FETCH_SIZE: 1.41 GB per launch against 0.88 GB of operands).  Only the order of the fp32 accumulation over pixels changes.
   int cur_n, cur_oy, cur_seg;
   {
-    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
-    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+    const int ch = c_begin < p.total_chunks ? c_begin : 0;
+    const int per_img = p.chunks_per_row * p.dy.h;
+    cur_n = ch / per_img;
+    const int rem = ch - cur_n * per_img;
+    cur_seg = rem / p.dy.h;
+    cur_oy = rem - cur_seg * p.dy.h;
   }
   unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
   unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wx * p.x.ld) * 4);
@@ -2818,16 +2831,16 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(slot + ldst[i]), 16, ok ? xbase + loff[i] : DMA_BAD, 0, 0, 0);
       }
     }
-    if (++cur_seg == p.chunks_per_row) {
-      cur_seg = 0;
-      yrow += yrow_step;
-      xrow += xrow_step;
-      if (++cur_oy == p.dy.h) {   // next image: its base need not follow the previous one
-        cur_oy = 0;
+    yrow += yrow_step;
+    xrow += xrow_step;
+    if (++cur_oy == p.dy.h) {     // next column segment of the image, or the next image (its base need not follow the previous one)
+      cur_oy = 0;
+      if (++cur_seg == p.chunks_per_row) {
+        cur_seg = 0;
         ++cur_n;
-        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
-        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
       }
+      yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+      xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
     }
   };
 

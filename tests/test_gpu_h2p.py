@@ -128,8 +128,8 @@ def test_conv_presplit_vs_float64(dev):
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 256, 256), (128, 128, 4, 128, 128), (256, 256, 8, 64, 64), (512, 256, 2, 128, 128)])
 def test_wgrad_presplit(dev, cin, cout, n, h, w):
     """wgrad3_h2p_kernel (both operands as planes, LDS-DMA ring): against float64 (<= 2e-6 of the largest entry), bias-gradient
-    column sums included; and bit-identical to round 3's wgrad3_x3_kernel<2> when both take the same bounds and the same split-K
-    count (the planes hold what the in-kernel split computes)."""
+    column sums included; and equal to round 3's wgrad3_x3_kernel<2> on the same bounds and split-K count up to the order of the fp32
+    sums (the planes hold what the in-kernel split computes; the traversal orders differ)."""
     from deflow_amd import ops
     from deflow_amd._lib import img, call
     g = torch.Generator().manual_seed(cin + h)
@@ -166,7 +166,12 @@ def test_wgrad_presplit(dev, cin, cout, n, h, w):
     call("df_conv2d_wgrad_h2", img(xd), img(dyd), ops.ptr(xb), ops.ptr(yb), 3, 1, 1, ops.ptr(ws0), splits, None, ops.stream())
     call("df_conv2d_wgrad_h2p", img(xh), img(dyh), ops.ptr(xb), ops.ptr(yb), 3, 1, 1, ops.ptr(ws1), splits, None, ops.stream())
     torch.cuda.synchronize()
-    assert torch.equal(ws0, ws1), float((ws0 - ws1).abs().max())
+    # (the two kernels walk the pixels in different orders since the pre-split one went column-major -- its x rows stay in L2 -- so a
+    # split holds different pixels: the planes being what the in-kernel split computes shows in the SUMS over the splits, which
+    # agree to the rounding of two fp32 summation orders)
+    s0 = ws0.view(splits, -1).double().sum(0)
+    s1 = ws1.view(splits, -1).double().sum(0)
+    assert float((s0 - s1).abs().max() / s0.abs().max()) <= 2e-6, float((s0 - s1).abs().max() / s0.abs().max())
 
 
 def test_bn_gelu_producers_write_planes_with_valid_bounds(dev):
