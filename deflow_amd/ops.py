@@ -435,7 +435,8 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             src._df_amax = (ya, ver(src))
     if ya is None and getattr(y, "_src", None) is not None:
         wrote(y._src)          # (an unmeasured write into a tensor that carried a bound)
-    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2) and x.c % 64 == 0
+    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2)
+           and x.c % (64 if os.environ.get("DF_CONV_H2F_C32", "1") == "0" else 32) == 0     # (32: the first encoder conv on the canvas: its bound comes from the pillar feature net's statistics)
            and getattr(x, "_amax", None) is not None and os.environ.get("DF_CONV_H2F", "1") != "0")
     fused_bn = False
     if (h2 and bwd_bn is not None and mode == CONV_DGRAD and y.elt == 0 and not accumulate and bias is None and y.ld == y.c
