@@ -23,8 +23,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
   void* ub = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
   return __builtin_amdgcn_make_buffer_rsrc(ub, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+// DF_BUF_ST_AUX (compile time; A/B through build.build_variant): cache policy of the plane stores -- 0 default, 2 = nt (streaming)
+#ifndef DF_BUF_ST_AUX
+#define DF_BUF_ST_AUX 0
+#endif
 __device__ __forceinline__ void buf_st4(rsrc_t r, unsigned voff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, DF_BUF_ST_AUX);
 }
 __device__ __forceinline__ void buf_st1(rsrc_t r, unsigned voff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
