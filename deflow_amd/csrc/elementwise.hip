@@ -324,6 +324,38 @@ __global__ __launch_bounds__(256) void bn_gelu_apply_kernel(const void* __restri
     if (amax) df_block_amax(mf, amax);      // max |z| for the fp16x2 convolution that reads z next (uniform branch)
 }
 
+// the plane PRODUCER form with eight channels per thread (round 4; DF_BN_X8=0: four): one 16-byte store per plane instead of two
+// 8-byte ones per four channels -- the h2 line of a 32-channel chunk is then written by four lanes x 2 stores instead of eight x 2
+typedef _Float16 f16x8e_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void bn_gelu_apply8_kernel(const float* __restrict__ y, const float* __restrict__ bn_ss, int imgs_per_group,
+                                                             df_img z, int64_t total8, const unsigned* __restrict__ bound) {
+  const int C8 = z.c >> 3;
+  const int hw = z.h * z.w;
+  const int c8s = df_pow2_shift(C8), hws = df_pow2_shift(hw);
+  const float zs = df_h2_scale(__builtin_bit_cast(float, *bound));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = df_udiv(i, C8, c8s);
+    const int c = (int)(i - m * C8) * 8;
+    const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
+    const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
+    const f32x4 v0 = ld4(y + m * z.c + c), v1 = ld4(y + m * z.c + c + 4);
+    const f32x4 sc0 = ld4(ss + c), sc1 = ld4(ss + c + 4), sh0 = ld4(ss + z.c + c), sh1 = ld4(ss + z.c + c + 4);
+    f16x8e_t hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t0 = df_gelu(v0[k] * sc0[k] + sh0[k]) * zs, t1 = df_gelu(v1[k] * sc1[k] + sh1[k]) * zs;
+      hi[k] = (_Float16)t0;
+      lo[k] = (_Float16)((t0 - (float)hi[k]) * 2048.f);
+      hi[4 + k] = (_Float16)t1;
+      lo[4 + k] = (_Float16)((t1 - (float)hi[4 + k]) * 2048.f);
+    }
+    const int64_t idx = df_img_base(z, n) + (int64_t)pix * z.ld + c;
+    char* b = reinterpret_cast<char*>(z.ptr) + (idx & ~31ll) * 4 + (idx & 31) * 2;
+    *reinterpret_cast<f16x8e_t*>(b) = hi;
+    *reinterpret_cast<f16x8e_t*>(b + 64) = lo;
+  }
+}
+
 // block layout shared by the row-partitioned channel reductions: C/4 channel lanes x 256/(C/4) row lanes
 struct RowPart {
   int c, row_lane, row_lanes;
@@ -737,7 +769,11 @@ extern "C" int df_bn_gelu_apply_t(const void* y, int y_elt, const float* bn_ss, 
   const int64_t total4 = (int64_t)z.n * z.h * z.w * (z.c / 4);
   const dim3 grid(grid_for(total4));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (z.elt == 2) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 2>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
+  static const int x8 = getenv("DF_BN_X8") ? atoi(getenv("DF_BN_X8")) : 1;
+  if (z.elt == 2 && x8 && (z.c % 8) == 0)
+    hipLaunchKernelGGL(bn_gelu_apply8_kernel, dim3(grid_for(total4 / 2)), dim3(256), 0, s, reinterpret_cast<const float*>(y), bn_ss, imgs_per_group, z,
+                       total4 / 2, amax);
+  else if (z.elt == 2) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 2>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else if (y_elt == 0 && z.elt == 0) hipLaunchKernelGGL((bn_gelu_apply_kernel<0, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else if (y_elt == 1 && z.elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 1>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
   else if (y_elt == 1) hipLaunchKernelGGL((bn_gelu_apply_kernel<1, 0>), grid, dim3(256), 0, s, y, bn_ss, imgs_per_group, z, total4, amax);
