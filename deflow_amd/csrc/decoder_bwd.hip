@@ -533,6 +533,73 @@ extern "C" int df_gru_decoder_bwd_mp(const float* dflow, const float* offs, cons
   return DF_OK;
 }
 
+// Batched form (round 4, second session).  The kernel above walks its cells one at a time through FOUR dependent global round
+// trips each (cell range -> point index -> compact position -> dh0 row): 0.74 ms per step at B = 16 for 2.8 GB.  Here a lane
+// group (32 lanes: `before` | `after` halves, or 16 lanes when only d(after) is wanted) takes U cells per pass with all their
+// ranges, then all their j-th indices, positions and rows in flight together (buffer loads: an inactive slot's offset is out of
+// range and reads 0 -- no branches, no waits at merges); per cell the rows are added in the order of the kernel above
+// (bit-identical).
+template <int U, bool BOTH>
+__global__ __launch_bounds__(256) void gather_bwd_batched_kernel(const float* __restrict__ dh0,
+                                                                 const uint32_t* __restrict__ idx_sorted,
+                                                                 const int32_t* __restrict__ cell_rng,
+                                                                 const int32_t* __restrict__ cpos, int N, int ncell, int BN,
+                                                                 df_img dbefore, df_img dafter, int acc_before, int acc_after) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int LPC = BOTH ? 32 : 16, CPP = 256 / LPC;      // lanes per cell, cells per pass of the workgroup
+  const int b = blockIdx.y, sub = threadIdx.x & (LPC - 1), grp = threadIdx.x / LPC;
+  const bool is_after = !BOTH || sub >= 16;
+  const df_img& im = is_after ? dafter : dbefore;
+  float* __restrict__ op = reinterpret_cast<float*>(im.ptr) + df_img_base(im, b) + (sub & 15) * 4;
+  const int ld = im.ld;
+  const bool acc = is_after ? acc_after != 0 : acc_before != 0;
+  constexpr unsigned OOB = 0xF0000000u;
+  const __amdgpu_buffer_rsrc_t rng_r = __builtin_amdgcn_make_buffer_rsrc((void*)(cell_rng + 2 * (int64_t)b * ncell), 0, (unsigned)ncell * 8u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t idx_r = __builtin_amdgcn_make_buffer_rsrc((void*)idx_sorted, 0, (unsigned)BN * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t cpos_r = __builtin_amdgcn_make_buffer_rsrc((void*)cpos, 0, (unsigned)BN * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dh_r = __builtin_amdgcn_make_buffer_rsrc((void*)(dh0 + (int64_t)b * N * 128), 0, (unsigned)N * 512u, 0x00020000);
+  const unsigned col = BOTH ? (unsigned)sub * 16u : 256u + (unsigned)sub * 16u;   // byte offset inside a dh0 row
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  for (int cell0 = blockIdx.x * CPP * U; cell0 < ncell; cell0 += gridDim.x * CPP * U) {
+    int s[U], len[U];
+    f32x4 a[U];
+    int maxlen = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cell = cell0 + grp + CPP * u;
+      const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rng_r, cell < ncell ? (unsigned)cell * 8u : OOB, 0, 0);
+      s[u] = (int)r[0];
+      len[u] = (int)r[1] - (int)r[0];
+      a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) maxlen = max(maxlen, len[u]);
+    for (int j = 0; __any(j < maxlen); ++j) {
+      unsigned flat[U], cp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) flat[u] = __builtin_amdgcn_raw_buffer_load_b32(idx_r, j < len[u] ? (unsigned)(s[u] + j) * 4u : OOB, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) cp[u] = __builtin_amdgcn_raw_buffer_load_b32(cpos_r, j < len[u] ? flat[u] * 4u : OOB, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        a[u] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dh_r, j < len[u] ? cp[u] * 512u + col : OOB, 0, 0));
+    }
+    if (acc) {   // (not the engine's case: both images are written fresh there)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cell = cell0 + grp + CPP * u;
+        if (cell < ncell) a[u] += ld4(op + (int64_t)cell * ld);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cell = cell0 + grp + CPP * u;
+      if (cell < ncell) st4(op + (int64_t)cell * ld, a[u]);
+    }
+  }
+#endif
+}
+
 extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
                              int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
                              int nblk, void* stream) {
@@ -541,6 +608,23 @@ extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const
   if (dbefore.ptr)
     DF_REQUIRE(dbefore.n == B && dbefore.c == 64 && dbefore.h == dafter.h && dbefore.w == dafter.w && (dbefore.ld % 4) == 0,
                DF_E_SHAPE);
+  static const int batched = getenv("DF_GATHER_BWD_V1") ? 0 : 1;   // A/B: the one-cell-at-a-time kernel
+  const int64_t ncell = (int64_t)dafter.h * dafter.w;
+  if (batched && (int64_t)B * N < (1 << 29) && ncell < (1 << 28)) {   // (32-bit byte offsets of the buffer loads)
+    constexpr int U = 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dbefore.ptr) {
+      const int nb = (int)min((int64_t)8192, (ncell + 8 * U - 1) / (8 * U));
+      hipLaunchKernelGGL((gather_bwd_batched_kernel<U, true>), dim3(nb, B), dim3(256), 0, st, dh0, idx_sorted, cell_rng, cpos, N,
+                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after);
+    } else {
+      const int nb = (int)min((int64_t)8192, (ncell + 16 * U - 1) / (16 * U));
+      hipLaunchKernelGGL((gather_bwd_batched_kernel<U, false>), dim3(nb, B), dim3(256), 0, st, dh0, idx_sorted, cell_rng, cpos, N,
+                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after);
+    }
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(nblk, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dh0,
                      idx_sorted, cell_rng, cpos, N, dafter.h * dafter.w, dbefore, dafter, accumulate_before,
                      accumulate_after);

@@ -419,15 +419,26 @@ struct SparseWgradParams {
   float* bias_ws;   // [gridDim.y * gridDim.x][64] or nullptr
 };
 
+// Round 4 (second session): the kernel was neither matrix- nor bandwidth-bound (62 GFLOP at 53 TFLOP/s, the fp32 matrix pipe 40 %
+// busy): a wave issued the 32 loads of a 16-pixel step, waited for them, then issued its 64 MFMAs, and a 64-point window holds
+// ~35 pillars -- three steps with the last one a third full.  Now a window is 256 points (four ballots: ~140 pillars, nine
+// steps, the last one wasted on average half a step instead of a third of every third), and the loads of step s + 1 are
+// issued BEFORE the MFMAs of step s (two register sets, the loop unrolled by two): load latency rides under ~2000 matrix cycles.
+constexpr int SW_WIN = 256;   // sorted points per window
+
 __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams p) {
-  __shared__ int Plist[9 * 64];
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass
+  __shared__ int Plist[9 * SW_WIN];
   const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y, ncell = p.H * p.W;
   const int ty = tap / 3 - 1, tx = tap % 3 - 1;
-  int* plist = Plist + tap * 64;
+  int* plist = Plist + tap * SW_WIN;
   const float* dy = reinterpret_cast<const float*>(p.dy.ptr) + df_img_base(p.dy, b);
   const float* xp = reinterpret_cast<const float*>(p.x.ptr) + df_img_base(p.x, b);
+  // one sample's image is far below 4 GB (the C entry checks it): byte offsets fit the buffer instructions' 32 bits
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)((int64_t)ncell * p.dy.ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (unsigned)((int64_t)ncell * p.x.ld * 4), 0x00020000);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -436,18 +447,32 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const SampleRange sr = sample_range(p.counts, b);
   const int end = sr.off + sr.cnt;
-  for (int base = sr.off + blockIdx.x * 64; base < end; base += gridDim.x * 64) {
-    const int i = base + lane;
-    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
-    const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
-    const unsigned long long m = __ballot(head);
-    const int n = (int)__popcll(m);
-    if (head) plist[__popcll(m & ((1ull << lane) - 1))] = (int)(key - (uint32_t)b * (uint32_t)ncell);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int base = sr.off + blockIdx.x * SW_WIN; base < end; base += gridDim.x * SW_WIN) {
+    const int wend = min(end, base + SW_WIN);
+    uint32_t key[SW_WIN / 64], prev[SW_WIN / 64];
+#pragma unroll
+    for (int w = 0; w < SW_WIN / 64; ++w) {   // all key loads of the window in flight together
+      const int i = base + 64 * w + lane;
+      key[w] = i < wend ? p.key_sorted[i] : 0xffffffffu;
+      prev[w] = (i < wend && i > sr.off) ? p.key_sorted[i - 1] : 0xfffffffeu;
+    }
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < SW_WIN / 64; ++w) {
+      const int i = base + 64 * w + lane;
+      const bool head = i < wend && (i == sr.off || prev[w] != key[w]);
+      const unsigned long long m = __ballot(head);
+      if (head) plist[n + (int)__popcll(m & lt)] = (int)(key[w] - (uint32_t)b * (uint32_t)ncell);
+      n += (int)__popcll(m);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int s0 = 0; s0 < n; s0 += 16) {   // 16 pixels = four MFMA k steps; all 32 loads are issued before the 64 MFMAs
-      float a[4][4], bv[4][4];
+    // one step = 16 pixels = four MFMA k steps: 32 loads, 64 MFMAs
+    // branch-free: buffer loads whose offset is out of range for a missing pixel / a tap outside the image return 0 (a
+    // conditional load compiles to a branch per load and a wait where its value merges with the 0)
+    auto load_step = [&](int s0, float (&a)[4][4], float (&bv)[4][4]) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = s0 + 4 * u + lq;
@@ -455,14 +480,16 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
         const int y = cell / p.W, x = cell - y * p.W;
         const int qy = y + ty, qx = x + tx;
         const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
-        const float* ar = dy + (int64_t)(cell < 0 ? 0 : cell) * p.dy.ld + li;
-        const float* br = xp + (int64_t)(okq ? qy * p.W + qx : 0) * p.x.ld + li;
+        const unsigned ao = cell >= 0 ? (unsigned)((cell * p.dy.ld + li) * 4) : 0xF0000000u;
+        const unsigned bo = okq ? (unsigned)(((qy * p.W + qx) * p.x.ld + li) * 4) : 0xF0000000u;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          a[u][t] = cell >= 0 ? ar[16 * t] : 0.f;
-          bv[u][t] = okq ? br[16 * t] : 0.f;
+          a[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, ao, 64 * t, 0));
+          bv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, bo, 64 * t, 0));
         }
       }
+    };
+    auto mma_step = [&](const float (&a)[4][4], const float (&bv)[4][4]) {
       if (tap == 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -476,6 +503,17 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
             acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ct], bv[u][nt], acc[ct][nt], 0, 0, 0);
+    };
+    float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
+    if (n > 0) load_step(0, a0, b0);
+    for (int s0 = 0; s0 < n; s0 += 32) {
+      const bool more1 = s0 + 16 < n;
+      if (more1) load_step(s0 + 16, a1, b1);
+      mma_step(a0, b0);
+      if (more1) {
+        if (s0 + 32 < n) load_step(s0 + 32, a0, b0);
+        mma_step(a1, b1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -498,6 +536,7 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
       if (lq == 0) p.bias_ws[blk * 64 + 16 * t + li] = v;
     }
   }
+#endif
 }
 
 
@@ -955,6 +994,7 @@ extern "C" int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* cou
   DF_REQUIRE(x.n == B && dy.n == B && x.c == 64 && dy.c == 64 && x.h == dy.h && x.w == dy.w && x.grp_size == x.n &&
                  dy.grp_size == dy.n,
              DF_E_SHAPE);
+  DF_REQUIRE((int64_t)dy.h * dy.w * dy.ld < (int64_t)0x30000000 && (int64_t)x.h * x.w * x.ld < (int64_t)0x30000000, DF_E_SHAPE);   // 32-bit byte offsets
   SparseWgradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.H = dy.h; p.W = dy.w; p.dy = dy; p.x = x; p.ws = ws; p.bias_ws = bias_ws;
   hipLaunchKernelGGL(sparse_wgrad3x3_kernel, dim3(nblk, B), dim3(576), 0, reinterpret_cast<hipStream_t>(stream), p);
