@@ -302,6 +302,7 @@ struct PillarGradParams {
 };
 
 __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W1s = lds;                       // [9][64][32]
   float* W3s = W1s + 9 * 64 * 32;         // [64][32]
@@ -340,10 +341,7 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   // acc[nt] += A_row(li)[16 lq .. 16 lq + 15] x Ws[(16 lq + s) * 32 + 16 nt + li], s = 0..15
-  auto mma_row = [&](const float* src /* this lane's cell row, or nullptr */, const float* Ws, f32x4 (&acc)[2]) {
-    f32x4 a4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a4[k] = src ? ld4(src + 16 * lq + 4 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma_row = [&](const f32x4 (&a4)[4], const float* Ws, f32x4 (&acc)[2]) {
     const float* wl = Ws + 16 * lq * 32 + li;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -351,6 +349,16 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[s * 32], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wl[s * 32 + 16], acc[1], 0, 0, 0);
     }
+  };
+  // (round 4, second session) the rows of a batch -- the skip gradient and the one to four reachable taps of dy1 -- are fetched
+  // TOGETHER with branch-free buffer loads (a missing row's offset is out of range and reads 0) and multiplied as they land; before,
+  // each row was a load round trip in front of its 32 MFMAs
+  constexpr unsigned OOB = 0xF0000000u;
+  const __amdgpu_buffer_rsrc_t dskr = __builtin_amdgcn_make_buffer_rsrc((void*)dsk, 0, (unsigned)(((int64_t)(ncell - 1) * p.dskip.ld + 64) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)dy1, 0, (unsigned)((int64_t)h2 * w2 * 64 * 4), 0x00020000);
+  auto fetch_row = [&](__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 (&a4)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 16 * k, 0));
   };
 
   for (int base = sr.off + (blockIdx.x * (PG_THREADS / 64) + wave) * 64; base < end; base += gridDim.x * (PG_THREADS / 64) * 64) {
@@ -378,14 +386,24 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
         lds_fence();
         const int y = cell / p.W, x = cell - y * p.W;
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        mma_row(cell >= 0 ? dsk + (int64_t)cell * p.dskip.ld : nullptr, W3s, acc);
-        for (int iy = 0; iy < nky; ++iy)
-          for (int ix = 0; ix < nkx; ++ix) {
+        f32x4 a_sk[4], a_t[4][4];
+        fetch_row(dskr, cell >= 0 ? (unsigned)((cell * p.dskip.ld + 16 * lq) * 4) : OOB, a_sk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // tap t = (iy, ix) = (t >> 1, t & 1); taps beyond (nky, nkx) are not fetched
+          const int iy = t >> 1, ix = t & 1;
+          if (iy < nky && ix < nkx) {
             const int ky = ky0 + 2 * iy, kx = kx0 + 2 * ix;
             const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
             const bool ok = cell >= 0 && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
-            mma_row(ok ? dy1 + ((int64_t)oy * w2 + ox) * 64 : nullptr, W1s + (ky * 3 + kx) * 64 * 32, acc);
+            fetch_row(dyr, ok ? (unsigned)(((oy * w2 + ox) * 64 + 16 * lq) * 4) : OOB, a_t[t]);
           }
+        }
+        mma_row(a_sk, W3s, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // the same tap order as before: (iy, ix) ascending
+          const int iy = t >> 1, ix = t & 1;
+          if (iy < nky && ix < nkx) mma_row(a_t[t], W1s + ((ky0 + 2 * iy) * 3 + kx0 + 2 * ix) * 64 * 32, acc);
+        }
         // C layout: acc[nt][r] = row 4 lq + r, channel 16 nt + li
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
       }
     }
   }
+#endif
 }
 
 
@@ -676,15 +695,23 @@ struct SparseInWgradParams {
   float* ws;          // [gridDim.y * gridDim.x][64][9][32]
 };
 
+// (Round 4, second session: windows of 512 sorted points -- a tap keeps about a quarter of a window's pillar heads, ~9 of a
+// 64-point window: one or two 8-cell steps, each a load round trip in front of 16 MFMAs -- 16-cell steps whose loads are issued a
+// step ahead of the MFMAs, branch-free buffer loads; as sparse_wgrad3x3_kernel above.)
+constexpr int SIW_WIN = 512;
+
 __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParams p) {
-  __shared__ int Plist[9 * 64];
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass
+  __shared__ int Plist[9 * SIW_WIN];
   const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int b = blockIdx.y, ncell = p.H * p.W, h2 = p.H >> 1, w2 = p.W >> 1;
   const int ky = tap / 3, kx = tap % 3;
-  int* plist = Plist + tap * 64;
+  int* plist = Plist + tap * SIW_WIN;
   const float* dy1 = p.dy1 + (int64_t)(p.cloud * p.B + b) * h2 * w2 * 64;
   const float* cv = reinterpret_cast<const float*>(p.canvas.ptr) + df_img_base(p.canvas, b);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)dy1, 0, (unsigned)((int64_t)h2 * w2 * 64 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t cvr = __builtin_amdgcn_make_buffer_rsrc((void*)cv, 0, (unsigned)(((int64_t)(ncell - 1) * p.canvas.ld + 32) * 4), 0x00020000);
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -692,41 +719,66 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const SampleRange sr = sample_range(p.counts, b);
   const int end = sr.off + sr.cnt;
-  for (int base = sr.off + blockIdx.x * 64; base < end; base += gridDim.x * 64) {
-    const int i = base + lane;
-    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
-    const int cell = (int)(key - (uint32_t)b * (uint32_t)ncell);
-    const int y = cell / p.W, x = cell - y * p.W;
-    const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
-    const bool mine = i < end && (i == sr.off || p.key_sorted[i - 1] != key) && (((y + 1 - ky) & 1) == 0) &&
-                      (((x + 1 - kx) & 1) == 0) && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
-    const unsigned long long m = __ballot(mine);
-    const int n = (int)__popcll(m);
-    if (mine) plist[__popcll(m & ((1ull << lane) - 1))] = cell;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int base = sr.off + blockIdx.x * SIW_WIN; base < end; base += gridDim.x * SIW_WIN) {
+    const int wend = min(end, base + SIW_WIN);
+    uint32_t key[SIW_WIN / 64], prev[SIW_WIN / 64];
+#pragma unroll
+    for (int w = 0; w < SIW_WIN / 64; ++w) {
+      const int i = base + 64 * w + lane;
+      key[w] = i < wend ? p.key_sorted[i] : 0xffffffffu;
+      prev[w] = (i < wend && i > sr.off) ? p.key_sorted[i - 1] : 0xfffffffeu;
+    }
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < SIW_WIN / 64; ++w) {
+      const int i = base + 64 * w + lane;
+      const int cell = (int)(key[w] - (uint32_t)b * (uint32_t)ncell);
+      const int y = cell / p.W, x = cell - y * p.W;
+      const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
+      const bool mine = i < wend && (i == sr.off || prev[w] != key[w]) && (((y + 1 - ky) & 1) == 0) &&
+                        (((x + 1 - kx) & 1) == 0) && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
+      const unsigned long long m = __ballot(mine);
+      if (mine) plist[n + (int)__popcll(m & lt)] = cell;
+      n += (int)__popcll(m);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int s0 = 0; s0 < n; s0 += 8) {   // 8 cells = two MFMA k steps
-      float a[2][4], bv[2][2];
+    // one step = 16 cells = four MFMA k steps: 24 loads, 32 MFMAs
+    auto load_step = [&](int s0, float (&a)[4][4], float (&bv)[4][2]) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const int k = s0 + 4 * u + lq;
         const int c2 = k < n ? plist[k] : -1;
         const int y2 = c2 / p.W, x2 = c2 - y2 * p.W;
-        const float* ar = dy1 + ((int64_t)((y2 + 1 - ky) >> 1) * w2 + ((x2 + 1 - kx) >> 1)) * 64 + li;
-        const float* br = cv + (int64_t)c2 * p.canvas.ld + li;
+        const unsigned ao = c2 >= 0 ? (unsigned)(((((y2 + 1 - ky) >> 1) * w2 + ((x2 + 1 - kx) >> 1)) * 64 + li) * 4) : 0xF0000000u;
+        const unsigned bo = c2 >= 0 ? (unsigned)((c2 * p.canvas.ld + li) * 4) : 0xF0000000u;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[u][t] = c2 >= 0 ? ar[16 * t] : 0.f;
+        for (int t = 0; t < 4; ++t) a[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, ao, 64 * t, 0));
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bv[u][t] = c2 >= 0 ? br[16 * t] : 0.f;
+        for (int t = 0; t < 2; ++t) bv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 64 * t, 0));
       }
+    };
+    auto mma_step = [&](const float (&a)[4][4], const float (&bv)[4][2]) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ct], bv[u][nt], acc[ct][nt], 0, 0, 0);
+    };
+    float a0[4][4], b0[4][2], a1[4][4], b1[4][2];
+    if (n > 0) load_step(0, a0, b0);
+    for (int s0 = 0; s0 < n; s0 += 32) {
+      const bool more1 = s0 + 16 < n;
+      if (more1) load_step(s0 + 16, a1, b1);
+      mma_step(a0, b0);
+      if (more1) {
+        if (s0 + 32 < n) load_step(s0 + 32, a0, b0);
+        mma_step(a1, b1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -739,6 +791,7 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[((16 * ct + 4 * lq + r) * 9 + tap) * 32 + 16 * nt + li] = acc[ct][nt][r];
+#endif
 }
 
 // ---------------------------------------------------------------------------- cell sort -------------
@@ -975,7 +1028,8 @@ extern "C" int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* c
   DF_REQUIRE(key_sorted && counts && dy1 && w1 && dskip.ptr && w3 && dcanvas.ptr && B > 0 && nblk > 0 && (cloud == 0 || cloud == 1),
              DF_E_ARG);
   DF_REQUIRE((H % 2) == 0 && (W % 2) == 0 && dskip.n == B && dskip.h == H && dskip.w == W && dskip.c == 64 && (dskip.ld % 2) == 0 &&
-                 dcanvas.n == B && dcanvas.h == H && dcanvas.w == W && dcanvas.c == 32,
+                 dcanvas.n == B && dcanvas.h == H && dcanvas.w == W && dcanvas.c == 32 &&
+                 (int64_t)H * W * dskip.ld < (int64_t)0x30000000,   // 32-bit byte offsets inside one sample (buffer loads)
              DF_E_SHAPE);
   PillarGradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.accumulate = accumulate;
@@ -1022,6 +1076,7 @@ extern "C" int df_sparse_in_wgrad(const uint32_t* key_sorted, const int32_t* cou
                                   const float* dy1, df_img canvas, float* ws, int nblk, void* stream) {
   DF_REQUIRE(key_sorted && counts && dy1 && canvas.ptr && ws && B > 0 && nblk > 0 && (cloud == 0 || cloud == 1), DF_E_ARG);
   DF_REQUIRE((H % 2) == 0 && (W % 2) == 0 && canvas.n == B && canvas.h == H && canvas.w == W && canvas.c == 32, DF_E_SHAPE);
+  DF_REQUIRE((int64_t)H * W * canvas.ld < (int64_t)0x30000000, DF_E_SHAPE);   // 32-bit byte offsets inside one sample
   SparseInWgradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.dy1 = dy1; p.canvas = canvas;
   p.ws = ws;
