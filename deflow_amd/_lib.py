@@ -111,6 +111,7 @@ _SIGS = {
     "df_conv2d_wgrad_splits": [DfImg, DfImg, I, I],
     "df_conv2d_wgrad": [DfImg, DfImg, I, I, I, P, I, P, I, P, P],
     "df_conv2d_wgrad_reduce": [P, I, I, I, I, P, L, I, P],
+    "df_conv2d_wgrad_reduce_bias": [P, I, I, I, I, P, L, I, P, P, P],
     "df_upsample2x": [DfImg, DfImg, I, P],
     "df_upsample2x_bwd": [DfImg, DfImg, I, P],
     "df_gru_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P],

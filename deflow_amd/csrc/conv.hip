@@ -3402,6 +3402,51 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, in
   *o = accumulate ? (*o + s) : s;
 }
 
+// ... and the bias partials of the same split-K pass in the SAME launch (round 4, second session: a conv layer's weight gradient
+// was followed by wgrad_reduce + colsum_finalize, two 5-25 us launches; 33 of each per step).  Blocks [0, nblk_w) reduce the weight
+// partials exactly as above; the blocks behind them sum bias_ws [splits][cout] over the splits in double (32 columns x 8 split lanes each).
+__global__ void wgrad_reduce_bias_kernel(const float* __restrict__ ws, int splits, int64_t per_split, int row_len,
+                                         float* __restrict__ dw, int64_t ld_co, int accumulate, int nblk_w,
+                                         const float* __restrict__ bias_ws, int cout, float* __restrict__ db) {
+  if ((int)blockIdx.x >= nblk_w) {   // 32 columns x 8 split lanes per block (256 threads), as colsum_finalize_kernel
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - nblk_w) * 32 + cl;
+    double s = 0.0;
+    if (c < cout) {
+      int k = tl;
+      for (; k + 24 < splits; k += 32) {   // four loads in flight
+        const float v0 = bias_ws[(int64_t)k * cout + c], v1 = bias_ws[(int64_t)(k + 8) * cout + c];
+        const float v2 = bias_ws[(int64_t)(k + 16) * cout + c], v3 = bias_ws[(int64_t)(k + 24) * cout + c];
+        s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+      }
+      for (; k < splits; k += 8) s += (double)bias_ws[(int64_t)k * cout + c];
+    }
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0 && c < cout) {
+      for (int j = 1; j < 8; ++j) s += red[j][cl];
+      db[c] = (float)s;
+    }
+    return;
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_split) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= splits; k += 4) {
+    s0 += ws[(int64_t)k * per_split + i];
+    s1 += ws[(int64_t)(k + 1) * per_split + i];
+    s2 += ws[(int64_t)(k + 2) * per_split + i];
+    s3 += ws[(int64_t)(k + 3) * per_split + i];
+  }
+  for (; k < splits; ++k) s0 += ws[(int64_t)k * per_split + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int64_t co = i / row_len, r = i - co * row_len;
+  float* o = dw + co * ld_co + r;
+  *o = accumulate ? (*o + s) : s;
+}
+
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int taps,
                                         int cin) {
   // wt[ci][t][co] = w[co][t][ci]; one thread per output element (co fastest => coalesced writes)
@@ -4151,6 +4196,17 @@ extern "C" int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int
   const int64_t per = (int64_t)cout * taps * cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), ws, splits, per, taps * cin, dw, ld_co, accumulate);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_conv2d_wgrad_reduce_bias(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
+                                           int accumulate, const float* bias_ws, float* db, void* stream) {
+  DF_REQUIRE(ws && dw && bias_ws && db && splits >= 1 && cout >= 1, DF_E_ARG);
+  const int64_t per = (int64_t)cout * taps * cin;
+  const int nblk_w = (int)((per + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_bias_kernel, dim3((unsigned)(nblk_w + (cout + 31) / 32)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), ws, splits, per, taps * cin, dw, ld_co, accumulate, nblk_w, bias_ws, cout, db);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

@@ -755,6 +755,11 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fbh'[x.elt]}{'fbh'[dy.elt]}"
         prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
+    if want_bias and os.environ.get("DF_FUSE_REDUCE", "1") != "0":   # weight + bias partials in one launch
+        db = _f32(dy.c, device=dev)
+        call("df_conv2d_wgrad_reduce_bias", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
+             taps * x.c if ld_co is None else ld_co, int(accumulate), ptr(bias_ws), ptr(db), stream())
+        return db
     call("df_conv2d_wgrad_reduce", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,
          taps * x.c if ld_co is None else ld_co, int(accumulate), stream())
     if want_bias:

@@ -484,9 +484,8 @@ class FastFlow3DUNet(nn.Module):
             call("df_sparse_wgrad3x3", ptr(dv_cells.key_sorted), ptr(dv_cells.counts), B, img(xu), img(dv), ptr(ws), ptr(bws),
                  nblk, stream())
             dw4 = torch.empty_like(w4)
-            call("df_conv2d_wgrad_reduce", ptr(ws), nblk * B, 64, 9, 64, ptr(dw4), 9 * 64, 0, stream())
             db4 = torch.empty(64, **f32)
-            call("df_colsum_finalize", ptr(bws), nblk * B, 64, 1, ptr(db4), 0, stream())
+            call("df_conv2d_wgrad_reduce_bias", ptr(ws), nblk * B, 64, 9, 64, ptr(dw4), 9 * 64, 0, ptr(bws), ptr(db4), stream())
             grads[m.weight] = dw4.permute(0, 3, 1, 2)
             grads[m.bias] = db4
         # decoder_step3: a = T, b = bstar

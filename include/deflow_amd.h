@@ -270,6 +270,10 @@ int df_conv2d_wgrad_mp(df_img x, df_img dy, int ksize, int stride, int pad, floa
                        const int32_t* row_counts, int rows_per_seg, float* bias_ws, int mfma_bf16, void* stream);
 int df_conv2d_wgrad_reduce(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
                            int accumulate, void* stream);
+/* the same reduction and the bias partials' (bias_ws [splits, Cout] -> db [Cout], summed in double) in ONE launch:
+ * what a ConvWithNorms layer's weight + bias gradient [REF decoder.py:205,213] needs after its split-K pass */
+int df_conv2d_wgrad_reduce_bias(const float* ws, int splits, int cout, int taps, int cin, float* dw, int64_t ld_co,
+                                int accumulate, const float* bias_ws, float* db, void* stream);
 /* fp32-ACCURATE 3x3 stride-1 weight gradient on the bf16 matrix pipe (round 3, "bf16x3", the twin of df_conv2d_x3): fp32 x and
  * dy, each staged element split into three bf16 planes, six exact products per operand pair, transposing LDS reads, fp32
  * accumulation and split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce as df_conv2d_wgrad_mp.  _ok: 1 if the form
