@@ -83,6 +83,7 @@ struct ConvParams {
   int stats_mul;  // statistics rows per tile (1; 2 when a 256-row tile fills the partial table sized for 128-row tiles: the second is 0)
   const float* amax_x;   // fp16x2 form (conv_halo_x3_kernel<.., NP = 2>): upper bounds of max|x| and max|w| (device scalars) that
   const float* amax_w;   // set the power-of-two scales of the two fp16 planes
+  const void* w2p;       // conv_dma_kernel<.., H2, BP>: the weights PRE-SPLIT ([hi plane | lo plane] fp16 of w s_w, df_split_h2 / df_weight_prep), or null
   unsigned* amax_y;      // optional: the epilogue leaves max |y| there (bit pattern, atomic max) for an fp16x2 consumer of y
   const float* bound_y;  // y.elt == 2 (pre-split output): the bound of max |y| that defines the output's power-of-two scale
   // DF_EPI_BWD_STATS (round 4; data gradient only): y = dz is the gradient of a BatchNorm + GELU layer's OUTPUT.  bwd_y = that layer's
@@ -493,10 +494,18 @@ constexpr unsigned DMA_BAD = 0xFFFFFFFFu - (8u << 20);  // + soffset (< 8 MB) ne
 // accumulator, the cross terms in a second one) instead of eight v_mfma_f32_32x32x2_f32 -- the 1x1 and stride-2 convolutions,
 // whose im2col tiles have no halo to share, on the 16-bit matrix pipe.  The split costs ~6 VALU per element and fragment (the
 // kernel becomes VALU-bound: ~1.8x the fp32-MFMA form on the stride-2 layers; the 1x1 layers are HBM-bound either way).
-template <int BM, int BN, int WM, int WN, bool BF = false, bool H2 = false>
+// BP (H2 only; round 4, second session): the WEIGHTS arrive pre-split (p.w2p: [hi plane | lo plane] fp16 of w s_w, the planes the
+// 3x3 stride-1 kernels read, from the step's df_weight_prep launch): a weight row's stage is then 64 B of hi + 64 B of lo -- the
+// same 128 bytes per row and stage, fetched by the same DMA instruction (lanes of slots 0-3 address the hi plane, 4-7 the lo plane)
+// -- and a B fragment is two ds_read_b128 with no VALU.  The in-kernel split of B was redone by every wave that shares the
+// fragment (4 of 8 waves on the 128 x 64 tile) at ~50 VALU instructions per 8 values: the kernel was VALU-bound 4 : 1 against
+// its MFMAs on the 32 x 32 wave tiles.  A lane's 8 k values are CONSECUTIVE in this form (k = 16 q + 8 kh ..+7: the A slots
+// change to match); same products, another order inside the MFMA's 16-deep sum.
+template <int BM, int BN, int WM, int WN, bool BF = false, bool H2 = false, bool BP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
   static_assert(!(BF && H2), "one operand format");
+  static_assert(!BP || H2, "pre-split weights: the fp16x2 form only");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NW = WM * WN, RP = 8 * NW;       // waves; tile rows one DMA pass of the whole workgroup covers
   constexpr int RA = BM / RP, RB = BN / RP;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)(BP ? p.w2p : (const void*)p.w), 0, p.w_bytes, 0x00020000);
 
   const int c4s = c4 ^ ((r0 >> 1) & 7);  // logical 16-B slot this lane fetches (it lands in physical slot c4)
   unsigned aoff[RA], boff[RB];
@@ -563,7 +572,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((int64_t)(n0 + r0 + RP * i) * p.ks * p.ks * p.K + c4s * 4) * 4);
+  for (int i = 0; i < RB; ++i) {
+    if constexpr (BP)   // 2 bytes per element; logical slots 0-3 = hi k 0..31, 4-7 = lo k 0..31 (the lo plane follows the hi plane)
+      boff[i] = (unsigned)((int64_t)(n0 + r0 + RP * i) * p.ks * p.ks * p.K * 2 + (c4s & 3) * 16 + (c4s >> 2) * (int64_t)(p.w_bytes / 2));
+    else
+      boff[i] = (unsigned)(((int64_t)(n0 + r0 + RP * i) * p.ks * p.ks * p.K + c4s * 4) * 4);
+  }
 
   int l_kc = 0, l_iky = 0, l_ikx = 0;
   auto load_stage = [&](int buf) {
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
       wtap = fwd ? ty * p.ks + tx : (p.ks - 1 - ty) * p.ks + (p.ks - 1 - tx);
     }
     const unsigned soffA = (unsigned)(((ty * wx + tx) * ldx + l_kc * BK) * 4);
-    const unsigned soffB = (unsigned)((wtap * p.K + l_kc * BK) * 4);
+    const unsigned soffB = (unsigned)((wtap * p.K + l_kc * BK) * (BP ? 2 : 4));
     float* a = As + buf * BM * LDT + wave * 8 * LDT;
     float* b = Bs + buf * BN * LDT + wave * 8 * LDT;
 #pragma unroll
@@ -634,15 +648,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
       for (int q = 0; q < BK / 16; ++q) {
         f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+        const int swz = (li >> 1) & 7;
+        // BP: a lane's 8 k values are consecutive (fp32 slots 4 q + 2 kh, + 1) to match the pre-split weight planes
+        const int sl0 = BP ? ((4 * q + 2 * kh) ^ swz) * 4 : rslot[2 * q], sl1 = BP ? ((4 * q + 2 * kh + 1) ^ swz) * 4 : rslot[2 * q + 1];
         auto split = [&](const float* row, float sc, f16x8_t& hi, f16x8_t& lo) {
-          const f32x4 v0 = ld4(row + rslot[2 * q]), v1 = ld4(row + rslot[2 * q + 1]);
+          const f32x4 v0 = ld4(row + sl0), v1 = ld4(row + sl1);
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           df_h2_split(v, sc, hi, lo);
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i) split(a + i * 32 * LDT, sx, ah[i], al[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) split(b + j * 32 * LDT, sw, bh[j], bl[j]);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (BP) {   // hi: logical slot 2 q + kh, lo: 4 + 2 q + kh of the row's 128 bytes
+            bh[j] = *reinterpret_cast<const f16x8_t*>(b + j * 32 * LDT + ((2 * q + kh) ^ swz) * 4);
+            bl[j] = *reinterpret_cast<const f16x8_t*>(b + j * 32 * LDT + ((4 + 2 * q + kh) ^ swz) * 4);
+          } else {
+            split(b + j * 32 * LDT, sw, bh[j], bl[j]);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1844,6 +1868,12 @@ static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
   if (p.bf16) {
     DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, true>), (int)lds_bytes);
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
+  if (p.amax_x && p.amax_w && p.w2p) {   // ... with the weights pre-split
+    DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, false, true, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, false, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
     DF_CHECK_LAUNCH();
     return DF_OK;
   }
@@ -3511,7 +3541,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr,
                        const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr,
-                       const float* y_bound = nullptr, const float* bwd_y = nullptr, const float* bwd_ss = nullptr);
+                       const float* y_bound = nullptr, const float* bwd_y = nullptr, const float* bwd_ss = nullptr,
+                       const void* w2p = nullptr);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -3593,6 +3624,18 @@ extern "C" int df_conv2d_h2p_ok(df_img x, df_img y, int ksize, int stride, int m
 
 // the fp32-input kernels of df_conv2d_mp / df_conv2d_h2f / df_conv2d_amax with an h2 OUTPUT (y.elt = 2, scale from *y_bound): the
 // 1x1 convolutions that write a half of a pre-split concatenation, the 1x1 data gradients that feed a pre-split 3x3 layer
+// df_conv2d_h2f / df_conv2d_yh2 (y.elt = 2: y_bound required, no y_amax) with the weights ALSO given pre-split: w2 = the [hi | lo]
+// fp16 planes of w scaled by df_h2_scale(*w_amax) (df_split_h2, or the layer's planes from df_weight_prep) -- conv_dma_kernel<.., H2,
+// BP> fetches them by DMA instead of splitting the fp32 weight fragments in every wave; w (fp32) is still what the tile forms
+// without an fp16x2 mode read.
+extern "C" int df_conv2d_h2f_wp(df_img x, const float* w, const void* w2, const float* x_amax, const float* w_amax, const float* bias,
+                                df_img y, const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
+                                const float* shift, float* stats_partial, int accumulate, float* y_amax, void* stream) {
+  DF_REQUIRE(x_amax && w_amax && w2 && df_aligned16(w2) && (y.elt != 2 || y_bound), DF_E_ARG);
+  return conv2d_impl(x, w, nullptr, bias, y, ksize, stride, pad, mode, epi, scale, shift, stats_partial, accumulate, 0, false, stream,
+                     nullptr, x_amax, w_amax, y.elt == 2 ? nullptr : y_amax, y.elt == 2 ? y_bound : nullptr, nullptr, nullptr, w2);
+}
+
 extern "C" int df_conv2d_yh2(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y,
                              const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
                              const float* shift, float* stats_partial, int accumulate, void* stream) {
@@ -3664,7 +3707,8 @@ extern "C" int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int m
 static int conv2d_impl(df_img x, const float* w, const void* w16, const float* bias, df_img y, int ksize, int stride, int pad,
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3, const float* h2_amax_x,
-                       const float* h2_amax_w, float* y_amax, const float* y_bound, const float* bwd_y, const float* bwd_ss) {
+                       const float* h2_amax_w, float* y_amax, const float* y_bound, const float* bwd_y, const float* bwd_ss,
+                       const void* w2p) {
   if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
@@ -3699,6 +3743,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.stats_mul = 1;
   p.amax_x = h2_amax_x;      // (used by the fp16x2 forms only: conv_halo_x3_kernel<NP = 2> below, conv_dma_kernel<.., H2>)
   p.amax_w = h2_amax_w;
+  p.w2p = w2p;
   p.amax_y = reinterpret_cast<unsigned*>(y_amax);
   p.bound_y = y_bound;
   p.bwd_y = bwd_y;
@@ -3902,6 +3947,10 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     case 128128: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
       if (halo_ok) return launch_conv_halo<128, 2, 4>(p, s);
+      // pre-split weights (BP): B fragments cost no VALU, so the wave grid that shares an A fragment among FEWER waves wins -- 4 x 2
+      // (each wave splits one 32-row A fragment per 6 MFMAs) instead of 2 x 4 (two per 6, each redone by four waves)
+      static const int bp42 = getenv("DF_CONV_BP42") ? atoi(getenv("DF_CONV_BP42")) : 1;
+      if ((w8 & 1) && p.x_bytes && p.w2p && p.amax_x && p.amax_w && bp42) return launch_conv_w8<128, 128, 4, 2>(p, s);
       if ((w8 & 1) && p.x_bytes) return launch_conv_w8<128, 128, 2, 4>(p, s);
       return launch_conv<128, 128, 2, 2>(p, s);
     }
@@ -3913,6 +3962,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     default: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
       if (halo_ok) return launch_conv_halo<64, 4, 2>(p, s);
+      // (with pre-split weights a 4 x 1 grid -- 32 x 64 wave tiles, one A split per 6 MFMAs, but 4 waves per workgroup -- measured
+      // 9-33 % SLOWER than 4 x 2 on the four 64-wide layers: occupancy beats the split count here)
       if ((w8 & 2) && p.x_bytes) return launch_conv_w8<128, 64, 4, 2>(p, s);
       return launch_conv<128, 64, 2, 2>(p, s);
     }

@@ -262,8 +262,8 @@ def h2_pack(x: torch.Tensor, bound: torch.Tensor) -> torch.Tensor:
 
 class WeightPrep:
     """Every convolution layer's per-step weight forms from ONE launch (df_weight_prep; round 4): transposed weights, [hi | lo] fp16
-    planes of the weights and of their transpose (3x3 stride-1 layers), row L1 norms and max |bias| (a-priori bounds of pre-split
-    outputs).  optim.Trainer builds one at the top of every step (the parameters change once per step) and installs it as
+    planes of the weights and of their transpose (every layer: the 3x3 stride-1 kernels and, since the round's second session, the
+    1x1 / stride-2 kernel read them), row L1 norms and max |bias| (a-priori bounds of pre-split outputs).  optim.Trainer builds one at the top of every step (the parameters change once per step) and installs it as
     ops.WPREP; ops.weight_transpose / _split_h2 / rows_l1max answer from it when the tensor they are asked about is one of its
     layers, and fall back to their own launches otherwise (plain autograd users, the decoder head's GEMM weights)."""
 
@@ -282,7 +282,7 @@ class WeightPrep:
         for i, (w, m) in enumerate(zip(ws, self.convs)):
             co, kh, kw, ci = w.shape
             n = w.numel()
-            split = int(kh == 3 and m.stride[0] == 1)
+            split = 1      # (round 4, second session: the 1x1 / stride-2 layers read pre-split weights too: conv_dma_kernel<.., H2, BP>)
             rec[i] = ((w.data_ptr() - self.base) // 4, (m.bias.data_ptr() - self.base) // 4 if m.bias is not None else -1,
                       off, off + n, off + 2 * n, co, kh * kw, ci, split, blk, 0)
             self.layer[w.data_ptr()] = (i, off, n, (co, kh, kw, ci), split)
@@ -398,6 +398,15 @@ def _split_h2(w_ohwi: torch.Tensor):
     return w2, wa
 
 
+def _wprep_planes(w_ohwi: torch.Tensor):
+    """(planes, their amax) of a 1x1 / stride-2 layer's weights (or of the transpose ops.weight_transpose handed out) if the step's
+    WeightPrep made them -- then conv_dma_kernel<.., H2, BP> fetches the weights pre-split; None otherwise (plain autograd / inference
+    callers: the kernel splits its weight fragments itself).  DF_CONV_H2F_WP=0: never."""
+    if WPREP is None or os.environ.get("DF_CONV_H2F_WP", "1") == "0":
+        return None
+    return WPREP.h2(w_ohwi)
+
+
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
            mode: int = CONV_FWD, epi: int = EPI_BIAS, scale=None, shift=None, stats=None, accumulate: bool = False,
            amax_out: Optional[torch.Tensor] = None, bwd_bn=None):
@@ -456,8 +465,13 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             if wa is None:
                 wa = amax_slot(w_ohwi.device)
                 call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
-        call("df_conv2d_yh2", x, ptr(w_ohwi), ptr(x._amax) if h2f else None, ptr(wa), ptr(bias), y, ptr(y._amax), ks, stride, ks // 2, mode, epi,
-             ptr(scale), ptr(shift), ptr(stats), 0, stream())
+        wp = _wprep_planes(w_ohwi) if h2f else None
+        if wp is not None:      # the step's WeightPrep holds this layer's planes: no weight split in the kernel (conv_dma_kernel<.., H2, BP>)
+            call("df_conv2d_h2f_wp", x, ptr(w_ohwi), ptr(wp[0]), ptr(x._amax), ptr(wp[1]), ptr(bias), y, ptr(y._amax), ks, stride, ks // 2, mode,
+                 epi, ptr(scale), ptr(shift), ptr(stats), 0, None, stream())
+        else:
+            call("df_conv2d_yh2", x, ptr(w_ohwi), ptr(x._amax) if h2f else None, ptr(wa), ptr(bias), y, ptr(y._amax), ks, stride, ks // 2, mode, epi,
+                 ptr(scale), ptr(shift), ptr(stats), 0, stream())
     elif h2:
         # fp32-accurate product from TWO fp16 planes per operand with per-tensor power-of-two scales (conv_halo_x3_kernel<NP = 2>:
         # three MFMAs per operand pair instead of six)
@@ -470,8 +484,13 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
         if wa is None:
             wa = amax_slot(w_ohwi.device)
             call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
-        call("df_conv2d_h2f", x, ptr(w_ohwi), ptr(x._amax), ptr(wa), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift),
-             ptr(stats), int(accumulate), ptr(ya), stream())
+        wp = _wprep_planes(w_ohwi)
+        if wp is not None:
+            call("df_conv2d_h2f_wp", x, ptr(w_ohwi), ptr(wp[0]), ptr(x._amax), ptr(wp[1]), ptr(bias), y, None, ks, stride, ks // 2, mode, epi,
+                 ptr(scale), ptr(shift), ptr(stats), int(accumulate), ptr(ya), stream())
+        else:
+            call("df_conv2d_h2f", x, ptr(w_ohwi), ptr(x._amax), ptr(wa), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift),
+                 ptr(stats), int(accumulate), ptr(ya), stream())
     elif ya is not None and not x3:
         call("df_conv2d_amax", x, ptr(w_ohwi), ptr(bias), y, ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats),
              int(accumulate), ptr(ya), stream())

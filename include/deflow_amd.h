@@ -216,6 +216,12 @@ int df_conv2d_amax(df_img x, const float* w, const float* bias, df_img y, int ks
 int df_conv2d_h2f(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y, int ksize,
                   int stride, int pad, int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                   int accumulate, float* y_amax, void* stream);
+/* ... with the weights also handed over PRE-SPLIT (w2: the [hi | lo] fp16 planes of w s_w from df_split_h2 / df_weight_prep): the
+ * weight tiles go to LDS as planes by DMA and no wave splits a weight fragment (conv_dma_kernel<.., H2, BP>).  y.elt = 2: y_bound
+ * defines the output planes (as df_conv2d_yh2), else y_amax (optional) receives max |y| (as df_conv2d_h2f).  [REF decoder.py:205-211] */
+int df_conv2d_h2f_wp(df_img x, const float* w, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y,
+                     const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift,
+                     float* stats_partial, int accumulate, float* y_amax, void* stream);
 int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);

@@ -1037,8 +1037,23 @@ def test_conv_h2f_fragments(dev, monkeypatch, cin, cout, ks, stride, n, h, w, mo
     oh, ow, oc = want.shape[1], want.shape[2], want.shape[3]
     xd = x.to(dev)
     res = {}
-    for form in ("h2f", "fp32"):
-        monkeypatch.setenv("DF_CONV_H2F", "1" if form == "h2f" else "0")
+    # "h2f_wp": the weights come pre-split from a WeightPrep (what optim.Trainer installs every step): conv_dma_kernel<.., H2, BP>
+    conv_mod = torch.nn.Conv2d(cin, cout, ks, stride, pad).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        conv_mod.weight.copy_(wt.to(dev))
+        conv_mod.bias.copy_(bias.to(dev))
+    for form in ("h2f", "fp32", "h2f_wp"):
+        monkeypatch.setenv("DF_CONV_H2F", "0" if form == "fp32" else "1")
+        if form == "h2f_wp":
+            w_own = ops.ohwi(conv_mod.weight)
+            wa = torch.zeros(1, device=dev)
+            ops.call("df_absmax", img(w_own.reshape(1, 1, -1, w_own.shape[-1])), ops.ptr(wa), ops.stream())
+            wp = ops.WeightPrep([conv_mod], wa)
+            wp.run(wa)
+            monkeypatch.setattr(ops, "WPREP", wp)
+            monkeypatch.setattr(ops, "W_AMAX", wa)
+            wk = w_own if mode.startswith("fwd") else ops.weight_transpose(w_own)
+            assert ops._wprep_planes(wk) is not None
         y = torch.zeros(n, oh, ow, oc, device=dev)
         base = None
         if mode == "dgrad_acc":
@@ -1054,13 +1069,14 @@ def test_conv_h2f_fragments(dev, monkeypatch, cin, cout, ks, stride, n, h, w, mo
         finally:
             ops.PROFILER = None
         torch.cuda.synchronize()
-        assert prof.records[0][0].endswith("/h2") == (form == "h2f"), prof.records[0][0]
+        assert prof.records[0][0].endswith("/h2") == (form != "fp32"), prof.records[0][0]
         ref = want + (base.double() if base is not None else 0.0)
         res[form] = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
         if partial is not None:
             check(f"{form} stats sum", partial.sum(0).cpu()[:, 0], ref.reshape(-1, oc).sum(0).float(), 2e-5)
-    print(f"[parity] conv h2f {mode} {cin}->{cout} k{ks} s{stride}: fp16x2-on-fragments {res['h2f']:.2e} | fp32-MFMA {res['fp32']:.2e} (vs float64)")
-    assert res["h2f"] <= 2e-6, res
+    print(f"[parity] conv h2f {mode} {cin}->{cout} k{ks} s{stride}: fp16x2-on-fragments {res['h2f']:.2e} | pre-split weights {res['h2f_wp']:.2e} | "
+          f"fp32-MFMA {res['fp32']:.2e} (vs float64)")
+    assert res["h2f"] <= 2e-6 and res["h2f_wp"] <= 2e-6, res
 
 
 def _wide_range(shape, kind, g):
