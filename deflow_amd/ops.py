@@ -398,13 +398,34 @@ def _split_h2(w_ohwi: torch.Tensor):
     return w2, wa
 
 
+_PLANE_CACHE: dict = {}
+
+
 def _wprep_planes(w_ohwi: torch.Tensor):
     """(planes, their amax) of a 1x1 / stride-2 layer's weights (or of the transpose ops.weight_transpose handed out) if the step's
-    WeightPrep made them -- then conv_dma_kernel<.., H2, BP> fetches the weights pre-split; None otherwise (plain autograd / inference
-    callers: the kernel splits its weight fragments itself).  DF_CONV_H2F_WP=0: never."""
-    if WPREP is None or os.environ.get("DF_CONV_H2F_WP", "1") == "0":
+    WeightPrep made them, else from a split of its own (kept while the tensor is unchanged) -- conv_dma_kernel<.., H2, BP> fetches the
+    weights pre-split.  DF_CONV_H2F_WP=0: None (the kernel splits its weight fragments itself)."""
+    if os.environ.get("DF_CONV_H2F_WP", "1") == "0":
         return None
-    return WPREP.h2(w_ohwi)
+    if WPREP is not None:
+        hit = WPREP.h2(w_ohwi)
+        if hit is not None:
+            return hit
+    if W_AMAX is not None:      # inside a trainer step without the weight prep (DF_WPREP=0): the same kernel, planes from a per-call split
+        return _split_h2(w_ohwi)
+    # plain autograd / inference callers: the same kernel again (one form of the convolution whoever calls it: the captured trainer
+    # program and a hand-driven eager step agree bit for bit, tests/helpers/rccl_world1.py); planes are kept per weight tensor until it
+    # changes (inference: split once; a transposed copy made per call misses and is split per call)
+    try:
+        key = (w_ohwi.data_ptr(), w_ohwi._version, PARAM_GEN[0], tuple(w_ohwi.shape))
+    except RuntimeError:        # inference-mode tensors do not track versions
+        return _split_h2(w_ohwi)
+    hit = _PLANE_CACHE.get(key)
+    if hit is None:
+        if len(_PLANE_CACHE) > 128:
+            _PLANE_CACHE.clear()
+        hit = _PLANE_CACHE[key] = _split_h2(w_ohwi) + (w_ohwi,)     # (the tensor is kept: its address cannot be reused while cached)
+    return hit[0], hit[1]
 
 
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,

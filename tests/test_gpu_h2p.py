@@ -393,15 +393,12 @@ def test_weight_prep_one_launch_equals_per_call_forms(dev, monkeypatch):
         l1t, _ = wp.l1(wt, None)
         l1tr, _ = ops.rows_l1max(wt_ref.shape[0], wt_ref.numel() // wt_ref.shape[0], wt_ref, None)
         assert torch.equal(l1, l1r) and torch.equal(bm, bmr) and torch.equal(l1t, l1tr), m
-        h = wp.h2(w)
-        if m.kernel_size[0] == 3 and m.stride[0] == 1:
-            n_split += 1
-            for src, got in ((w, h[0]), (wt_ref, wp.h2(wt)[0])):
-                ref2 = torch.empty(2 * src.numel(), dtype=torch.float16, device=dev)
-                call("df_split_h2", ops.ptr(src.contiguous()), ops.ptr(wa), ops.ptr(ref2), src.numel(), ops.stream())
-                assert torch.equal(got, ref2)
-        else:
-            assert h is None
+        h = wp.h2(w)       # planes of EVERY layer (the 1x1 / stride-2 kernel reads them too since the round's second session)
+        n_split += int(m.kernel_size[0] == 3 and m.stride[0] == 1)
+        for src, got in ((w, h[0]), (wt_ref, wp.h2(wt)[0])):
+            ref2 = torch.empty(2 * src.numel(), dtype=torch.float16, device=dev)
+            call("df_split_h2", ops.ptr(src.contiguous()), ops.ptr(wa), ops.ptr(ref2), src.numel(), ops.stream())
+            assert torch.equal(got, ref2)
     assert n_split == 20
     # whole step: same bits with and without
     from deflow_amd.optim import Trainer

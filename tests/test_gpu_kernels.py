@@ -1044,6 +1044,7 @@ def test_conv_h2f_fragments(dev, monkeypatch, cin, cout, ks, stride, n, h, w, mo
         conv_mod.bias.copy_(bias.to(dev))
     for form in ("h2f", "fp32", "h2f_wp"):
         monkeypatch.setenv("DF_CONV_H2F", "0" if form == "fp32" else "1")
+        monkeypatch.setenv("DF_CONV_H2F_WP", "1" if form == "h2f_wp" else "0")     # "h2f": the in-kernel weight split (the A/B leg)
         if form == "h2f_wp":
             w_own = ops.ohwi(conv_mod.weight)
             wa = torch.zeros(1, device=dev)
