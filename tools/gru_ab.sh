@@ -3,7 +3,7 @@
 #   gru_base   -DDF_GRU_MERGE_SAVES=0 -DDF_GRU_PERM_PLANES=0   (the round-4 record's kernels)
 #   gru_merge  -DDF_GRU_PERM_PLANES=0                           (two store groups per iteration instead of four)
 #   default    both: + z, r, q as register-order tiles (16-byte stores / loads)
-# build the variants first (CPU): python -c "from deflow_amd import build as B; B.build_variant('gru_base', [...]); ..."
+# apply tools/gru_store_ab.patch, then build the variants (CPU): python -c "from deflow_amd import build as B; B.build_variant('gru_base', [...]); ..."
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for v in ${GRU_AB_VARIANTS:-gru_base gru_merge default gru_base default}; do
