@@ -122,6 +122,13 @@ _SIGS = {
     "df_gru_decoder_fwd_bf16": [DfImg, DfImg, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_gru_decoder_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, P],
     "df_gru_wgrad_splits": [],
+    "df_gru_xtab": [DfGruWeights, P, P],
+    "df_gru_lean_partial_width": [],
+    "df_gru_lean_fwd": [DfImg, DfImg, P, P, P, I, I, I, DfGruWeights, P, P, P, I, P],
+    "df_gru_lean_bwd": [P, P, P, I, I, I, DfGruWeights, DfGruWeightsT, P, P, P, P, P, P, I, P],
+    "df_gru_lean_wgrad": [P, P, P, I, I, I, P, I, I, P],
+    "df_gru_lean_head_wgrad": [P, P, P, I, I, P, I, P],
+    "df_gru_lean_finalize": [P, DfGruWeights, P, P, P, P, P, P],
     "df_gru_head_wgrad": [P, P, P, P, I, I, P, I, P],
     "df_gru_wgrad": [P, P, P, I, I, I, P, I, P],
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
@@ -137,7 +144,7 @@ _SIGS = {
     "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
 _RESTYPE = {"df_cell_sort_ws_bytes": C.c_int64}
-_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_h2p_ok", "df_conv2d_wgrad_h2p_ok", "df_conv2d_wgrad_h2p_splits", "df_conv2d_last_dma", "df_gru_wgrad_splits"}  # return values, not status
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_h2p_ok", "df_conv2d_wgrad_h2p_ok", "df_conv2d_wgrad_h2p_splits", "df_conv2d_last_dma", "df_gru_wgrad_splits", "df_gru_lean_partial_width"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

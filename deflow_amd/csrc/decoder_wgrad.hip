@@ -360,6 +360,272 @@ __global__ __launch_bounds__(384) void gru_head_wgrad_kernel(GruHeadWgradParams 
 #endif
 }
 
+
+// ---- round 5, the "lean" decoder (decoder4.hip): the x columns of every weight gradient come from the [416][4] sums of the backward
+// kernel, so the weight-gradient pass multiplies only the 128 h columns: dW_g[:, :128] = dg_pre^T h_in (z, r) / dq_pre^T (r * h).  One
+// gate's [128 co x 128 ci] tile per workgroup, waves 2 x 2 (64 x 64 each, four 32 x 32 accumulators), 16-row stages G [16][128] |
+// H [16][128] through a four-deep DMA ring (16 KB per stage in fp32).  G planes: gplanes [4][T][B*N][128] = dz_pre | dr_pre | dq_pre |
+// r * h; h_in: hsave [T + 1][B*N][128] (the forward's planes).  Partials ws[split][384][128].
+struct GruWgrad4Params {
+  const float* hsave;
+  const float* gplanes;
+  const int32_t* counts;
+  int B, N, T, nsplit;
+  int64_t plane_stride, iter_stride;   // floats
+  float* ws;
+};
+
+template <int MODE>   // 0: fp32 MFMA, 1: bf16 planes + bf16 MFMA, 3: fp32 planes, bf16x2 products
+__global__ __launch_bounds__(256, 2) void gru_wgrad4_kernel(GruWgrad4Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool BF = MODE == 1, X2 = MODE == 3;
+  constexpr int WD = 4;
+  constexpr int GSZ = BF ? WP * 64 : WP * 128;   // floats of the G (and H) tile
+  constexpr int STG = 2 * GSZ;
+  constexpr int OPS = BF ? 2 : 4;                // DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(16))) float ring[WD * STG];   // 64 KB (bf16 planes: 32 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int lg = df_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = lg / 3, gate = lg - 3 * split;   // gate 0: z, 1: r, 2: q
+  const float* gplane = p.gplanes + gate * p.plane_stride;
+  const float* hplane = gate == 2 ? p.gplanes + 3 * p.plane_stride : p.hsave;
+
+  int S = 0;
+  for (int b = 0; b < p.B; ++b) S += (p.counts[b] + WP - 1) / WP;
+  const int64_t total = (int64_t)S * p.T;
+  const int64_t w0 = total * split / p.nsplit, w1 = total * (split + 1) / p.nsplit;
+  const int nst = (int)(w1 - w0);
+  int it = S ? (int)(w0 / S) : 0, ib = 0, ic = S ? (int)(w0 % S) : 0, inch = 0;
+  if (nst > 0) {
+    for (;; ++ib) {
+      inch = (p.counts[ib] + WP - 1) / WP;
+      if (ic < inch) break;
+      ic -= inch;
+    }
+  }
+  const int g_row = lane >> 5, g_c4 = lane & 31;
+  const unsigned pl_bytes = (unsigned)min((int64_t)p.B * p.N * 512, (int64_t)0x7fffffff);
+
+  auto issue = [&](int buf) {
+    float* G = ring + buf * STG;
+    float* H = G + GSZ;
+    const int cnt = p.counts[ib];
+    const int row0 = ic * WP;
+    const int64_t srow = (int64_t)ib * p.N + row0;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(hplane + it * p.iter_stride), 0, pl_bytes, 0x00020000);
+    if constexpr (BF) {
+      const int r = 4 * wave + (lane >> 4);
+      const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 512 + (lane & 15) * 16) : BAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + wave * 256), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + wave * 256), 16, vo, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int op = 2 * wave + k;
+        const int r = 2 * op + g_row;
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)(((srow + r) * 128 + g_c4 * 4) * 4) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(G + op * 256), 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(H + op * 256), 16, vo, 0, 0, 0);
+      }
+    }
+    if (++ic == inch) {
+      ic = 0;
+      do {
+        if (++ib == p.B) { ib = 0; ++it; }
+        inch = (p.counts[ib] + WP - 1) / WP;
+      } while (inch == 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < WD - 1; ++d)
+    if (d < nst) issue(d);
+  for (int i = 0; i < nst; ++i) {
+    // this wave's DMA for stage i has landed (OPS instructions per stage and wave; up to WD - 2 younger stages in flight) ...
+    switch (min(WD - 2, nst - 1 - i) * OPS) {
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __syncthreads();   // ... and everyone's; all waves are also done reading slot (i - 1) % WD
+    if (i + WD - 1 < nst) issue((i + WD - 1) % WD);
+    const float* st = ring + (i % WD) * STG;
+    if constexpr (BF) {
+      bf16x8_t a8[2], b8[2];
+      const __bf16* g16 = reinterpret_cast<const __bf16*>(st);
+      const __bf16* h16 = reinterpret_cast<const __bf16*>(st + GSZ);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a8[0][k] = g16[(8 * kh + k) * 128 + wco * 64 + li];
+        a8[1][k] = g16[(8 * kh + k) * 128 + wco * 64 + 32 + li];
+        b8[0][k] = h16[(8 * kh + k) * 128 + wci * 64 + li];
+        b8[1][k] = h16[(8 * kh + k) * 128 + wci * 64 + 32 + li];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0], b8[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1], b8[j], acc[1][j], 0, 0, 0);
+      }
+      continue;
+    }
+    if constexpr (X2) {
+      bf16x8_t ah[2], al[2], bh[2], bl[2];
+      auto split8 = [&](const float* col, bf16x8_t& hi, bf16x8_t& lo) {   // rows 8 kh .. 8 kh + 7 of one column
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = col[(8 * kh + k) * 128];
+          hi[k] = (__bf16)v;
+          lo[k] = (__bf16)(v - (float)hi[k]);
+        }
+      };
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        split8(st + wco * 64 + 32 * i2 + li, ah[i2], al[i2]);
+        split8(st + GSZ + wci * 64 + 32 * i2 + li, bh[i2], bl[i2]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          f32x16 c = acc[i2][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i2], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i2], bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i2], bh[j], c, 0, 0, 0);
+          acc[i2][j] = c;
+        }
+      continue;
+    }
+#pragma unroll
+    for (int ks = 0; ks < WP / 2; ++ks) {
+      const float* a = st + (2 * ks + kh) * 128 + wco * 64 + li;
+      const float* bq = st + GSZ + (2 * ks + kh) * 128 + wci * 64 + li;
+      const float a0 = a[0], a1 = a[32], b0 = bq[0], b1 = bq[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  float* o = p.ws + ((int64_t)split * 384 + gate * 128) * 128;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = wci * 64 + 32 * j + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        o[co * 128 + ci] = acc[i][j][e];
+      }
+    }
+#endif
+}
+
+// the head's dW1[:, :128] = dpre1^T hT (the x columns come from the backward kernel's sums): gru_head_wgrad_kernel without the x
+// operand -- four waves, wave j owns columns 32 j of hT; 10 one-KB DMA ops per stage (2 G + 8 H) in 12 slots.  ws[split][32][128].
+__global__ __launch_bounds__(256) void gru_head_wgrad4_kernel(GruHeadWgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int STG = WP * (32 + 128);
+  constexpr int WD = 3;
+  __shared__ __attribute__((aligned(16))) float ring[WD * STG + 256 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int split = blockIdx.x;
+  int S = 0;
+  for (int b = 0; b < p.B; ++b) S += (p.counts[b] + WP - 1) / WP;
+  const int64_t w0 = (int64_t)S * split / p.nsplit, w1 = (int64_t)S * (split + 1) / p.nsplit;
+  const int nst = (int)(w1 - w0);
+  int ib = 0, ic = (int)w0, inch = 0;
+  if (nst > 0) {
+    for (;; ++ib) {
+      inch = (p.counts[ib] + WP - 1) / WP;
+      if (ic < inch) break;
+      ic -= inch;
+    }
+  }
+  const unsigned rows_b = (unsigned)min((int64_t)p.B * p.N, (int64_t)0x3fffff);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dpre), 0, rows_b * 128u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hT), 0, rows_b * 512u, 0x00020000);
+  auto issue = [&](int buf) {
+    float* st = ring + buf * STG;
+    const int cnt = p.counts[ib];
+    const int row0 = ic * WP;
+    const int64_t srow = (int64_t)ib * p.N + row0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int op = wave + 4 * e;
+      if (op < 2) {
+        const int r = 8 * op + (lane >> 3);
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 128 + (lane & 7) * 16) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_ptr_t)(st + op * 256), 16, vo, 0, 0, 0);
+      } else if (op < 10) {
+        const int r = 2 * (op - 2) + (lane >> 5);
+        const unsigned vo = (row0 + r < cnt) ? (unsigned)((srow + r) * 512 + (lane & 31) * 16) : BAD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(st + WP * 32 + (op - 2) * 256), 16, vo, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr_t)(ring + WD * STG + (op - 10) * 256), 16, BAD, 0, 0, 0);
+      }
+    }
+    if (++ic == inch) {
+      ic = 0;
+      do {
+        if (++ib == p.B) { ib = 0; break; }
+        inch = (p.counts[ib] + WP - 1) / WP;
+      } while (inch == 0);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int d = 0; d < WD - 1; ++d)
+    if (d < nst) issue(d);
+  for (int i = 0; i < nst; ++i) {
+    switch (min(WD - 2, nst - 1 - i)) {
+      case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __syncthreads();
+    if (i + WD - 1 < nst) issue((i + WD - 1) % WD);
+    const float* st = ring + (i % WD) * STG;
+    bf16x8_t ah, al, bh, bl;
+    auto split8 = [&](const float* col, int pitch, bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = col[(8 * kh + k) * pitch];
+        hi[k] = (__bf16)v;
+        lo[k] = (__bf16)(v - (float)hi[k]);
+      }
+    };
+    split8(st + li, 32, ah, al);
+    split8(st + WP * 32 + 32 * wave + li, 128, bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  float* o = p.ws + (int64_t)split * 32 * 128;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = (e & 3) + 8 * (e >> 2) + 4 * kh;
+    o[co * 128 + 32 * wave + li] = acc[e];
+  }
+#endif
+}
+
 }  // namespace
 
 // dW1 partials [nsplit][32][192] of the decoder head's first layer from dpre1 [B*N][32], hT [B*N][128] and x [B*N][64] (valid rows
@@ -396,6 +662,37 @@ extern "C" int df_gru_wgrad_mp(const float* save, const float* x, const int32_t*
   if (mfma_bf16 == 3) hipLaunchKernelGGL((gru_wgrad_kernel<false, true>), dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad_kernel<true>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(gru_wgrad_kernel<false>, dim3(nsplit * 3), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// ---- round 5: the lean decoder's weight-gradient pass (see gru_wgrad4_kernel) ------------------------------------------------------
+extern "C" int df_gru_lean_wgrad(const float* hsave, const float* gplanes, const int32_t* counts, int B, int N, int num_iters, float* ws,
+                                 int nsplit, int mfma_bf16, void* stream) {
+  DF_REQUIRE(hsave && gplanes && counts && ws && B > 0 && N > 0 && num_iters >= 1 && nsplit >= 1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(hsave) && df_aligned16(gplanes), DF_E_ALIGN);
+  DF_REQUIRE((int64_t)B * N * 512 < (int64_t)0x7fffffff, DF_E_SHAPE);  // 32-bit DMA offsets within one iteration's plane
+  GruWgrad4Params p;
+  p.hsave = hsave; p.gplanes = gplanes; p.counts = counts; p.B = B; p.N = N; p.T = num_iters; p.nsplit = nsplit;
+  p.iter_stride = (int64_t)B * N * 128;
+  p.plane_stride = p.iter_stride * num_iters;
+  p.ws = ws;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (mfma_bf16 == 3) hipLaunchKernelGGL(gru_wgrad4_kernel<3>, dim3(nsplit * 3), dim3(256), 0, s, p);
+  else if (mfma_bf16) hipLaunchKernelGGL(gru_wgrad4_kernel<1>, dim3(nsplit * 3), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gru_wgrad4_kernel<0>, dim3(nsplit * 3), dim3(256), 0, s, p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_gru_lean_head_wgrad(const float* dpre, const float* hT, const int32_t* counts, int B, int N, float* ws, int nsplit,
+                                      void* stream) {
+  DF_REQUIRE(dpre && hT && counts && ws && B > 0 && N > 0 && nsplit >= 1, DF_E_ARG);
+  DF_REQUIRE(df_aligned16(dpre) && df_aligned16(hT), DF_E_ALIGN);
+  DF_REQUIRE((int64_t)B * N < (int64_t)0x3fffff, DF_E_SHAPE);
+  GruHeadWgradParams p;
+  p.dpre = dpre; p.hT = hT; p.x = nullptr; p.counts = counts; p.B = B; p.N = N; p.nsplit = nsplit; p.ws = ws;
+  hipLaunchKernelGGL(gru_head_wgrad4_kernel, dim3(nsplit), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

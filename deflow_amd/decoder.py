@@ -124,6 +124,24 @@ class ConvGRUDecoder(nn.Module):
         return os.environ.get("DF_GRU_X2", "1") != "0" and not os.environ.get("DF_GRU_V1")
 
     @staticmethod
+    def _lean_on() -> bool:
+        """round 5: the lean decoder kernels (csrc/decoder4.hip).  DF_GRU_LEAN=0: the round-3/4 kernels (all planes saved), for A/B."""
+        return os.environ.get("DF_GRU_LEAN", "1") != "0" and not os.environ.get("DF_GRU_V1")
+
+    def _xtab(self, W: DfGruWeights) -> torch.Tensor:
+        """[416,4] fp32: (W[:, 128:] W_off | W[:, 128:] b_off + b) of the z, r, q gates and the head's first layer -- the whole
+        contribution of the offset encoding x = W_off o + b_off [REF decoder.py:172] as an affine map of the point's offsets.  One
+        small launch per parameter state (per optimizer step in training; cached for inference)."""
+        key = (ops.PARAM_GEN[0],) + tuple((p._version, p.data_ptr()) for p in self.parameters())
+        c = getattr(self, "_df_xtab", None)
+        if c is None or c[0] != key or torch.is_grad_enabled():
+            t = torch.empty(416, 4, dtype=torch.float32, device=self.offset_encoder.weight.device)
+            call("df_gru_xtab", W, ptr(t), stream())
+            c = (key, t)
+            self._df_xtab = c
+        return c[1]
+
+    @staticmethod
     def _split_x2(w: torch.Tensor) -> torch.Tensor:
         """[rows, cols] fp32 -> [rows, 2, cols] bfloat16 (hi | lo per row)"""
         w = w.contiguous()
@@ -148,10 +166,20 @@ class ConvGRUDecoder(nn.Module):
         W, keep = self._weights()
         bf = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
         x2 = (not bf) and self._x2_on()
+        xtab = self._xtab(W) if self._lean_on() else None
         if bf:
             W, keep = self._weights16(W, keep)
         elif x2:
             W, keep = self._weights_x2(W, keep)
+        if xtab is not None:
+            # round 5 (csrc/decoder4.hip): x contributions from the [416,4] table, (T + 1) saved planes, gates recomputed backwards
+            hs = torch.empty((T + 1) * B * N * 128, dtype=torch.float32, device=dev) if save else None
+            with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save} lean"):
+                call("df_gru_lean_fwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(xtab), ptr(flow),
+                     ptr(hs), 2 if bf else 3 if x2 else 0, stream())
+            if hs is not None:
+                hs.df_bf16, hs.df_lean, hs.df_xtab = bf, True, xtab
+            return flow, hs
         # algorithmic work per point (un-hoisted count): 589 824 * T / 4 + 12 870 FLOP; fused-minimum traffic
         # 128 * 4 B gathered + 36 B of coordinates / offsets / flow
         with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
@@ -185,6 +213,8 @@ class ConvGRUDecoder(nn.Module):
 
     def run_backward(self, dflow: torch.Tensor, ps: PointSet, sv: torch.Tensor, dbefore: DfImg, dafter: DfImg,
                      acc_before: bool, acc_after: bool, grads: dict, before: DfImg = None, after: DfImg = None):
+        if getattr(sv, "df_lean", False):
+            return self._run_backward_lean(dflow, ps, sv, dbefore, dafter, acc_before, acc_after, grads)
         B, N, _ = ps.coords.shape
         dev, T, s = dflow.device, self.num_iters, stream()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -295,6 +325,88 @@ class ConvGRUDecoder(nn.Module):
         grads[self.offset_encoder.bias] = bias_g[608:672]
         grads[self.decoder[2].weight] = bias_g[672:768].view(3, 32)
         grads[self.decoder[2].bias] = bias_g[768:771]
+        return dh0   # [B*N,128] gradient of the gathered rows (for a sparse d(before); see df_pillar_input_grad)
+
+    def _run_backward_lean(self, dflow: torch.Tensor, ps: PointSet, hs: torch.Tensor, dbefore: DfImg, dafter: DfImg,
+                           acc_before: bool, acc_after: bool, grads: dict):
+        """backward of the lean decoder (csrc/decoder4.hip): hs = the forward's (T + 1) hidden-state planes; the data pass recomputes
+        the gates and leaves dz_pre | dr_pre | dq_pre | r*h for the weight-gradient pass over the 128 h columns; every x-side gradient
+        comes out of the [416,4] sums (df_gru_lean_finalize)."""
+        B, N, _ = ps.coords.shape
+        dev, T, s = dflow.device, self.num_iters, stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        BN = B * N
+        bf = int(hs.df_bf16)
+        W0, keep = self._weights()                       # the fp32 parameters (finalize reads them)
+        w_zr, b_zr, w_q = keep
+        w1 = self.decoder[0].weight.detach()
+        wt_zr = ops.weight_transpose(w_zr.view(256, 1, 1, 192)).view(192, 256)
+        wt_q = ops.weight_transpose(w_q.view(128, 1, 1, 192)).view(192, 128)
+        wt_1 = ops.weight_transpose(w1.view(32, 1, 1, 192)).view(192, 32)
+        x2 = (not bf) and self._x2_on()
+        W = W0
+        if bf:
+            W, keep = self._weights16(W0, keep)
+            wt_zr, wt_q, wt_1 = wt_zr.to(torch.bfloat16), wt_q.to(torch.bfloat16), wt_1.to(torch.bfloat16)
+        elif x2:
+            W, keep = self._weights_x2(W0, keep)
+            wt_zr, wt_q, wt_1 = self._split_x2(wt_zr), self._split_x2(wt_q), self._split_x2(wt_1)
+        WT = DfGruWeightsT(ptr(wt_zr), ptr(wt_q), ptr(wt_1))
+        mode = 2 if bf else 3 if x2 else 0
+        gpl = torch.empty(4 * T * BN * 128, **f32)
+        dh0, dpre1 = torch.empty(BN, 128, **f32), torch.empty(BN, 32, **f32)
+        dflow = dflow.contiguous()
+        nblocks = B * ((N + 63) // 64)
+        PW = call("df_gru_lean_partial_width")
+        partial = torch.zeros(nblocks, PW, **f32)
+        # data gradients: the forward's h-side GEMMs against the transposed weights + the recompute of the three gates
+        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * 2 + 24.0)):
+            call("df_gru_lean_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(hs.df_xtab), ptr(hs), ptr(gpl),
+                 ptr(dh0), ptr(dpre1), ptr(partial), mode, s)
+        sums = torch.empty(PW, **f32)
+        if nblocks >= 2048:
+            staged = torch.empty(64, PW, **f32)
+            call("df_colsum_stage", ptr(partial), nblocks, PW, 64, ptr(staged), s)
+            call("df_colsum_finalize", ptr(staged), 64, PW, 1, ptr(sums), 0, s)
+        else:
+            call("df_colsum_finalize", ptr(partial), nblocks, PW, 1, ptr(sums), 0, s)
+        ncell = dafter.h * dafter.w
+        if dbefore is None:   # the caller evaluates d(before) sparsely from dh0 (df_pillar_input_grad)
+            dbefore = DfImg(0, 0, 0, 0, 0, 0, 1, 0, 0)
+        call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
+             int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
+        side = ops.SIDE
+        if side is not None:
+            side.keep.extend([hs, gpl, dpre1, sums, ps])
+        with (side.fork() if side is not None else contextlib.nullcontext()):
+            s = stream()  # the side stream inside the fork
+            nsplit = call("df_gru_wgrad_splits")
+            ws = torch.empty(nsplit, 384, 128, **f32)
+            with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
+                call("df_gru_lean_wgrad", ptr(hs), ptr(gpl), ptr(ps.counts), B, N, T, ptr(ws), nsplit, 3 if x2 else (1 if bf else 0), s)
+            dW_all = torch.empty(384, 192, **f32)
+            call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 128, ptr(dW_all), 192, 0, s)
+            nsp1 = 128
+            ws1 = torch.empty(nsp1, 32, 128, **f32)
+            with ops.timed("gru_head_wgrad", flops=2.0 * 32 * 192 * B * N, bytes=B * N * 4.0 * (32 + 192)):
+                call("df_gru_lean_head_wgrad", ptr(dpre1), hs.data_ptr() + 4 * T * BN * 128, ptr(ps.counts), B, N, ptr(ws1), nsp1, s)
+            dW1 = torch.empty(32, 192, **f32)
+            call("df_conv2d_wgrad_reduce", ptr(ws1), nsp1, 32, 1, 128, ptr(dW1), 192, 0, s)
+            dW_off, db_off, db = torch.empty(64, 3, **f32), torch.empty(64, **f32), torch.empty(416, **f32)
+            call("df_gru_lean_finalize", ptr(sums), W0, ptr(dW_all), ptr(dW1), ptr(dW_off), ptr(db_off), ptr(db), s)
+        g = self.gru
+        grads[g.convz.weight] = dW_all[:128].unsqueeze(2)
+        grads[g.convr.weight] = dW_all[128:256].unsqueeze(2)
+        grads[g.convq.weight] = dW_all[256:].unsqueeze(2)
+        grads[self.decoder[0].weight] = dW1
+        grads[g.convz.bias] = db[0:128]
+        grads[g.convr.bias] = db[128:256]
+        grads[g.convq.bias] = db[256:384]
+        grads[self.decoder[0].bias] = db[384:416]
+        grads[self.offset_encoder.weight] = dW_off
+        grads[self.offset_encoder.bias] = db_off
+        grads[self.decoder[2].weight] = sums[1664:1760].view(3, 32)
+        grads[self.decoder[2].bias] = sums[1760:1763]
         return dh0   # [B*N,128] gradient of the gathered rows (for a sparse d(before); see df_pillar_input_grad)
 
     # -- reference-compatible call ------------------------------------------------------------------------------

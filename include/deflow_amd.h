@@ -418,6 +418,35 @@ int df_gru_wgrad(const float* save, const float* x, const int32_t* counts, int B
                  int nsplit, void* stream);
 int df_gru_wgrad_mp(const float* save, const float* x, const int32_t* counts, int B, int N, int num_iters, float* ws,
                     int nsplit, int mfma_bf16, void* stream);
+
+/* ---- round 5: the "lean" ConvGRU decoder (csrc/decoder4.hip) -- the engine's default; the entries above remain for A/B ----
+ * Same computation as df_gru_decoder_fwd_mp / _bwd_mp / df_gru_wgrad_mp ([REF decoder.py:123-199] and its derivative), two changes:
+ *  (1) x = W_off o + b_off [REF decoder.py:172] is affine in the point's 3 offsets and enters every gate and the head linearly
+ *      [REF decoder.py:126-139,151,182], so its contribution is evaluated from a [416][4] table (rows z | r | q | head layer 1:
+ *      W[:, 128:] W_off | W[:, 128:] b_off + b) as 3 FMAs per value -- df_gru_xtab builds it from the fp32 parameters once per
+ *      optimizer step -- and backwards every x-side product collapses onto [416][4] sums S (plain and offset-weighted column sums of
+ *      the gate / head pre-activation gradients) which df_gru_lean_finalize turns into dW[:, 128:], d b, dW_off, d b_off;
+ *  (2) the forward saves only the hidden state entering each iteration and h_T, hsave [T + 1][B*N][128] (bf16 modes: planes
+ *      0 .. T-1 as bf16 half rows); the backward recomputes z, r, q and writes gplanes [4][T][B*N][128] = dz_pre | dr_pre | dq_pre |
+ *      r * h for df_gru_lean_wgrad, which multiplies the 128 h columns only: ws [nsplit][384][128] (reduce with
+ *      df_conv2d_wgrad_reduce(ws, nsplit, 384, 1, 128, dW, 192, ...)).  df_gru_lean_head_wgrad: ws [nsplit][32][128] = dpre1^T hT.
+ * wts: w_zr, w_q, w_1 (and wtt.*) in the form mfma_bf16 selects, exactly as for the _mp entries; w_2, b_2 fp32; the bias and
+ * offset-encoder fields are read by df_gru_xtab / df_gru_lean_finalize only (which take the fp32 struct).
+ * partial: [B * ceil(N / 64)][df_gru_lean_partial_width()] zero-filled; its column sums = S [416][4] | dW_2 [3][32] | d b_2 [3] | pad.
+ * df_gru_lean_finalize: dW_gates [384][192] and dW1 [32][192] get their columns 128..191; db [416] = d b_z | d b_r | d b_q | d b_1. */
+int df_gru_xtab(df_gru_weights wts, float* xtab, void* stream);
+int df_gru_lean_partial_width(void);
+int df_gru_lean_fwd(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts, int B, int N,
+                    int num_iters, df_gru_weights wts, const float* xtab, float* flow, float* hsave, int mfma_bf16, void* stream);
+int df_gru_lean_bwd(const float* dflow, const float* offs, const int32_t* counts, int B, int N, int num_iters, df_gru_weights wts,
+                    df_gru_weights_t wtt, const float* xtab, const float* hsave, float* gplanes, float* dh0, float* dpre1,
+                    float* partial, int mfma_bf16, void* stream);
+int df_gru_lean_wgrad(const float* hsave, const float* gplanes, const int32_t* counts, int B, int N, int num_iters, float* ws,
+                      int nsplit, int mfma_bf16, void* stream);
+int df_gru_lean_head_wgrad(const float* dpre, const float* hT, const int32_t* counts, int B, int N, float* ws, int nsplit,
+                           void* stream);
+int df_gru_lean_finalize(const float* sums, df_gru_weights wts, float* dW_gates, float* dW1, float* dW_off, float* db_off, float* db,
+                         void* stream);
 /* gather backward without atomics: every BEV cell sums the dh0 rows of its own pc0 points (cell_rng / idx_sorted /
  * cpos from the pillarise step).  dbefore / dafter (64 ch each) are fully written (zeros for empty cells) or,
  * with accumulate_* != 0, added to.  dbefore.ptr == NULL skips the `before` image. */
