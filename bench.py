@@ -60,6 +60,15 @@ def parse():
     return ap.parse_args()
 
 
+def _git(args):
+    """best-effort git query (the GPU box's snapshot has no .git: None there)"""
+    try:
+        r = subprocess.run(["git", "-C", ROOT, *args], capture_output=True, text=True, timeout=10)
+        return r.stdout.strip() or None if r.returncode == 0 else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -446,9 +455,12 @@ def main():
                 "frac_at_sustained_clock": (achieved / (sus["random_operands_tflops"] / nmfma)) if x3 else None,
                 "note": "register-resident v_mfma_f32_32x32x16_f16 stream measured in this run (tools/mfma_peak_probe.hip): the matrix pipe alone, "
                         "clock = 2.4 GHz x random / 2500"}
-        try:   # worst three-way errors at configs[2] from the committed parity report of this round's GPU test run
+        try:   # worst three-way errors at configs[2] from the newest COMMITTED parity report (a GPU test run's record, NOT measured
+            # by this bench run: `source` / `source_commit` say which file and which code state it describes)
             worst = {}
-            with open(os.path.join(ROOT, "profiles", "r04_parity_report.jsonl")) as f:
+            reports = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_parity_report.jsonl"))
+            report = os.path.join(ROOT, "profiles", reports[-1])
+            with open(report) as f:
                 for line in f:
                     e = json.loads(line)
                     if e.get("test") in ("bs16_512", "bs16_512_gru_fp32") and "max_proj_err_over_l2" in e:
@@ -458,7 +470,11 @@ def main():
             if worst:
                 out["model_error_budget"] = {"workload": "configs[2] (B=16, 512x512, 80k pts) training step vs the float64 oracle digests: worst "
                                                          "|projection error| / ||g|| over every parameter gradient (a few sigma of the rms-relative error); "
-                                                         "bound 1e-4 x 4.5 sigma", **worst}
+                                                         "bound 1e-4 x 4.5 sigma", **worst,
+                                             "source": os.path.relpath(report, ROOT), "source_mtime": int(os.path.getmtime(report)),
+                                             "source_commit": _git(["log", "-1", "--format=%h", "--", os.path.relpath(report, ROOT)]),
+                                             "head_commit": _git(["rev-parse", "--short", "HEAD"]),
+                                             "measured_in_this_run": False}
         except Exception:   # noqa: BLE001
             pass
         # HBM-bound stages and the GRU kernels: algorithmic bytes / measured time / 8 TB/s
@@ -474,6 +490,11 @@ def main():
             e = {"ms_per_step": msx / args.steps, "algorithmic_mb_per_step": b / args.steps / 1e6,
                  "achieved_gbps": b / (msx * 1e-3) / 1e9, "peak_gbps": PEAK_HBM_GBPS, "frac": b / (msx * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                  "note": note}
+            mv = sum(v.get("moved", 0.0) for v in sel)
+            if mv:   # what the implementation streams through HBM by construction (saved / gradient planes), beside the algorithmic minimum
+                e["moved_mb_per_step"] = mv / args.steps / 1e6
+                e["moved_gbps"] = mv / (msx * 1e-3) / 1e9
+                e["moved_over_algorithmic"] = mv / b if b else None
             if fl:
                 e["tflops"] = fl / (msx * 1e-3) / 1e12
                 # the decoder GEMMs run as bf16x2 (three 16-bit MFMAs per multiply: roof = 2500 / 3) unless DF_GRU_X2=0 (fp32 MFMA: 157.3)
@@ -493,11 +514,16 @@ def main():
         for k in ("gru_fwd", "gru_bwd", "gru_wgrad"):
             if k in summ:
                 summ[k]["flops"] *= vf
-                summ[k]["bytes"] *= vf
+                summ[k]["moved"] = summ[k].get("moved", 0.0) * vf
+                if k != "gru_wgrad":        # (its algorithmic bytes are the weights: fused into the data pass it would re-read nothing)
+                    summ[k]["bytes"] *= vf
         entry("gru_fwd", ["gru_fwd"], "gather + T GRU steps + head, training form; bytes = fused minimum (548 B/point)")
         entry("gru_bwd", ["gru_bwd"], "data gradients (flops = the forward's un-hoisted count: the same GEMMs against transposed weights); "
-                                      "bytes = (T+2) state planes + dflow/offsets per point")
-        entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = one read of the three gate-gradient planes + h|x rows per step")
+                                      "bytes = the FUSED minimum (re-gather 512 B + dh0 512 B + dflow/offsets per point); moved = the hidden-state "
+                                      "planes read + the gate-gradient / r*h planes written for the weight-gradient pass")
+        entry("gru_wgrad", ["gru_wgrad"], "gate weight gradients; bytes = the FUSED minimum (the weights: fused into the data pass it would re-read "
+                                          "no activations); moved = the planes it streams (3 gate-gradient planes + h_in + r*h per step)")
+        entry("gru_trio", ["gru_fwd", "gru_bwd", "gru_wgrad"], "the three decoder kernels together against SURVEY 8(d)'s fused minimum")
         out["roofline_hbm"] = hbm
 
     if not args.no_extras:

@@ -79,6 +79,8 @@ class HDF5Dataset:
                         flow_category_indices=t(g0["flow_category_indices"]))
         if "ego_motion" in g0:
             item["ego_motion"] = t(g0["ego_motion"])
+        if "eval_mask" in g0:          # the benchmark's point mask of the official validation split
+            item["eval_mask"] = t(g0["eval_mask"]).reshape(-1).bool()
         return item
 
 
@@ -106,6 +108,8 @@ def collate_fn_pad(batch: List[Dict[str, object]]) -> Dict[str, object]:
         res["flow_category_indices"] = _pad([b["flow_category_indices"][k] for b, k in zip(batch, keep0)], 0)
     if "ego_motion" in batch[0]:
         res["ego_motion"] = torch.stack([b["ego_motion"].float() for b in batch])
+    if "eval_mask" in batch[0]:
+        res["eval_mask"] = _pad([b["eval_mask"][k] for b, k in zip(batch, keep0)], False)
     return res
 
 

@@ -174,7 +174,8 @@ class ConvGRUDecoder(nn.Module):
         if xtab is not None:
             # round 5 (csrc/decoder4.hip): x contributions from the [416,4] table, (T + 1) saved planes, gates recomputed backwards
             hs = torch.empty((T + 1) * B * N * 128, dtype=torch.float32, device=dev) if save else None
-            with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save} lean"):
+            with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save} lean",
+                           moved=B * N * (512.0 * (1 + (T + 1 if save else 0)) + 36.0)):      # gather + (T + 1) hidden-state planes
                 call("df_gru_lean_fwd", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(xtab), ptr(flow),
                      ptr(hs), 2 if bf else 3 if x2 else 0, stream())
             if hs is not None:
@@ -182,7 +183,8 @@ class ConvGRUDecoder(nn.Module):
             return flow, hs
         # algorithmic work per point (un-hoisted count): 589 824 * T / 4 + 12 870 FLOP; fused-minimum traffic
         # 128 * 4 B gathered + 36 B of coordinates / offsets / flow
-        with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}"):
+        with ops.timed("gru_fwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 + 36.0), tag=f"T={T} save={save}",
+                       moved=B * N * (512.0 * (1 + (5 * T + 1 if save else 0)) + 36.0)):        # gather + 5 T + 1 planes
             call("df_gru_decoder_fwd_mp", before, after, ptr(ps.coords), ptr(ps.offs), ptr(ps.counts), B, N, T, W, ptr(flow),
                  ptr(sv), 2 if bf else 3 if x2 else 0, stream())
         if sv is not None:
@@ -241,7 +243,8 @@ class ConvGRUDecoder(nn.Module):
         bias_partial = torch.zeros(nblocks, 772, **f32)
         # data gradients = the forward's GEMMs against the transposed weights: the same FLOP count (the weight gradients are
         # gru_wgrad's)
-        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * (T + 2) + 24.0)):
+        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * 2 + 24.0),
+                       moved=B * N * (512.0 * (4 * T + 1 + 3 * T + 1) + 24.0 + 256.0 + 384.0)):   # 4 T + 1 planes in, 3 T planes + dh0 (+ dx, x, dpre1) out
             call("df_gru_decoder_bwd_mp", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(sv), ptr(dh0), ptr(dx),
                  ptr(dpre1), ptr(xbuf), ptr(bias_partial), 2 if bf else 3 if x2 else 0, s)
         bias_g = torch.empty(772, **f32)
@@ -290,7 +293,8 @@ class ConvGRUDecoder(nn.Module):
             else:  # one fused streaming pass over the planes
                 nsplit = call("df_gru_wgrad_splits")
                 ws = torch.empty(nsplit, 384, 192, **f32)
-                with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
+                with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=3.0 * 128 * 192 * 4,
+                               moved=B * N * T * 4.0 * (384 + 256 + 64)):     # 3 gate-gradient planes + h_in + r*h + x rows per step
                     call("df_gru_wgrad_mp", ptr(sv), ptr(xbuf), ptr(ps.counts), B, N, T, ptr(ws), nsplit, 3 if x2 else bf, s)
                 dW_all = torch.empty(384, 192, **f32)
                 call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 192, ptr(dW_all), 192, 0, s)
@@ -360,7 +364,8 @@ class ConvGRUDecoder(nn.Module):
         PW = call("df_gru_lean_partial_width")
         partial = torch.zeros(nblocks, PW, **f32)
         # data gradients: the forward's h-side GEMMs against the transposed weights + the recompute of the three gates
-        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * 2 + 24.0)):
+        with ops.timed("gru_bwd", flops=B * N * (589824.0 * T / 4 + 12870.0), bytes=B * N * (512.0 * 2 + 24.0),
+                       moved=B * N * (512.0 * (T + 1 + 4 * T + 1) + 24.0 + 128.0)):    # T + 1 planes in, 4 T planes + dh0 (+ dpre1) out
             call("df_gru_lean_bwd", ptr(dflow), ptr(ps.offs), ptr(ps.counts), B, N, T, W, WT, ptr(hs.df_xtab), ptr(hs), ptr(gpl),
                  ptr(dh0), ptr(dpre1), ptr(partial), mode, s)
         sums = torch.empty(PW, **f32)
@@ -382,7 +387,8 @@ class ConvGRUDecoder(nn.Module):
             s = stream()  # the side stream inside the fork
             nsplit = call("df_gru_wgrad_splits")
             ws = torch.empty(nsplit, 384, 128, **f32)
-            with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=B * N * T * 4.0 * (384 + 192)):
+            with ops.timed("gru_wgrad", flops=2.0 * 384 * 192 * B * N * T, bytes=3.0 * 128 * 192 * 4,
+                           moved=B * N * T * 4.0 * (384 + 256)):      # 3 gate-gradient planes + h_in + r*h per step
                 call("df_gru_lean_wgrad", ptr(hs), ptr(gpl), ptr(ps.counts), B, N, T, ptr(ws), nsplit, 3 if x2 else (1 if bf else 0), s)
             dW_all = torch.empty(384, 192, **f32)
             call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 128, ptr(dW_all), 192, 0, s)

@@ -4,7 +4,8 @@ model plugin ([REF README.md:88]: "python eval.py checkpoint=... av2_mode=val  #
 -> the scene files under ``<dataset_path>/val``; ``val_data=<dir>`` names the directory directly).
 
 The checkpoint carries its training configuration (``hyper_parameters``, as Lightning checkpoints do), so only the
-checkpoint and the data need naming.  Metrics: deflow_amd/metrics.py (EPE, accuracy, 3-way EPE) averaged over the sweeps
+checkpoint and the data need naming.  Metrics: deflow_amd/metrics.py -- ``leaderboard_version=1`` (default) the Argoverse-2 three-way
+EPE table, ``leaderboard_version=2`` the bucketed normalised EPE; plus a range-free EPE / accuracy summary -- over the sweeps
 of ``val_data`` (preprocessed scene files, deflow_amd/data.py) or over seeded synthetic pairs with ``val_data=synthetic``.
 ``av2_mode=test`` (leaderboard submission zips) is the reference's control plane and is not built."""
 from __future__ import annotations
@@ -54,7 +55,11 @@ def main(argv=None):
     assert torch.cuda.is_available(), "evaluation runs on the HIP engine only"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    from .metrics import evaluate_batch
+    from .metrics import OfficialMetrics, evaluate_batch
+    version = int(given.get("leaderboard_version", "leaderboard_version=1").split("=", 1)[1])
+    if version not in (1, 2):
+        raise SystemExit("leaderboard_version must be 1 (three-way EPE) or 2 (bucketed normalised EPE)")
+    official = OfficialMetrics()
     model = build_model(cfg).to(dev)
     res = model.load_from_checkpoint(path)
     if res.missing_keys or res.unexpected_keys:   # strict=False as the reference loads [REF deflow.py:47] -- but never silently
@@ -77,13 +82,20 @@ def main(argv=None):
     tot, wsum = {}, {}
     with torch.no_grad():
         for batch in batches:
-            m = evaluate_batch(model(batch), batch)
+            m = evaluate_batch(model(batch), batch, official)
             w = len(batch["pose0"])
             for k, v in m.items():
                 tot[k] = tot.get(k, 0.0) + v * w
                 wsum[k] = wsum.get(k, 0) + w
     out = {k: tot[k] / wsum[k] for k in tot}
-    print(json.dumps({"checkpoint": path, "model": cfg["model"], "val_data": cfg["val_data"], "metrics": out}), flush=True)
+    # the leaderboard table the reference prints at the end of validation [REF README.md:88-91]: leaderboard_version=1 the three-way
+    # EPE (+ IoU, accuracies, angle error inside the 35 m box), leaderboard_version=2 the bucketed normalised EPE
+    board = official.result(version)
+    print(official.table(version), file=sys.stderr, flush=True)
+    print(json.dumps({"checkpoint": path, "model": cfg["model"], "val_data": cfg["val_data"], "metrics": out,
+                      "leaderboard_version": version, "leaderboard": board}), flush=True)
+    out = dict(out)
+    out["leaderboard"] = board
     return out
 
 

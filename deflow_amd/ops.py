@@ -29,15 +29,16 @@ class KernelProfiler:
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (kernel / stage name, algorithmic flops, start event, end event, layer tag[, algorithmic bytes])
+        self.records = []  # (kernel / stage name, algorithmic flops, start event, end event, layer tag[, algorithmic bytes[, moved bytes]])
 
     def summary(self):
         out = {}
         for name, flops, e0, e1, _tag, *rest in self.records:
-            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0, "moved": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += rest[0] if rest else 0.0
+            d["moved"] += rest[1] if len(rest) > 1 else 0.0
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -80,10 +81,11 @@ class mfma_bf16:
 class timed:
     """with ops.timed("stage", bytes=..., flops=...): HIP events around a launch (or a short chain of launches) on the current
     stream when a KernelProfiler is installed; free otherwise.  `bytes` / `flops` are the ALGORITHMIC figures of DESIGN.md
-    section 4 (what the stage has to move / compute), not what the implementation happens to do."""
+    section 4 (what the stage has to move / compute), not what the implementation happens to do; `moved` (optional) = the bytes the
+    implementation is KNOWN to stream through HBM by construction (e.g. the GRU kernels' saved planes), reported beside them."""
 
-    def __init__(self, name: str, bytes: float = 0.0, flops: float = 0.0, tag: str = ""):
-        self.name, self.bytes, self.flops, self.tag = name, float(bytes), float(flops), tag
+    def __init__(self, name: str, bytes: float = 0.0, flops: float = 0.0, tag: str = "", moved: float = 0.0):
+        self.name, self.bytes, self.flops, self.tag, self.moved = name, float(bytes), float(flops), tag, float(moved)
         self.prof = PROFILER
 
     def __enter__(self):
@@ -95,7 +97,7 @@ class timed:
     def __exit__(self, *exc):
         if self.prof is not None and exc[0] is None:
             self.e1.record()
-            self.prof.records.append((self.name, self.flops, self.e0, self.e1, self.tag, self.bytes))
+            self.prof.records.append((self.name, self.flops, self.e0, self.e1, self.tag, self.bytes, self.moved))
         return False
 
 

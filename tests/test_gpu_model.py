@@ -1117,6 +1117,72 @@ def test_config0_fastflow3d_ff3dloss_bs1_from_scene_files(dev, tmp_path, capsys)
     assert "mismatch" not in cap.err and abs(m3["EPE"] - m["EPE"]) < 1e-6
 
 
+@pytest.mark.parametrize("version", [1, 2])
+def test_eval_leaderboard_tables_vs_oracle(dev, tmp_path, capsys, version):
+    """Row N3: ``python -m deflow_amd.eval checkpoint=... av2_mode=val leaderboard_version=1|2`` [REF README.md:88-91;
+    assets/slurm/2_eval.sh:33-35] on labelled scene files: every number of the leaderboard table (three-way EPE / IoU / accuracies /
+    angle error inside the 35 m box; bucketed normalised EPE per meta-class) against oracle/ref_metrics.py evaluated on the ORACLE
+    model's flow (oracle/ref_torch.py, same weights, same sweeps, CPU).  The flows agree to ~1e-5, so do the tables."""
+    import json
+    import shutil
+    from deflow_amd import eval as E
+    from deflow_amd.data import HDF5Dataset, collate_fn_pad
+    from oracle import ref_metrics as R
+    from oracle import ref_torch as O
+    # tests/golden/av2_mini/val (gen_h5_val_fixture.py): labels consistent with the ego motion, every meta-class and speed bucket,
+    # points on both sides of the 35 m range, unlabelled points, an eval_mask dataset
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "av2_mini", "val")
+    val = tmp_path / "sensor" / "val"
+    shutil.copytree(src, val)
+    cfg = dict(voxel_size=[0.4, 0.4, 6], point_cloud_range=[-51.2, -51.2, -3, 51.2, 51.2, 3], grid_feature_size=[256, 256],
+               decoder_option="gru", num_iters=2)
+    torch.manual_seed(77)
+    ref = O.DeFlow(**cfg).eval()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.6, 1.4); m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.5)
+    ck = tmp_path / "model.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in ref.state_dict().items()},
+                "hyper_parameters": {"cfg": {"model": {"name": "deflow", "target": {"num_iters": 2, "decoder_option": "gru"}},
+                                             "voxel_size": [0.4, 0.4, 6], "point_cloud_range": cfg["point_cloud_range"], "batch_size": 4}}}, ck)
+    out = E.main([f"checkpoint={ck}", "av2_mode=val", f"dataset_path={tmp_path / 'sensor'}", "num_workers=0", "batch_size=4",
+                  f"leaderboard_version={version}"])
+    cap = capsys.readouterr()
+    line = json.loads([l for l in cap.out.splitlines() if l.startswith("{")][-1])
+    assert line["leaderboard_version"] == version and ("Three-way" if version == 1 else "mean/Dynamic") in line["leaderboard"]
+    assert ("Three-way" if version == 1 else "WHEELED_VRU") in cap.err          # the printed table
+    # the oracle: same sweeps through the CPU model, metrics by the numpy restatement
+    ds = HDF5Dataset(str(val))
+    om = R.OfficialMetrics()
+    with torch.no_grad():
+        for i0 in range(0, len(ds), 4):
+            batch = collate_fn_pad([ds[i] for i in range(i0, min(i0 + 4, len(ds)))])
+            res = ref(batch)
+            for b in range(len(res["flow"])):
+                vi = res["pc0_valid_point_idxes"][b]
+                pf = res["pose_flow"][b][vi]
+                a = [(pf + res["flow"][b]).double().numpy(), pf.double().numpy(), batch["pc0"][b][vi].double().numpy(),
+                     batch["flow"][b][vi].double().numpy(), (batch["flow_is_valid"][b][vi] & batch["eval_mask"][b][vi]).numpy(),
+                     batch["flow_category_indices"][b][vi].numpy()]
+                om.step(R.evaluate_leaderboard(*a), R.evaluate_leaderboard_v2(*a))
+    want, got = om.result(version), out["leaderboard"]
+    assert set(want) == set(got)
+    n_checked = 0
+    for k, w in want.items():
+        g = got[k]
+        if isinstance(w, float) and np.isnan(w):
+            assert np.isnan(g), k
+            continue
+        assert abs(g - w) <= 1e-3 * max(1.0, abs(w)), (k, g, w)       # flows differ by ~1e-5; thresholded counts by at most a point
+        n_checked += 1
+    # the fixture fills every cell of both tables except BACKGROUND/Dynamic (unlabelled points do not move)
+    assert n_checked == len(want) - (1 if version == 2 else 0) and (version == 1 or np.isnan(want["BACKGROUND/Dynamic"]))
+    if version == 1:
+        assert got["n"] == want["n"] and got["n"] > 1000
+
+
 def test_gradient_clipping_matches_clip_grad_norm(dev):
     """Trainer(gradient_clip_val=c) = torch.nn.utils.clip_grad_norm_(params, c) before Adam: parameters after two steps vs the
     oracle trained with torch's own clipping"""
