@@ -32,6 +32,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "frame-pairs/sec training (deflow, bs=16, 512x512 BEV)"
+WORKLOAD = "deflow train step (deflowLoss, Adam lr=2e-4): BASELINE configs[2] per GPU"      # the same strings at every N (SCALE vs BENCH)
 PER_GPU_BATCH = 16
 N_POINTS = 80000
 GRID = 512
@@ -206,9 +208,13 @@ def dry_run(args, rank, world):
     ids = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(ids, t)
     if rank == 0:
-        print(json.dumps({"metric": "frame-pairs/sec training (deflow, bs=16, 512x512 BEV)", "dry_run": True, "value": None,
+        print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "unit": "frame-pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": [int(x.item()) for x in ids],
-                          "allreduce_sum_ok": bool(float(g[0]) == world), "ms_per_step": float(dt.item()) / args.steps * 1e3}), flush=True)
+                          "allreduce_sum_ok": bool(float(g[0]) == world), "ms_per_step": float(dt.item()) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak",
+                          "config": {"workload": WORKLOAD, "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                                     "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS, "parallelism": f"dp{world}"}}),
+              flush=True)
     dist.destroy_process_group()
 
 
@@ -299,6 +305,34 @@ def main():
     exposed = None
     bf16_multi = None
     graph_multi = None
+    buckets = None
+    one_bucket = None
+    if use_dist and trainer.collective and not args.no_extras:
+        # the gradient collectives of one eager step, bucket by bucket (after the timed region): arena range, bytes, issue ->
+        # complete on the device clock.  A first 8-GPU run that scales badly can then be read from this one line: which bucket is
+        # late, how long each is in flight, how much of the last one sticks out behind the backward
+        try:
+            trainer.sink.trace_on(True)
+            for _ in range(2):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            buckets = trainer.sink.trace_report()
+        except Exception as e:      # noqa: BLE001
+            buckets = {"error": f"{type(e).__name__}: {e}"[:300]}
+        trainer.sink.trace_on(False)
+        # fallback leg: no bucketing, ONE all-reduce of the whole arena after the backward (DF_ONE_BUCKET=1 makes it the default)
+        try:
+            prev = trainer.sink.one_bucket
+            trainer.sink.one_bucket = True
+            trainer.step(batch)
+            dt1, _, _ = timed_steps(args.steps)
+            t1_ = torch.tensor([dt1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t1_, op=dist.ReduceOp.MAX)
+            one_bucket = {"ms_per_step": float(t1_.item()) / args.steps * 1e3, "bytes": trainer.flat.numel * 4,
+                          "note": "the same step with DF_ONE_BUCKET=1: one all-reduce of the whole gradient arena after the backward, nothing overlapped"}
+            trainer.sink.one_bucket = prev
+        except Exception as e:      # noqa: BLE001
+            one_bucket = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world > 1 and not args.no_extras:
         # BASELINE configs[4] ("bf16 MFMA, 8xMI355X"): the same data-parallel step with dtype=bf16, collectives on, timed the same way
         trainer.mfma_bf16 = True
@@ -359,7 +393,7 @@ def main():
 
     ms = dt / args.steps * 1e3
     out = {
-        "metric": "frame-pairs/sec training (deflow, bs=16, 512x512 BEV)",
+        "metric": METRIC,
         "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -371,7 +405,7 @@ def main():
                        "activations / gradients are STORED as those planes, 4 bytes per element), GRU decoder bf16x2 "
                        "(2 bf16 planes, 3 MFMAs), other layers fp32 MFMA or fp16x2 on fragments; strict_fp32 / gru_fp32 = the same step with those forms off" if (os.environ.get("DF_CONV_X3", "1") != "0" or os.environ.get("DF_GRU_X2", "1") != "0")
                        else "f32 tensors, accumulation and MFMA operands"),
-        "config": {"workload": "deflow train step (deflowLoss, Adam lr=2e-4): BASELINE configs[2] per GPU", "per_gpu_batch": args.batch,
+        "config": {"workload": WORKLOAD, "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
                    "parallelism": f"dp{world}", "loss": float(loss)},
     }
@@ -382,6 +416,13 @@ def main():
         out["per_rank_ms_per_step"] = {"min": min(float(x[0]) for x in per_rank), "max": max(float(x[0]) for x in per_rank)}
     if exposed is not None:
         out["allreduce_exposed_ms"] = exposed
+    if buckets is not None:
+        out["allreduce_buckets"] = buckets
+    if one_bucket is not None:
+        out["one_bucket"] = one_bucket
+    if use_dist:
+        out["collectives"] = {"backend": "gloo (test hook)" if share_gpu else "nccl (RCCL)", "one_bucket_default": bool(trainer.sink.one_bucket),
+                              "arena_bytes": trainer.flat.numel * 4, "ranks": world}
     if share_gpu:
         out["collective_backend"] = "gloo, all ranks on cuda:0 (DF_BENCH_SHARE_GPU test hook: not a measurement)"
     if bf16_multi is not None:

@@ -168,8 +168,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       dec(m0, n_, oy_, ox_);
       bgrp = n_ / p.y.grp_size;           // statistic group of this tile (a tile never straddles two)
     }
-    auto body = [&](auto y_tag) {
+    // FULL (round 5): every row of the tile is inside the tensor (m0 + BM <= m_end -- all of this network's layers), so no element
+    // needs its "row exists" test.  With the tests, the 64 per-element conditions of a wave (64-bit lane masks) did not fit the
+    // scalar registers: they were spilled to VGPR lanes and every masked sum / max cost two v_readlane + a v_cndmask on top of its
+    // arithmetic -- ~13 of the ~32 VALU instructions per output element of the fp16x2 epilogue (ISA count, conv_halo_x3p_kernel<512,64>),
+    // while the epilogue is the part of a tile in which no wave of the workgroup issues MFMAs.
+    auto body = [&](auto y_tag, auto full_tag) {
       constexpr int YT = decltype(y_tag)::value;
+      constexpr bool FULL = decltype(full_tag)::value;
       constexpr bool Y16 = YT == 1, YH2 = YT == 2;
       constexpr int ESZ = Y16 ? 2 : 4;
       float sy = 1.f;
@@ -195,8 +201,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            if constexpr (YH2) ob[e] = off >= 0 ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
-            else ob[e] = off >= 0 ? (unsigned)((off + co) * ESZ) : ROW_BAD;
+            if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
+            else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
           }
           float old[16];
           if constexpr (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
@@ -233,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             } else {
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
             }
-            if (ob[e] != ROW_BAD) {
+            if (FULL || ob[e] != ROW_BAD) {
               if constexpr (bws) {
                 const float g = v * df_gelu_grad(fmaf(old[e], b_sc, b_sh));
                 s1 += g;
@@ -257,9 +263,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         }
       }
     };
-    if (p.y.elt == 2) body(std::integral_constant<int, 2>{});
-    else if (p.y.elt == 1) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 0>{});
+    const bool full = m0 + BM <= m_end;      // (workgroup-uniform)
+    if (full) {
+      if (p.y.elt == 2) body(std::integral_constant<int, 2>{}, std::true_type{});
+      else if (p.y.elt == 1) body(std::integral_constant<int, 1>{}, std::true_type{});
+      else body(std::integral_constant<int, 0>{}, std::true_type{});
+    } else {
+      if (p.y.elt == 2) body(std::integral_constant<int, 2>{}, std::false_type{});
+      else if (p.y.elt == 1) body(std::integral_constant<int, 1>{}, std::false_type{});
+      else body(std::integral_constant<int, 0>{}, std::false_type{});
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

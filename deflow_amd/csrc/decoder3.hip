@@ -11,6 +11,16 @@
 #include "common.h"
 #include "gemm_dma.h"
 
+// occupancy knobs of the forward kernel for the register-file experiment of tools/pfn_race_probe10.sh (defaults = the shipped kernel)
+#ifndef DF_GRU_LB
+#define DF_GRU_LB 2
+#endif
+#ifdef DF_GRU_NUM_VGPR
+#define DF_GRU_ATTR __attribute__((amdgpu_num_vgpr(DF_GRU_NUM_VGPR)))
+#else
+#define DF_GRU_ATTR
+#endif
+
 namespace {
 
 using namespace gd;
@@ -30,7 +40,7 @@ struct Gru3Params {
 // W16 (with BF): the gate / head weights p.w.{w_zr, w_q, w_1} point at bf16 copies (gemm_dma.h, WStreamT<2>)
 // X2 (fp32 training, mfma_bf16 == 3): the same pointers hold the pre-split two-plane weights of WStreamT<3>; planes saved fp32
 template <bool SAVE, bool BF = false, bool W16 = false, bool X2 = false>
-__global__ __launch_bounds__(256, 2) void gru_fwd3_kernel(Gru3Params p) {
+__global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd3_kernel(Gru3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
   __shared__ __attribute__((aligned(16))) float As[4 * 16 * LDH];   // 33.8 KB

@@ -22,6 +22,16 @@
 #include "common.h"
 #include "gemm_dma.h"
 
+// occupancy knobs of the forward kernel for the register-file experiment of tools/pfn_race_probe10.sh (defaults = the shipped kernel)
+#ifndef DF_GRU_LB
+#define DF_GRU_LB 2
+#endif
+#ifdef DF_GRU_NUM_VGPR
+#define DF_GRU_ATTR __attribute__((amdgpu_num_vgpr(DF_GRU_NUM_VGPR)))
+#else
+#define DF_GRU_ATTR
+#endif
+
 namespace {
 
 using namespace gd;
@@ -103,7 +113,7 @@ __device__ __forceinline__ void offs_to_lds(float* Ow, const float* offs, int64_
 }
 
 template <bool SAVE, int MODE>
-__global__ __launch_bounds__(256, 2) void gru_fwd4_kernel(Gru4Params p) {
+__global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd4_kernel(Gru4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool BF = MODE == 1 || MODE == 2, W16 = MODE == 2, X2 = MODE == 3;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
@@ -482,31 +492,23 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
     float* pl_dr = p.gplanes + 1 * p.plane_stride + it * p.iter_stride;
     float* pl_dq = p.gplanes + 2 * p.plane_stride + it * p.iter_stride;
     float* pl_rh = p.gplanes + 3 * p.plane_stride + it * p.iter_stride;
-    f32x4 h[8], z[8], q[8];
-    const unsigned cl_off = (4 * lq * 128 + li) * 4;
+    f32x4 h[8], z[8], q[8], r[8];
     // (the last GEMM's closing barrier is behind every wave: the A region is free)
     rows_to_lds(p.hsave + it * p.iter_stride, BF);
     wave_lds_sync();
     // ---- recompute the gates [REF decoder.py:126-139] ----
     xinit(z, 0);
     gemm<128, 4, false, 128>(w_z, 0, w_r, 0, a_lane, xf, ws, z);
-    {
-      f32x4 r[8];
-      xinit(r, 1);
-      gemm<128, 4, false, 128>(w_r, 0, w_q, 0, a_lane, xf, ws, r);
-      lds_to_c(h);
-      // r is needed again only after two more GEMMs: park it in the (not yet written) dr_pre plane, element for element where this
-      // lane reads it back -- five live 32-register planes instead of four is what spills
-      const rsrc_t pr = make_rsrc(pl_dr + grow0 * 128, row_bytes);
+    xinit(r, 1);
+    gemm<128, 4, false, 128>(w_r, 0, w_q, 0, a_lane, xf, ws, r);
+    lds_to_c(h);
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float rr = df_sigmoid_fast(r[t][k]);
-          buf_st1(pr, cl_off + (k * 128 + 16 * t) * 4, rr);
-          c_lane[k * LDH + 16 * t] = rr * h[t][k];
-        }
-    }
+      for (int k = 0; k < 4; ++k) {
+        r[t][k] = df_sigmoid_fast(r[t][k]);
+        c_lane[k * LDH + 16 * t] = r[t][k] * h[t][k];
+      }
     wave_lds_sync();
     lds_to_plane(pl_rh);
     xinit(q, 2);
@@ -532,11 +534,6 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
     colsum(2);
     {
       f32x4 drh[8];
-      const rsrc_t pr = make_rsrc(pl_dr + grow0 * 128, row_bytes);
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) z[t][k] = buf_ld1(pr, cl_off + (k * 128 + 16 * t) * 4);   // z <- r (rows past the count: 0)
 #pragma unroll
       for (int t = 0; t < 8; ++t) drh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       gemm<128, 4, false, 128, 128, 256>(wt_q, 0, wt_zr + 128 / CSC, 0, a_lane, xf, ws, drh);
@@ -544,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
       for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float d = drh[t][k], rr = z[t][k];
+          const float d = drh[t][k], rr = r[t][k];
           dh[t][k] += d * rr;
           q[t][k] = d * h[t][k] * rr * (1.f - rr);   // dr_pre
         }

@@ -93,10 +93,36 @@ class GradSink:
         self.delivered = set()
         self.works: list = []
         self.cap: Optional["SegmentedCapture"] = None   # set while Trainer.capture records the step
+        # DF_ONE_BUCKET=1 (or .one_bucket = True): no bucketing -- the phases only copy, ONE all-reduce over the whole arena goes out
+        # after the backward (nothing overlapped): the fallback / A-B leg of the first multi-GPU runs
+        self.one_bucket = os.environ.get("DF_ONE_BUCKET") == "1"
+        # trace_on(): per-bucket record of an eager step -- arena range, bytes, issue -> complete times on the device -- without
+        # changing the step's own ordering (a probe stream waits for each collective and drops an event)
+        self.trace: Optional[list] = None
+        self._probe = None
+        self._t0 = None
 
     def begin(self):
         self.delivered.clear()
         self.works.clear()
+        if self.trace is not None:
+            self.trace.clear()
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
+
+    def trace_on(self, on: bool = True):
+        self.trace = [] if on else None
+        if on and self._probe is None and self.flat.grad.is_cuda:
+            self._probe = torch.cuda.Stream(device=self.flat.grad.device)
+
+    def trace_report(self) -> list:
+        """after a traced step (and a device synchronize): one dict per collective in issue order -- arena range, bytes, when it was
+        issued / completed relative to the start of the step (ms, device clock) and how long it was in flight"""
+        out = []
+        for lo, hi, e_issue, e_done in (self.trace or []):
+            out.append({"arena_range": [lo, hi], "bytes": (hi - lo) * 4, "issued_ms": self._t0.elapsed_time(e_issue),
+                        "completed_ms": self._t0.elapsed_time(e_done), "in_flight_ms": e_issue.elapsed_time(e_done)})
+        return out
 
     def deliver(self, params, grads):
         dsts, srcs, slots = [], [], []
@@ -118,7 +144,7 @@ class GradSink:
         torch._foreach_copy_(dsts, srcs)
         if self.cap is not None:
             self.cap.touch()
-        if self.collective:
+        if self.collective and not self.one_bucket:
             slots.sort()
             lo, hi = slots[0][0], slots[0][0] + slots[0][1]
             runs = []
@@ -138,6 +164,16 @@ class GradSink:
             self.cap.emit(("allreduce", list(runs)))
             return
         for lo, hi in runs:
+            if self.trace is not None and self._probe is not None:
+                e_issue, e_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_issue.record()
+                w = self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True)
+                with torch.cuda.stream(self._probe):     # the probe stream (only) waits for this collective
+                    w.wait()
+                    e_done.record()
+                self.trace.append((lo, hi, e_issue, e_done))
+                self.works.append(w)
+                continue
             self.works.append(self.dist.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
 
     def was_delivered(self, p) -> bool:
@@ -294,7 +330,7 @@ class Trainer:
         """Sum the gradient arena over the data-parallel ranks (ONE collective over 27.6 MB); returns the scale that
         turns the sum into DDP's mean (folded into the Adam kernel instead of a separate divide pass)."""
         if self.collective:
-            if self.sink.delivered:   # bucketed, already in flight; then whatever did not go through the sink
+            if self.sink.delivered and not self.sink.one_bucket:   # bucketed, already in flight; then whatever did not go through the sink
                 rest = sorted(self.sink.slot_of[p.data_ptr()] for p in self.flat.params if not self.sink.was_delivered(p))
                 if rest:
                     if self.sink.cap is not None:

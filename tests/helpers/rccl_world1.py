@@ -51,6 +51,25 @@ def run(force: bool):
         assert kinds.count("graph") >= 6 and kinds[-2:] == ["wait", "graph"], kinds
         assert torch.equal(t2.flat.param, tr.flat.param) and float(lg) == float(loss.detach()), "captured RCCL program != eager"
         print(f"RCCL_WORLD1_GRAPH_OK segments={kinds.count('graph')}")
+        # the per-bucket trace bench.py reports at N > 1 (optim.GradSink.trace_on) and the DF_ONE_BUCKET fallback, over RCCL:
+        # tracing must not change the step; one bucket must give the bits of the bucketed step (a 1-rank sum is the identity)
+        torch.manual_seed(0)
+        m3 = deflow_amd.DeFlow(grid_feature_size=[128, 128], point_cloud_range=[-12.8, -12.8, -3, 12.8, 12.8, 3],
+                               num_iters=2).to(dev).train()
+        t3 = Trainer(m3, lr=2e-4)
+        t3.sink.trace_on(True)
+        t3.step(batch)
+        torch.cuda.synchronize()
+        rep = t3.sink.trace_report()
+        assert len(rep) >= 4 and all(r["completed_ms"] >= r["issued_ms"] >= 0 and r["in_flight_ms"] >= 0 for r in rep), rep
+        assert 0.9 * t3.flat.numel * 4 <= sum(r["bytes"] for r in rep) <= t3.flat.numel * 4
+        assert all(a["issued_ms"] <= b["issued_ms"] for a, b in zip(rep, rep[1:]))
+        t3.sink.trace_on(False)
+        t3.sink.one_bucket = True
+        t3.step(batch)
+        torch.cuda.synchronize()
+        assert torch.equal(t3.flat.param, tr.flat.param), "traced + one-bucket steps != the bucketed eager steps"
+        print(f"RCCL_WORLD1_TRACE_OK buckets={len(rep)} in_flight_ms={[round(r['in_flight_ms'], 3) for r in rep]}")
     return tr.flat.param.clone(), tr.flat.grad.clone(), float(loss.detach()), issued
 
 

@@ -53,3 +53,22 @@ def test_without_a_gpu_the_real_run_stops_at_the_cuda_check():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert "there is no CPU fallback" in r.stderr and "WORLD_SIZE" not in r.stderr.split("AssertionError")[-1]
+
+
+def test_dry_run_world8_line_carries_the_n1_strings():
+    """the N > 1 line must be mechanically comparable with the N = 1 line (SCALE vs BENCH): same `metric`, same `config.workload`,
+    the contract's keys, global batch = 8 x the per-GPU batch"""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = _run("--gpus", "8", "--steps", "2", "--warmup", "0", "--dry-run", timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["metric"] == bench.METRIC and out["config"]["workload"] == bench.WORKLOAD
+    assert out["n_gpus"] == 8 and out["ranks"] == list(range(8)) and out["config"]["global_batch"] == 8 * bench.PER_GPU_BATCH
+    assert out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["unit"] == "frame-pairs/s" and out["allreduce_sum_ok"]
+    # the strings are module constants used by the real (GPU) line too
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count('"metric": METRIC') >= 2 and src.count('"workload": WORKLOAD') >= 2

@@ -62,6 +62,18 @@ def _worker(rank, world, port, q):
     tr.reduce_gradients()
     sink_err = float((tr.flat.grad - want_sink).abs().max())
     all_delivered = all(tr.sink.was_delivered(p) for p in model.parameters())
+    # DF_ONE_BUCKET fallback (GradSink.one_bucket): the phases only copy, ONE all-reduce over the whole arena after the last one
+    tr.flat.zero_grad()
+    tr.sink.begin()
+    tr.sink.one_bucket = True
+    tr.sink.deliver(model.head.parameters(), gd)
+    tr.sink.deliver([p for p in bb.parameters()], gd)
+    one_works_mid = len(tr.sink.works)
+    tr.sink.deliver(list(model.parameters()), gd)
+    tr.reduce_gradients()
+    tr.sink.one_bucket = False
+    one_err = float((tr.flat.grad - want_sink).abs().max())
+    sink_err = max(sink_err, one_err + (1.0 if one_works_mid != 0 else 0.0))
     # parameter views see the arena; gradient views alias the gradient arena
     w = model.backbone.decoder_step4.weight
     alias_ok = w.grad.data_ptr() >= tr.flat.grad.data_ptr() and w.data_ptr() >= tr.flat.param.data_ptr()

@@ -972,7 +972,7 @@ def test_rccl_collective_path_on_a_one_rank_group():
                         os.path.join(root, "tests", "helpers", "rccl_world1.py")],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-3000:])
-    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout and "RCCL_WORLD1_GRAPH_OK" in r.stdout
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout and "RCCL_WORLD1_GRAPH_OK" in r.stdout and "RCCL_WORLD1_TRACE_OK" in r.stdout
 
 
 def test_training_from_scene_files(dev, tmp_path, capsys):
@@ -1441,6 +1441,13 @@ def test_bench_two_ranks_share_the_gpu(dev):
     assert d["rccl_selfcheck"]["params_bit_identical_across_ranks_after_warmup"] is True and d["rccl_selfcheck"]["steps_checked"] == 1
     assert 0 < d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.05
     assert "allreduce_exposed_ms" in d and math.isfinite(d["allreduce_exposed_ms"])
+    # first-8-GPU-run diagnostics: the collectives of one step bucket by bucket, and the one-bucket fallback leg
+    bk = d["allreduce_buckets"]
+    assert isinstance(bk, list) and len(bk) >= 4 and all(b["bytes"] > 0 and b["completed_ms"] >= b["issued_ms"] for b in bk), bk
+    assert 0.9 * d["collectives"]["arena_bytes"] <= sum(b["bytes"] for b in bk) <= d["collectives"]["arena_bytes"]
+    assert d["one_bucket"]["ms_per_step"] > 0 and d["one_bucket"]["bytes"] == d["collectives"]["arena_bytes"] and d["collectives"]["ranks"] == 2
+    import bench as _bench
+    assert d["metric"] == _bench.METRIC and d["config"]["workload"] == _bench.WORKLOAD
     assert math.isfinite(d["config"]["loss"]) and math.isfinite(d["bf16_training"]["loss"])
     assert d["bf16_training"]["pairs_per_s"] > 0      # (two ranks SHARING one GPU, the bf16 leg with the kernel profiler on: not a measurement)
     assert (d["roofline"]["kernel"].startswith("conv_") or d["roofline"]["kernel"].startswith("wgrad")) and "cpu_baseline" not in d and "forward_only" not in d
