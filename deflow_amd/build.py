@@ -128,4 +128,7 @@ def build_probe(verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))
-    print(build_probe(verbose=True))
+    try:
+        print(build_probe(verbose=True))
+    except RuntimeError as e:   # the probe is a measuring tool: a failure there must not fail the library build
+        print("warning:", e)

@@ -299,9 +299,22 @@ class WeightPrep:
         self.bias_of = {m.bias.data_ptr(): self.layer[w.data_ptr()][0] for w, m in zip(ws, self.convs) if m.bias is not None}
         self._anchor = torch.empty(0, dtype=torch.float32, device=dev)
 
+    def stale(self) -> bool:
+        """True when a conv parameter no longer lives where the table says (model.to(), load_state_dict(assign=True), p.data = ...):
+        the table holds raw addresses, so the caller must rebuild the WeightPrep before running it"""
+        for m in self.convs:
+            e = self.layer.get(m.weight.data_ptr())          # (the OHWI view of a channels_last weight starts at the same address)
+            co, ci, kh, kw = m.weight.shape
+            if e is None or e[3] != (co, kh, kw, ci):
+                return True
+            if m.bias is not None and m.bias.data_ptr() not in self.bias_of:
+                return True
+        return False
+
     def run(self, w_amax: torch.Tensor):
         """(re)compute every form for the current parameter values"""
         import ctypes
+        assert not self.stale(), "WeightPrep: a conv parameter moved since the table was built -- rebuild it (Trainer does: _wprep)"
         self.w_amax = w_amax
         self.norms.zero_()
         call("df_weight_prep", ctypes.c_void_p(self.base), ptr(self.table), self.nl, self.total_blocks, ptr(w_amax), ptr(self.out), ptr(self.norms),

@@ -479,6 +479,8 @@ class Trainer:
             backbone = getattr(model, "backbone", None)
             if backbone is not None and os.environ.get("DF_WPREP", "1") != "0":
                 wp = getattr(self, "_wprep", None)
+                if wp and wp.stale():      # a parameter was re-assigned since the table of raw addresses was built
+                    wp = None
                 if wp is None:
                     convs = [m for m in backbone.modules() if isinstance(m, torch.nn.Conv2d)]
                     wp = self._wprep = ops.WeightPrep(convs, wa) if convs else False

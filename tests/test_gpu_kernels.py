@@ -961,7 +961,8 @@ def test_conv_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, mode):
     # (K = 9 x 256 terms: the fp32 accumulation's own rounding reaches 2-3e-6 of the largest output -- the fp32-MFMA kernel measures
     # 3.2e-6 there -- and which side of 2e-6 the bf16x3 form lands on depends on the order of the tap rows: rotated order 2.2e-6,
     # plain order 1.7e-6.  Bound: 2e-6, or the fp32-MFMA kernel's own error on the same operands where that is larger.)
-    lim = max(2e-6, outs["fp32"])
+    # (capped -- a regression of the fp32-MFMA kernel, or of staging / epilogue code all three forms share, must not loosen it)
+    lim = min(4e-6, max(2e-6, outs["fp32"]))
     assert outs["x3"] <= lim and outs["h2"] <= lim, outs
 
 
