@@ -593,14 +593,17 @@ def _load_head(cls, g, dev, **kw):
     return m.to(dev)
 
 
+@pytest.mark.parametrize("form", ["lean_ws", "lean", "full"])   # round 5: weight-stationary forward / weight-streaming lean kernels / round 4's
 @pytest.mark.parametrize("iters", [1, 4, 8, 16])       # 16: [REF assets/slurm/1_train.sh:50] (model.target.num_iters=16 ablation)
-def test_gru_decoder_golden(dev, golden_dir, iters):
+def test_gru_decoder_golden(dev, golden_dir, iters, form, monkeypatch):
     """REAL reference vectors: ConvGRUDecoder forward + all gradients ([REF decoder.py:141-199]).  Each tensor is measured
     against the reference executed in float64 on the same weights / inputs (oracle/gen_golden_f64.py) and must satisfy
     err(HIP, fp64) <= max(1e-4, 4 x err(reference fp32, fp64)) -- the north-star tolerance, forward and backward."""
     import os
     import parity
     from deflow_amd.decoder import ConvGRUDecoder
+    monkeypatch.setenv("DF_GRU_LEAN", "0" if form == "full" else "1")
+    monkeypatch.setenv("DF_GRU_WS", "1" if form == "lean_ws" else "0")
     g = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}.npz")))
     g64 = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}_f64.npz")))
     t = lambda a: torch.from_numpy(a)
@@ -610,7 +613,7 @@ def test_gru_decoder_golden(dev, golden_dir, iters):
     infos = [{"voxel_coords": t(g[f"vc{i}"]), "point_offsets": t(g[f"off{i}"])} for i in range(3)]
     flows = m(before, after, infos)
     assert [f.shape[0] for f in flows] == [333, 0, 1]
-    tag = f"gru_golden_it{iters}"
+    tag = f"gru_golden_it{iters}" + ("" if form == "lean_ws" else "_" + form)
     for i in (0, 2):
         parity.three_way(tag, f"flow{i}", flows[i], t(g[f"flow{i}"]), t(g64[f"flow{i}"]))
     loss = sum((f * t(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows))
