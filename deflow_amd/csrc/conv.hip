@@ -3955,8 +3955,14 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   }
   DF_REQUIRE(x.elt == 0, DF_E_ARG);
   switch (var) {
-    case 128032: return launch_conv<128, 32, 4, 1>(p, s);
-    case 64064: return launch_conv<64, 64, 2, 2>(p, s);
+    // (round 5: the small tiles chosen for layers with few pixels -- a B = 1 forward -- ran on the fp32 MFMA whatever the caller asked
+    // for: launch_conv has no fp16x2 form.  With a bound on x and w they take the DMA-tile kernel's H2 forms like the large tiles.)
+    case 128032:
+      if (p.x_bytes && p.amax_x && p.amax_w) return launch_conv_w8<128, 32, 4, 1>(p, s);
+      return launch_conv<128, 32, 4, 1>(p, s);
+    case 64064:
+      if (p.x_bytes && p.amax_x && p.amax_w) return launch_conv_w8<64, 64, 2, 2>(p, s);
+      return launch_conv<64, 64, 2, 2>(p, s);
     case 128128: {
       static const int w8 = getenv("DF_CONV_W8") ? atoi(getenv("DF_CONV_W8")) : 3;
       if (halo_ok) return launch_conv_halo<128, 2, 4>(p, s);

@@ -406,8 +406,25 @@ def _split_h2(w_ohwi: torch.Tensor):
             return hit
     wa = W_AMAX
     if wa is None:
-        wa = amax_slot(w_ohwi.device)
+        # outside a trainer step (inference, plain autograd): planes are kept per weight tensor until it changes -- an eval-mode forward
+        # split every 3x3 layer's weights on every call (round 5: 14 df_split_h2 + 21 df_absmax launches of the 95 of a B = 1 forward)
+        try:
+            key = (w_ohwi.data_ptr(), w_ohwi._version, PARAM_GEN[0], tuple(w_ohwi.shape))
+        except RuntimeError:        # inference-mode tensors do not track versions
+            key = None
+        hit = _PLANE_CACHE.get(key) if key is not None else None
+        if hit is not None:
+            return hit[0], hit[1]
+        # (a bound of its own tensor, NOT a pooled slot: amax_pool_reset() recycles those between steps)
+        wa = torch.zeros(1, dtype=torch.float32, device=w_ohwi.device)
         call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
+        w2 = torch.empty(2 * w_ohwi.numel(), dtype=torch.float16, device=w_ohwi.device)
+        call("df_split_h2", ptr(w_ohwi), ptr(wa), ptr(w2), w_ohwi.numel(), stream())
+        if key is not None:
+            if len(_PLANE_CACHE) > 128:
+                _PLANE_CACHE.clear()
+            _PLANE_CACHE[key] = (w2, wa, w_ohwi)     # (the tensor is kept: its address cannot be reused while cached)
+        return w2, wa
     w2 = torch.empty(2 * w_ohwi.numel(), dtype=torch.float16, device=w_ohwi.device)
     call("df_split_h2", ptr(w_ohwi), ptr(wa), ptr(w2), w_ohwi.numel(), stream())
     return w2, wa
@@ -431,16 +448,7 @@ def _wprep_planes(w_ohwi: torch.Tensor):
     # plain autograd / inference callers: the same kernel again (one form of the convolution whoever calls it: the captured trainer
     # program and a hand-driven eager step agree bit for bit, tests/helpers/rccl_world1.py); planes are kept per weight tensor until it
     # changes (inference: split once; a transposed copy made per call misses and is split per call)
-    try:
-        key = (w_ohwi.data_ptr(), w_ohwi._version, PARAM_GEN[0], tuple(w_ohwi.shape))
-    except RuntimeError:        # inference-mode tensors do not track versions
-        return _split_h2(w_ohwi)
-    hit = _PLANE_CACHE.get(key)
-    if hit is None:
-        if len(_PLANE_CACHE) > 128:
-            _PLANE_CACHE.clear()
-        hit = _PLANE_CACHE[key] = _split_h2(w_ohwi) + (w_ohwi,)     # (the tensor is kept: its address cannot be reused while cached)
-    return hit[0], hit[1]
+    return _split_h2(w_ohwi)     # (W_AMAX is None here: _split_h2 keeps the planes in _PLANE_CACHE)
 
 
 def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfImg, ks: int, stride: int = 1,
@@ -480,7 +488,9 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             src._df_amax = (ya, ver(src))
     if ya is None and getattr(y, "_src", None) is not None:
         wrote(y._src)          # (an unmeasured write into a tensor that carried a bound)
-    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2)
+    # (round 5: also the 3x3 stride-1 layers that have NO haloed fp16x2 tile form -- too few pixels: the 64 x 64 layers of a B = 1
+    # forward ran on the fp32 MFMA, 5 x 94 us of a 2.2 ms forward)
+    h2f = (h2_active() and not x3 and not w16 and x.elt == 0 and y.elt in (0, 2) and (ks == 1 or stride == 2 or (ks == 3 and stride == 1))
            and x.c % (64 if os.environ.get("DF_CONV_H2F_C32", "1") == "0" else 32) == 0     # (32: the first encoder conv on the canvas: its bound comes from the pillar feature net's statistics)
            and getattr(x, "_amax", None) is not None and os.environ.get("DF_CONV_H2F", "1") != "0")
     fused_bn = False
