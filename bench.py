@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (the metric is quoted at 16)")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct HBM-resident batches the timed steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=5, help="timed CPU-oracle repetitions per leg (after 2 warm-ups)")
     ap.add_argument("--no-extras", action="store_true",
@@ -260,6 +261,16 @@ def main():
     trainer = Trainer(model, lr=2e-4)
     # weak scaling: every rank owns its own shard of frame pairs (seeded by global sample index), resident in HBM
     batch = synth_batch(args.batch, N_POINTS, seed=Trainer.shard_seed(20240116, rank, args.batch), device=dev)
+    # round 5: the timed steps ROTATE over --rotate distinct resident batches (other scenes: other occupied pillars) -- the engine
+    # keeps its BEV canvas across steps and rewrites only the cells whose occupancy changed (csrc/pillar_bands.hip), so stepping one
+    # batch over and over would skip the re-zeroing a real epoch pays for; `pillar_canvas` in the line reports the measured fractions
+    batches = [batch] + [synth_batch(args.batch, N_POINTS, seed=Trainer.shard_seed(20240116 + 100003 * j, rank, args.batch), device=dev)
+                         for j in range(1, max(1, args.rotate))]
+    step_no = [0]
+
+    def next_batch():
+        step_no[0] += 1
+        return batches[step_no[0] % len(batches)]
 
     def barrier():
         if use_dist:
@@ -270,14 +281,14 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(k):
-            loss_ = trainer.step(batch)
+            loss_ = trainer.step(next_batch())
         torch.cuda.synchronize()
         local = time.perf_counter() - t0
         barrier()
         return time.perf_counter() - t0, local, loss_
 
     for _ in range(args.warmup):
-        trainer.step(batch)
+        trainer.step(next_batch())
     selfcheck = None
     if use_dist:
         # RCCL self-check before the timed region: after the arena broadcast and the warm-up steps (each rank on its OWN shard, the
@@ -409,6 +420,28 @@ def main():
                    "global_batch": world * args.batch, "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS,
                    "parallelism": f"dp{world}", "loss": float(loss)},
     }
+    out["config"]["distinct_batches_rotated"] = len(batches)
+    try:
+        # what the persistent BEV canvas saved / paid between two consecutive (different) batches: cells occupied now, cells that had
+        # to be re-zeroed because they were occupied by the previous batch only -- read off the band kernels' occupancy words
+        from deflow_amd import deflow as _D
+        ents = [v for k, v in (_D._CANVASES.get(model) or {}).items() if k[0] == args.batch and not k[4]]
+        if ents and len(batches) > 1:
+            occs = [o for o in ents[0][1] if o is not None]
+            sh = torch.arange(32, device=dev, dtype=torch.int32)
+            nbits = lambda w: int(((w.reshape(-1, 1) >> sh) & 1).sum().item())
+            trainer.step(batches[0])
+            prev = [o.clone() for o in occs]
+            trainer.step(batches[1])
+            cells = float(2 * args.batch * GRID * GRID)
+            out["pillar_canvas"] = {"persistent": True, "occupied_frac": sum(nbits(o) for o in occs) / cells,
+                                    "rezeroed_frac": sum(nbits(p_ & ~o) for p_, o in zip(prev, occs)) / cells,
+                                    "note": "fractions of the 2 x B x 512 x 512 canvas cells written per step (pillar rows / zero rows); a dense "
+                                            "canvas (DF_CANVAS_PERSIST=0) writes all of them"}
+        else:
+            out["pillar_canvas"] = {"persistent": False}
+    except Exception as e:      # noqa: BLE001
+        out["pillar_canvas"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if selfcheck is not None:
         out["rccl_selfcheck"] = selfcheck
     if per_rank is not None:

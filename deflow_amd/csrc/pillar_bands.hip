@@ -246,6 +246,7 @@ struct P2Band {
   df_img out;
   int bn_stride, mode, S;
   int dbg;   // timing ablations (env DF_P2_DBG): bit 0 = no pillar loop, bit 1 = no zero stores, bit 2 = no sort / copy
+  uint32_t* occ;   // round 5, PERSISTENT canvas (df_pillar2_band_sp): [S][NB][64] occupancy words of the previous call, updated in place
 };
 
 // BC = LDS cell-table size (cells per band <= BC): 2048, or 1024 for thin bands -- 24.7 KB of LDS instead of 32.9, i.e. 6
@@ -457,6 +458,32 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   // ---- from here on no workgroup barrier (canvas kernels): wave 3 streams the zeros of the band's empty cells (128 B each,
   // 8 lanes x 16 B; every canvas byte is written exactly once) while waves 0-2 walk the pillars
   const int ngrp = CANVAS ? 24 : 32;
+  if (CANVAS && wave == 3 && a.occ) {
+    // PERSISTENT canvas (round 5): the buffer is zero wherever the PREVIOUS call of this (sample set, band geometry) left no pillar
+    // -- the invariant its owner keeps (deflow.py) -- so only cells that were occupied then and are empty now need their zeros: the
+    // band's occupancy words (64 x 32 cells, touched by this workgroup alone) are read, compared and rewritten in place.  The 128-byte
+    // zero rows of a dense canvas were 87 % of the stage's bytes (537 MB per cloud at B = 16, 4.2 TB/s: profiles/r05_pmc_band.txt).
+    uint32_t* ow = a.occ + ((int64_t)s * NB + band) * 64;
+    const unsigned prevw = ow[lane];
+    unsigned curw = 0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < ncb; c0 += 64) {
+      const int c = c0 + lane;
+      const bool on = c < ncb && cnt[c] > 0;
+      const unsigned long long m = __ballot(on);
+      const unsigned plo = (unsigned)__shfl((int)prevw, c0 >> 5), phi = (unsigned)__shfl((int)prevw, (c0 >> 5) + 1);
+      const unsigned long long pv = ((unsigned long long)phi << 32) | plo;
+      if (lane == (c0 >> 5)) curw = (unsigned)m;
+      if (lane == (c0 >> 5) + 1) curw = (unsigned)(m >> 32);
+      if (c < ncb && (((pv & ~m) >> lane) & 1ull)) {
+        float* o = op + (int64_t)c * a.out.ld;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st4(o + 4 * k, z);
+      }
+    }
+    ow[lane] = curw;
+    return;
+  }
   if (CANVAS && wave == 3) {
     if (!(a.dbg & 2)) {
       const int zg = lane >> 3;
@@ -590,11 +617,39 @@ extern "C" int df_pillar2_scatter(const float* pts, int S, int N, df_pillar_geom
   return DF_OK;
 }
 
+static int pillar2_band_impl(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
+                             const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
+                             const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
+                             uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
+                             void* stream);
+
 extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
                                const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                                const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                                uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial,
                                void* stream) {
+  return pillar2_band_impl(in_key, in_idx, in_pts, tot, bucket0, S, g, rows_per_band, flags, w_pfn, bn_ss, bn_sample_stride, mode, out,
+                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, nullptr, stream);
+}
+
+// PERSISTENT-canvas form of a canvas-writing band call (flags & 4): `out` must be zero wherever the previous call with the same
+// (S, grid, rows_per_band) and the same `occ` left no pillar (initially: out all zero, occ all zero); only the occupied cells and the
+// cells occupied last time are written, occ [S][bands][64] u32 is updated in place.  Same results as df_pillar2_band on such a buffer.
+extern "C" int df_pillar2_band_sp(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
+                                  const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
+                                  const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
+                                  uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
+                                  void* stream) {
+  DF_REQUIRE(occ && (flags & 4), DF_E_ARG);
+  return pillar2_band_impl(in_key, in_idx, in_pts, tot, bucket0, S, g, rows_per_band, flags, w_pfn, bn_ss, bn_sample_stride, mode, out,
+                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, occ, stream);
+}
+
+static int pillar2_band_impl(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
+                             const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
+                             const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
+                             uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
+                             void* stream) {
   P2Geom q;
   const bool sort = flags & 1, stats = flags & 2, canvas = flags & 4;
   DF_REQUIRE(in_key && in_pts && tot && bucket0 && w_pfn && S > 0 && (mode == 0 || mode == 1), DF_E_ARG);
@@ -609,7 +664,7 @@ extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, c
   P2Band a;
   a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.bucket0 = bucket0; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
   a.pts_sorted = pts_sorted; a.cell_rng = cell_rng; a.w_pfn = w_pfn; a.bn_ss = bn_ss; a.partial = stats_partial; a.out = out;
-  a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S;
+  a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S; a.occ = occ;
   static const int dbg = getenv("DF_P2_DBG") ? atoi(getenv("DF_P2_DBG")) : 0;
   a.dbg = dbg;
   const dim3 grid(q.NB, S);

@@ -9,6 +9,7 @@ valid-point counts) happens per forward, after every kernel has been queued.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -40,6 +41,9 @@ def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor, form: Optional[str] =
     inv[:3, :3] = pose1[:3, :3].T
     inv[:3, 3] = (pose1[:3, :3].T * -pose1[:3, 3]).sum(axis=1)
     return inv @ pose0.type(inv.dtype)
+
+
+_CANVASES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> {shape key: (canvas, occupancy words)}: persistent canvases
 
 
 class DeFlow(nn.Module):
@@ -74,21 +78,40 @@ class DeFlow(nn.Module):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device
-        with ops.timed("canvas_zero_fill"):   # (first-generation pillariser only: the band pipeline writes its own zeros)
-            bstar = canvas_alloc(B, emb.H, emb.W, 64, device=dev)
+        merged = not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0"
+        # round 5: a PERSISTENT canvas where the engine owns its lifetime -- no-grad forwards and the trainer's one-forward-one-
+        # backward step (`_persist_canvas`, set by optim.Trainer) -- so that the band kernels write occupied cells only instead of
+        # streaming zeros into the 87 % empty ones (csrc/pillar_bands.hip, df_pillar2_band_sp).  Autograd users (several forwards may
+        # be alive) get a fresh, fully written buffer as before.  DF_CANVAS_PERSIST=0: always the dense form.
+        persist = ((not save) or getattr(self, "_persist_canvas", False)) and os.environ.get("DF_CANVAS_PERSIST", "1") != "0"
+        occs = (None, None)
+        if persist:
+            key = (B, emb.H, emb.W, str(dev), merged, emb.bands(2 * B if merged else B))
+            store = _CANVASES.setdefault(self, {})    # (outside the module's __dict__: deepcopy / pickling must not drag 1 GB buffers along)
+            pc = store.get(key)
+            if pc is None:
+                if len(store) >= 4:          # a handful of shapes at most (train / eval batch sizes)
+                    store.clear()
+                pc = store[key] = (torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev),
+                                            (emb.occ_alloc(2 * B, dev), None) if merged else (emb.occ_alloc(B, dev), emb.occ_alloc(B, dev)))
+            bstar, occs = pc
+            ops.wrote(bstar)      # (whatever max |x| record the previous forward's consumers left on the tensor is void)
+        else:
+            with ops.timed("canvas_zero_fill"):   # (first-generation pillariser only: the band pipeline writes its own zeros)
+                bstar = canvas_alloc(B, emb.H, emb.W, 64, device=dev)
         self.timer[1].start("Voxelization")
         # fp16x2 training: an a-priori bound of max |canvas| comes out of the feature net's BatchNorm finalisation (one slot, both clouds)
         emb.canvas_bound = ops.amax_slot(dev) if (train and save and ops.h2_active() and ops.SYNC is None) else None
-        if not save and pc0s.shape == pc1s.shape and os.environ.get("DF_MERGE_CLOUDS") != "0":
+        if merged:
             # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
             # samples writing the two channel halves of bstar -- half the launches of the ~15-kernel pipeline, which is
             # what a B = 1 forward spends there.  Same arithmetic sample by sample (BatchNorm statistics are per sample).
             both = emb.pillarize(torch.cat([pc0s, pc1s], 0), DfImg(bstar.data_ptr(), 2 * B, emb.H, emb.W, 32, 64, B,
-                                                                  bstar.stride(0), 32), train, need_cells=False)
+                                                                  bstar.stride(0), 32), train, need_cells=False, occ=occs[0])
             p0, p1 = both.split(B)
         else:
-            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save)
-            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save)
+            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save, occ=occs[0])
+            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save, occ=occs[1])
         self.timer[1].stop()
         if emb.canvas_bound is not None:
             bstar._df_amax = (emb.canvas_bound, _ver(bstar))

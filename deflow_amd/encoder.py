@@ -98,13 +98,33 @@ class DynamicEmbedder(nn.Module):
         return self.feature_net.pfn_layers[0][1]
 
     # -- engine ------------------------------------------------------------------------------
-    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool = True) -> PillarState:
+    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool = True, occ: Optional[torch.Tensor] = None) -> PillarState:
         """pts [B,N,3] f32 contiguous on the GPU; writes the WHOLE [B,H,W,32] canvas `out` (zeros included: the canvas needs no
-        prior fill).  need_cells: also leave the dense per-cell [start, end) table the backward kernels read."""
+        prior fill).  need_cells: also leave the dense per-cell [start, end) table the backward kernels read.
+        occ (round 5): the PERSISTENT-canvas form -- `out` is a buffer this embedder wrote last time with the same `occ`
+        ([S][bands][64] int32 occupancy words from `occ_alloc`, zero at first together with the buffer): only occupied cells and the
+        cells occupied last time are written (df_pillar2_band_sp); the result is the same canvas."""
         B, N, _ = pts.shape
         # algorithmic traffic of the stage (SURVEY 8(d)): the points once in, the dense 32-channel canvas once out
         with ops.timed("pillarise_fwd", bytes=B * (N * 12.0 + 32.0 * self.H * self.W * 4.0), tag=f"B={B} N={N}"):
-            return self._pillarize(pts, out, train, need_cells)
+            return self._pillarize(pts, out, train, need_cells, occ)
+
+    def bands(self, S: int) -> Tuple[int, int]:
+        """(rows per band, bands per sample) of the band pipeline for a set of S samples"""
+        H, W = self.H, self.W
+        R = call("df_pillar2_rows_per_band", H, W)
+        if R <= 0:
+            raise RuntimeError(f"pillarise: a {H}x{W} grid is not supported (rows wider than 2048 cells)")
+        # few samples (B = 1 inference: S = 2): thinner bands, so that the band kernel still has >= ~2048 workgroups to spread
+        # over the 256 CUs (one workgroup per (band, sample); its latency chain shortens with the band)
+        rmin = int(os.environ.get("DF_P2_MIN_WGS", "2048"))
+        while R > 1 and S * ((H + R - 1) // R) < rmin and (H + R // 2 - 1) // (R // 2) <= 512:
+            R //= 2
+        return R, (H + R - 1) // R
+
+    def occ_alloc(self, S: int, device) -> torch.Tensor:
+        """zeroed occupancy words of a persistent canvas for sets of S samples"""
+        return torch.zeros(S, self.bands(S)[1], 64, dtype=torch.int32, device=device)
 
     def _bn_state(self, train: bool, partial, counts, B: int, nbs: int, dev):
         """-> (bn_ss, bn_stride): per-sample batch statistics (training; running statistics updated) or the folded running ones"""
@@ -130,21 +150,20 @@ class DynamicEmbedder(nn.Module):
             bn._df_fold_ss = c
         return c[1], 0
 
-    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool) -> PillarState:
+    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool, occ: Optional[torch.Tensor] = None) -> PillarState:
         """Band-bucketed pipeline (csrc/pillar_bands.hip): hist -> scan -> scatter -> band (4 launches; training 6)."""
         assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
         S, N, _ = pts.shape
         dev, g, s = pts.device, self.geom, stream()
         H, W = self.H, self.W
-        R = call("df_pillar2_rows_per_band", H, W)
-        if R <= 0:
-            raise RuntimeError(f"pillarise: a {H}x{W} grid is not supported (rows wider than 2048 cells)")
-        # few samples (B = 1 inference: S = 2): thinner bands, so that the band kernel still has >= ~2048 workgroups to spread
-        # over the 256 CUs (one workgroup per (band, sample); its latency chain shortens with the band)
-        rmin = int(os.environ.get("DF_P2_MIN_WGS", "2048"))
-        while R > 1 and S * ((H + R - 1) // R) < rmin and (H + R // 2 - 1) // (R // 2) <= 512:
-            R //= 2
-        NB = (H + R - 1) // R
+        R, NB = self.bands(S)
+        assert occ is None or (tuple(occ.shape) == (S, NB, 64) and occ.dtype == torch.int32 and occ.is_contiguous())
+
+        def band_canvas(*a):      # the canvas-writing band call: dense, or the persistent-canvas form
+            if occ is None:
+                call("df_pillar2_band", *a, s)
+            else:
+                call("df_pillar2_band_sp", *a, ptr(occ), s)
         ncol = NB + 1
         nblk = (N + call("df_pillar2_tile") - 1) // call("df_pillar2_tile")
         i32 = dict(dtype=torch.int32, device=dev)
@@ -173,12 +192,12 @@ class DynamicEmbedder(nn.Module):
             call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), ptr(bucket0), S, g, R, SORT | STATS, ptr(w), None, 0, self.mode, out,
                  ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), None, ptr(partial), s)
             bn_ss, bn_stride = self._bn_state(True, partial, counts, S, NB, dev)
-            call("df_pillar2_band", ptr(key_sorted), None, ptr(pts_sorted), ptr(tot), ptr(bucket0), S, g, R, CANVAS, ptr(w), ptr(bn_ss), bn_stride,
-                 self.mode, out, None, None, None, ptr(cell_rng), None, s)
+            band_canvas(ptr(key_sorted), None, ptr(pts_sorted), ptr(tot), ptr(bucket0), S, g, R, CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+                        self.mode, out, None, None, None, ptr(cell_rng), None)
         else:
             bn_ss, bn_stride = self._bn_state(False, None, counts, S, NB, dev)
-            call("df_pillar2_band", ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), ptr(bucket0), S, g, R, SORT | CANVAS, ptr(w), ptr(bn_ss), bn_stride,
-                 self.mode, out, ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), ptr(cell_rng), None, s)
+            band_canvas(ptr(bkey), ptr(bidx), ptr(bpts), ptr(tot), ptr(bucket0), S, g, R, SORT | CANVAS, ptr(w), ptr(bn_ss), bn_stride,
+                        self.mode, out, ptr(key_sorted), ptr(idx_sorted), ptr(pts_sorted), ptr(cell_rng), None)
         return PillarState(pts, counts, points_c, coords_c, idx_c, offs_c, cpos, idx_sorted, cell_rng, key_sorted, pts_sorted, bn_ss,
                            bn_stride)
 

@@ -422,6 +422,8 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(cap_stream)
         self._program = cap.ops
         self._cap = cap      # keeps the pool handle alive
+        from .deflow import _CANVASES
+        self._canvas_pin = dict(_CANVASES.get(self.model, {}))      # the graphs hold the persistent canvas's ADDRESS: it must outlive the store's entry
         self._graph = cap    # (truthy marker older callers test for)
         # the captured launch sequence was RECORDED, not executed: undo the host-side counter
         self.opt.step_count = snap[3]
@@ -502,7 +504,11 @@ class Trainer:
             return loss.detach()
         from .autograd import deflow_backward
         with torch.no_grad():
-            st = model.forward_padded(batch, engine_tape=True)
+            model._persist_canvas = True     # one forward, then its backward, per step: the engine may keep its BEV canvas across steps (deflow.py)
+            try:
+                st = model.forward_padded(batch, engine_tape=True)
+            finally:
+                model._persist_canvas = False
             flow = st["flow"]
             B, N, _ = flow.shape
             dev = flow.device

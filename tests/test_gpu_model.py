@@ -1065,6 +1065,92 @@ def test_merged_cloud_pillarisation_is_bit_identical(dev, train):
         assert torch.equal(a[4][k], b[4][k]), k
 
 
+def _varied_batches(dev):
+    """batches whose occupied cells differ a lot from one to the next (sparser, denser, shifted, ragged, an empty cloud)"""
+    out = []
+    for i, (n, seed) in enumerate([(2000, 900), (600, 77), (2600, 5), (2000, 1234), (2000, 900)]):
+        b = make_batch(3, n, seed)
+        if i == 1:
+            b["pc0"][0] = float("nan")                  # an empty cloud: every cell it occupied before must be zero again
+            b["pc1"][2, 100:] = float("nan")
+        if i == 2:
+            b["pc0"][..., 0] += 3.1                       # shifted: other cells
+        if i == 3:
+            b["pc1"][1, 900:] = float("nan")
+        out.append(to_dev(b, dev))
+    return out
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_persistent_canvas_equals_the_dense_one(dev, train, monkeypatch):
+    """round 5: no-grad forwards keep ONE BEV canvas per (model, shape) and the band kernel rewrites only the cells occupied now or
+    last time (df_pillar2_band_sp).  Over a sequence of different batches: the canvas equals a freshly, densely written one bit for
+    bit, and so do the flows; a batch-size change in between (another canvas) does not disturb the first one's invariant."""
+    import copy
+    from deflow_amd import deflow as D
+    from deflow_amd._lib import img
+    _, base = build_pair(dev, 22, decoder_option="gru", num_iters=2)
+    batches = _varied_batches(dev)
+    small = to_dev(make_batch(1, 1500, 31), dev)
+    flows = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DF_CANVAS_PERSIST", mode)
+        m = copy.deepcopy(base).train(train)
+        res = []
+        with torch.no_grad():
+            for i, b in enumerate(batches):
+                st = m.forward_padded(b)
+                res.append((st["flow"].clone(), st["counts0"].clone()))
+                if i == 2:
+                    m.forward_padded(small)
+                if mode == "1":
+                    # the persistent canvas itself against a dense write of the same clouds
+                    store = D._CANVASES[m]
+                    (canvas, _), = [v for k, v in store.items() if k[0] == 3]
+                    emb = m.embedder
+                    dense = torch.full_like(canvas, float("nan"))
+                    keep = [t.clone() for t in emb.buffers()]       # (train mode: the dense reference must not move the running statistics)
+                    emb.pillarize(st["pc0s"], img(dense, 32, 0), train, need_cells=False)      # (pc0 after the ego-motion transform)
+                    emb.pillarize(b["pc1"], img(dense, 32, 32), train, need_cells=False)
+                    for t, v in zip(emb.buffers(), keep):
+                        t.copy_(v)
+                    assert torch.equal(canvas, dense), (i, int((canvas != dense).sum()))
+        flows[mode] = res
+        assert (m in D._CANVASES) == (mode == "1")
+    for i, (a, b) in enumerate(zip(flows["1"], flows["0"])):
+        assert torch.equal(a[1], b[1]), i
+        for s in range(3):
+            n = int(a[1][s])
+            assert torch.equal(a[0][s, :n], b[0][s, :n]), (i, s)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_trainer_persistent_canvas_steps_equal_dense_steps(dev, dtype, monkeypatch):
+    """the trainer's step keeps its canvas across steps (one forward, then its backward): five steps on five different batches
+    leave bit-identical parameters and losses with DF_CANVAS_PERSIST=1 and =0; an evaluation forward between two steps (its own
+    canvas: the merged 2B-sample form) changes nothing"""
+    import copy
+    from deflow_amd.optim import Trainer
+    _, base = build_pair(dev, 23, decoder_option="gru", num_iters=2)
+    batches = _varied_batches(dev)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DF_CANVAS_PERSIST", mode)
+        m = copy.deepcopy(base).train()
+        tr = Trainer(m, lr=1e-3, dtype=dtype)
+        losses = []
+        for i, b in enumerate(batches):
+            losses.append(tr.step(b).clone())
+            if i == 1:
+                m.eval()
+                with torch.no_grad():
+                    m.forward_padded(batches[3])
+                m.train()
+        out[mode] = (torch.stack(losses), tr.flat.param.clone(), tr.flat.grad.clone())
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_config0_fastflow3d_ff3dloss_bs1_from_scene_files(dev, tmp_path, capsys):
     """BASELINE configs[0] ("fastflow3d model, ... single AV2 scene, batch_size=1", the README's baseline command
     [REF README.md:68]) as plumbing through this engine: model=fastflow3d (LinearDecoder head) with loss_fn=ff3dLoss at

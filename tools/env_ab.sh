@@ -14,7 +14,9 @@ i, leg = sys.argv[1], sys.argv[2]
 try:
     d = json.loads([l for l in open(f"gpurun_out/env_ab_{i}.json") if l.startswith("{")][-1])
     h = d.get("roofline_hbm", {})
-    print(f"[{leg or 'default':28s}] step {d['ms_per_step']:.2f} ms  gru fwd/bwd/wgrad " + " / ".join(f"{h[k]['ms_per_step']:.3f}" for k in ("gru_fwd", "gru_bwd", "gru_wgrad") if k in h), flush=True)
+    print(f"[{leg or 'default':28s}] step {d['ms_per_step']:.2f} ms  gru fwd/bwd/wgrad " + " / ".join(f"{h[k]['ms_per_step']:.3f}" for k in ("gru_fwd", "gru_bwd", "gru_wgrad") if k in h)
+          + (f"  pillarise_fwd {h['pillarise_fwd']['ms_per_step']:.3f} ms frac {h['pillarise_fwd'].get('frac_hbm', h['pillarise_fwd'].get('frac', 0)):.3f}" if "pillarise_fwd" in h else "")
+          + f"  canvas {d.get('pillar_canvas')}", flush=True)
 except Exception as e:
     print(leg, "FAILED", e, open(f"gpurun_out/env_ab_{i}.err").read()[-1500:])
 PY
