@@ -3052,6 +3052,244 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
 #endif
 }
 
+// ---- 1x1 weight gradient on the fp16 matrix pipe, fp32 tensors split in flight (round 5; df_conv2d_wgrad1_h2) ----------------
+// dW[co, ci] = sum_p dy[p, co] x[p, ci] is a row GEMM whose K dimension is the pixel count: every operand byte is read once and the
+// fp32 MFMA (wgrad1x1_kernel: 32x32x2, 64 cycles each) cannot keep up with the memory system -- 82-88 TFLOP/s = 1.4-2.6 TB/s of
+// operands on the decoder's skip / latent layers, 55-60 with the 64 x 64 tile of wgrad_kernel<1,1,32> (profiles/r05_layer_table.txt).
+// Here every staged element is split ONCE into two scaled fp16 planes (df_h2_split, the scales from bounds of max |x| / max |dy| as in
+// wgrad3_x3_kernel<2>) on its way global -> registers -> LDS, the planes take the transposing-read image of wgrad3_tr_kernel
+// ([plane][32-channel half][pixel][64 B]) and a product is three v_mfma_f32_32x32x16_f16 -- 5.3 x the fp32 MFMA rate, which leaves
+// the kernel to the memory system.  COT x CIT tile (128 or 64 each), 4 waves = 2 x 2 wave tiles, 32 pixels per stage, two LDS
+// stages, the next stage's elements in registers while the current one is multiplied; two workgroups per CU.
+template <int COT, int CIT>
+__global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 32;
+  constexpr int HY = COT / 32, HX = CIT / 32;          // 32-channel halves of the two operands
+  constexpr int HB = P * 64;                           // bytes of one half of one plane: [32 px][64 B]
+  constexpr int YB = HY * HB, XB = HX * HB;
+  constexpr int PLB = YB + XB, STG = 2 * PLB;          // plane, stage (hi | lo)
+  constexpr int NYS = YB / 16, NXS = XB / 16;          // 16-byte slots = 8 channels of one pixel of one plane
+  constexpr int NIT = (NYS + NXS) / 256, NIY = NYS / 256;
+  constexpr int TCO = COT / 64, TCI = CIT / 64;        // 32-wide tiles per wave and operand
+  static_assert(NYS % 256 == 0 && NXS % 256 == 0 && (COT == 64 || COT == 128) && (CIT == 64 || CIT == 128), "tile");
+  const float sx = df_h2_scale(*p.amax_x), sdy = df_h2_scale(*p.amax_dy);
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {   // all (ci, co) tiles of a split on one XCD: they read the same x / dy rows (see wgrad3_ring_kernel)
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * CIT, co0 = by * COT;
+  const bool do_bias = p.bias_ws && bx == 0;
+  float bsum = 0.f;
+
+  f32x16 acc[TCO][TCI], acc1[TCO][TCI];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+
+  // staging items: item e of a thread = slot tid + 256 e of a plane image -- items < NIY are dY ([half][px][4 slots]), the rest X;
+  // the source of a slot is 8 consecutive fp32 channels (two 16-byte loads)
+  unsigned loff[NIT];
+  int lpx[NIT];
+#pragma unroll
+  for (int e = 0; e < NIT; ++e) {
+    const int t = (tid + 256 * e) - (e < NIY ? 0 : NYS);
+    const int h = t >> 7, px = (t & 127) >> 2, q = t & 3;
+    if (e < NIY) {
+      lpx[e] = px;
+      loff[e] = (unsigned)((px * p.dy.ld + co0 + 32 * h + 8 * q) * 4);
+    } else {
+      lpx[e] = (ci0 + 32 * h + 8 * q) < p.K ? px : (1 << 28);       // (channel groups past K: never in range -> zeros)
+      loff[e] = (unsigned)((px * p.x.ld + ci0 + 32 * h + 8 * q) * 4);
+    }
+  }
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)cur_oy * wy * p.x.ld) * 4);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 4), xrow_step = (unsigned)(wy * p.x.ld * 4);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 4), xseg_step = (unsigned)(P * p.x.ld * 4);
+  f32x4 ra[NIT][2];
+  auto fetch = [&]() {          // the cursor's chunk -> registers, then advance the cursor
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      const bool ok = ox0 + lpx[e] < wy;
+      if (e < NIY) {
+        const unsigned v = ok ? ybase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v + 16, 0, 0));
+      } else {
+        const unsigned v = ok ? xbase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, 0, 0));
+      }
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {
+        cur_oy = 0;
+        ++cur_n;
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
+      }
+    }
+  };
+  auto stash = [&](int buf) {   // registers -> (hi, lo) fp16 planes -> LDS
+    char* st = ldsb + buf * STG;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+      f16x8_t h, l;
+      df_h2_split(v, e < NIY ? sdy : sx, h, l);
+      char* d = st + 16 * (tid + 256 * e);            // (dY slots first, X slots behind them: YB = 16 NYS)
+      *reinterpret_cast<f16x8_t*>(d) = h;
+      *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+  const int tr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // (see wgrad3_tr_kernel)
+  const unsigned a_base = lds0 + wco * TCO * HB + (8 * kh) * 64 + tr_lane;
+  const unsigned b_base = lds0 + YB + wci * TCI * HB + (8 * kh) * 64 + tr_lane;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto op8 = [](u32x2_t lo, u32x2_t hi) -> f16x8_t {
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+  // one 32 x 16 operand tile = (hi, lo) x (pixels +0..3, +4..7): four transposing reads
+  auto rd4 = [](unsigned hi_addr, unsigned lo_addr, u32x2_t (&r)[4]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\t"
+        "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %5\n\t"
+        "ds_read_b64_tr_b16 %3, %5 offset:256"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(hi_addr), "v"(lo_addr)
+        : "memory");
+  };
+
+  if (nst > 0) {
+    fetch();
+    stash(0);
+  }
+  __syncthreads();
+  for (int i = 0; i < nst; ++i) {
+    if (i + 1 < nst) fetch();
+    const unsigned so = (unsigned)((i & 1) * STG);
+#pragma unroll
+    for (int ks = 0; ks < P / 16; ++ks) {
+      u32x2_t fa[TCO][4], fb[TCI][4];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) rd4(a_base + so + ks * 1024 + t * HB, a_base + so + ks * 1024 + t * HB + PLB, fa[t]);
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) rd4(b_base + so + ks * 1024 + t * HB, b_base + so + ks * 1024 + t * HB + PLB, fb[t]);
+      if constexpr (TCO == 2 && TCI == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
+                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])
+                     :: "memory");
+      } else if constexpr (TCO == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
+                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3])
+                     :: "memory");
+      } else if constexpr (TCI == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])
+                     :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3])
+                     :: "memory");
+      }
+#pragma unroll
+      for (int ti = 0; ti < TCO; ++ti) {
+        const f16x8_t ah = op8(fa[ti][0], fa[ti][1]), al = op8(fa[ti][2], fa[ti][3]);
+#pragma unroll
+        for (int tj = 0; tj < TCI; ++tj) {
+          const f16x8_t bh = op8(fb[tj][0], fb[tj][1]), bl = op8(fb[tj][2], fb[tj][3]);
+          acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[ti][tj], 0, 0, 0);
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ti][tj], 0, 0, 0);
+          acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[ti][tj], 0, 0, 0);
+        }
+      }
+    }
+    if (do_bias) {   // column tid % COT, pixel group tid / COT: value = hi + lo / 2048 (scaled)
+      const char* stp = ldsb + (i & 1) * STG;
+      constexpr int NG = 256 / COT;                 // pixel groups (2 or 4)
+      const int c = tid % COT, g = tid / COT;
+#pragma unroll
+      for (int j = 0; j < P / NG; ++j) {
+        const int el = (c >> 5) * (P * 32) + (g * (P / NG) + j) * 32 + (c & 31);
+        bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+      }
+    }
+    if (i + 1 < nst) stash((i + 1) & 1);    // ring slot (i + 1) & 1 was last read in stage i - 1, behind the previous barrier
+    __syncthreads();
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(ldsb);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < COT) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 256 / COT; ++g) t += red[g * COT + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t * (1.f / sdy);
+    }
+  }
+  {
+    float* o = p.ws + (int64_t)split * p.N * p.K;
+    const float ix = 1.f / sx, iy = 1.f / sdy;      // exact powers of two
+#pragma unroll
+    for (int ti = 0; ti < TCO; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TCI; ++tj) {
+        const int ci = ci0 + (wci * TCI + tj) * 32 + li;
+        if (ci < p.K) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int co = co0 + (wco * TCO + ti) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            o[(int64_t)co * p.K + ci] = (acc[ti][tj][e] + acc1[ti][tj][e] * H2_LO_INV) * ix * iy;
+          }
+        }
+      }
+  }
+#endif
+}
+
 // ---- 3x3 stride-1 weight gradient of PRE-SPLIT fp16x2 tensors (round 4; df_conv2d_wgrad_h2p) ------------------------------
 // wgrad3_x3_kernel<2> splits every staged fp32 element in registers (global -> registers -> ~7 VALU per element -> LDS, 5.9
 // VALU + 1.9 LDS instructions per MFMA, the matrix pipe 47 % busy).  Here BOTH operands arrive split: x and dy are "h2" images
@@ -4170,6 +4408,63 @@ static int wgrad_x3_impl(df_img x, df_img dy, const float* x_amax, const float* 
   p.xcd_map = xcd_map;
   if (x_amax) return launch_wgrad_dma(wgrad3_x3_kernel<2>, grid, 2 * 2 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
   return launch_wgrad_dma(wgrad3_x3_kernel<3>, grid, 2 * 3 * 17152, reinterpret_cast<hipStream_t>(stream), p, 768);
+}
+
+// 1x1 weight gradient, fp32 tensors, fp16x2 products (wgrad1_h2_kernel; round 5).  _ok: shapes it takes (DF_WGRAD1_H2=0 switches it
+// off); _splits: split-K count (two 4-wave workgroups per CU: one resident round = 512); workspace [splits][Cout][Cin] and the reduce
+// as df_conv2d_wgrad_mp.  x_amax / dy_amax = upper bounds of max|x| / max|dy| (device scalars).
+static inline int wgrad1_cot(int cout) { return (cout % 128) == 0 ? 128 : 64; }
+static inline int wgrad1_cit(int cin) { return cin >= 128 ? 128 : 64; }
+extern "C" int df_conv2d_wgrad1_h2_ok(df_img x, df_img dy) {
+  static const int on = getenv("DF_WGRAD1_H2") ? atoi(getenv("DF_WGRAD1_H2")) : 1;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  return on && x.elt == 0 && dy.elt == 0 && img_ok(x) && img_ok(dy) && x.n == dy.n && x.h == dy.h && x.w == dy.w && (x.c % 32) == 0 &&
+         (dy.c % 64) == 0 && (x.ld % 4) == 0 && (dy.ld % 4) == 0 && x.img_stride >= 0 && dy.img_stride >= 0 && x.grp_off >= 0 &&
+         dy.grp_off >= 0 && extent(x) < (int64_t)DMA_BAD && extent(dy) < (int64_t)DMA_BAD;
+}
+
+extern "C" int df_conv2d_wgrad1_h2_splits(df_img x, df_img dy) {
+  static const int target = getenv("DF_WGRAD1_H2_BLOCKS") ? atoi(getenv("DF_WGRAD1_H2_BLOCKS")) : 512;
+  const int cot = wgrad1_cot(dy.c), cit = wgrad1_cit(x.c);
+  const int tiles = ((x.c + cit - 1) / cit) * (dy.c / cot);
+  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + 31) / 32);
+  int64_t splits = (target + tiles - 1) / tiles;
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  const int64_t cps = (chunks + splits - 1) / splits;
+  return (int)((chunks + cps - 1) / cps);
+}
+
+extern "C" int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits, float* bias_ws,
+                                   void* stream) {
+  DF_REQUIRE(x_amax && dy_amax && ws && df_aligned16(ws), DF_E_ARG);
+  DF_REQUIRE(df_conv2d_wgrad1_h2_ok(x, dy) == 1, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
+  p.amax_x = x_amax; p.amax_dy = dy_amax;
+  p.stride = 1; p.pad = 0; p.K = x.c; p.N = dy.c;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  p.x_bytes = (unsigned)extent(x);
+  p.dy_bytes = (unsigned)extent(dy);
+  p.chunks_per_row = (dy.w + 31) / 32;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  const int cot = wgrad1_cot(dy.c), cit = wgrad1_cit(x.c);
+  dim3 grid((x.c + cit - 1) / cit, dy.c / cot, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)2 * 2 * (cot + cit) * 64;      // two stages x two planes x (COT + CIT) / 32 halves x 32 px x 64 B
+  if (cot == 128 && cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 128>, grid, lds, s, p);
+  if (cot == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 64>, grid, lds, s, p);
+  if (cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<64, 128>, grid, lds, s, p);
+  return launch_wgrad_dma(wgrad1_h2_kernel<64, 64>, grid, lds, s, p);
 }
 
 // PRE-SPLIT fp16x2 tensors (round 4): x and dy are h2 images (df_img.elt = 2: per pixel and 32-channel chunk one 128-byte line

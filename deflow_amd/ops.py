@@ -789,7 +789,12 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     assert pre or (x.elt != 2 and dy.elt != 2), "a pre-split tensor meets an fp32 one in a weight gradient: unpack it (ops.h2_unpack) or keep both split"
     if pre:
         assert ks == 3 and stride == 1 and row_counts is None and call("df_conv2d_wgrad_h2p_ok", x, dy, ks, stride) == 1
-    splits = call("df_conv2d_wgrad_h2p_splits", x, dy) if pre else call("df_conv2d_wgrad_splits", x, dy, ks, stride)
+    t16 = bool(x.elt == 1 and dy.elt == 1)
+    # round 5: the 1x1 layers' fp32 tensors split in flight (wgrad1_h2_kernel) -- fp16x2 products instead of the fp32 MFMA
+    h2_1 = bool(not pre and not t16 and not MFMA_BF16 and ks == 1 and stride == 1 and row_counts is None and _h2_on() and h2_active()
+                and call("df_conv2d_wgrad1_h2_ok", x, dy) == 1)
+    splits = (call("df_conv2d_wgrad_h2p_splits", x, dy) if pre else call("df_conv2d_wgrad1_h2_splits", x, dy) if h2_1
+              else call("df_conv2d_wgrad_splits", x, dy, ks, stride))
     taps = ks * ks
     ws = _f32(splits * dy.c * taps * x.c, device=dev)
     prof = PROFILER
@@ -797,7 +802,6 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     bias_ws = _f32(splits, dy.c, device=dev) if want_bias else None
-    t16 = bool(x.elt == 1 and dy.elt == 1)
     x3 = (not pre and not t16 and not MFMA_BF16 and ks == 3 and stride == 1 and row_counts is None
           and call("df_conv2d_wgrad_x3_ok", x, dy, ks, stride) == 1)
     h2 = x3 and _h2_on()
@@ -805,6 +809,8 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         call("df_conv2d_wgrad_h2p", x, dy, ptr(x._amax), ptr(dy._amax), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     elif t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
+    elif h2_1:
+        call("df_conv2d_wgrad1_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ptr(ws), splits, ptr(bias_ws), stream())
     elif h2:     # fp32 mode: fp32-accurate product from two scaled fp16 planes per operand (wgrad3_x3_kernel<2>)
         call("df_conv2d_wgrad_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws),
              stream())
@@ -815,7 +821,7 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
              int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = ("wgrad3_h2p_kernel<4>" if pre else "wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_h2p_kernel<4>" if pre else f"wgrad1_h2_kernel<{128 if dy.c % 128 == 0 else 64},{128 if x.c >= 128 else 64}>" if h2_1 else "wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fbh'[x.elt]}{'fbh'[dy.elt]}"

@@ -299,6 +299,17 @@ int df_conv2d_wgrad_x3_ok(df_img x, df_img dy, int ksize, int stride);
 /* its fp16x2 form (wgrad3_x3_kernel<2>): x_amax / dy_amax as for df_conv2d_h2 */
 int df_conv2d_wgrad_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, int ksize, int stride, int pad, float* ws,
                        int splits, float* bias_ws, void* stream);
+/* 1x1 weight gradient of fp32 x and dy with fp16x2 products (round 5, wgrad1_h2_kernel): dW[co, ci] = sum_p dy[p, co] x[p, ci] is a
+ * row GEMM over the pixels that reads every operand byte once -- each staged element is split in flight into two scaled fp16 planes
+ * (x_amax / dy_amax as for df_conv2d_h2), three MFMAs per product, so that the kernel runs at the memory system's pace instead of the
+ * fp32 MFMA's.  _ok: 1 if the form takes the call (same geometry, Cin % 32 == 0, Cout % 64 == 0, DMA-addressable tensors;
+ * DF_WGRAD1_H2=0: never); _splits: its split-K count; ws [splits][Cout][Cin], bias_ws [splits][Cout] or NULL, then
+ * df_conv2d_wgrad_reduce(_bias) as for df_conv2d_wgrad_mp.  [REF decoder.py:205,213] weight gradient of the UNet's 1x1 convolutions
+ * (the reference's backbone: scripts/network/models/basic/unet.py UpsampleSkip u1 / u3 through torch autograd). */
+int df_conv2d_wgrad1_h2_ok(df_img x, df_img dy);
+int df_conv2d_wgrad1_h2_splits(df_img x, df_img dy);
+int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits, float* bias_ws,
+                        void* stream);
 /* bf16-STORAGE training (round 3): the 3x3 stride-1 weight gradient of BFLOAT16 x and dy (df_img.elt = 1 on both; W % 32 == 0):
  * bf16 tiles by LDS-DMA into a four-deep ring, fragments by transposing LDS reads (ds_read_b64_tr_b16), fp32 accumulation and
  * fp32 split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce exactly as df_conv2d_wgrad_mp.  Replaces the weight

@@ -1233,6 +1233,43 @@ def test_h2_bound_is_dropped_after_an_inplace_write(dev):
     check("conv after in-place write", z, want.float(), 2e-6)
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,sliced", [(64, 64, 2, 8, 64, False), (128, 64, 2, 5, 32, True), (128, 128, 3, 7, 96, True),
+                                                   (256, 128, 1, 4, 40, False), (512, 256, 2, 3, 64, False), (96, 192, 2, 6, 33, True),
+                                                   (32, 64, 1, 1, 5, False)])
+def test_wgrad_1x1_h2_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, sliced):
+    """df_conv2d_wgrad1_h2 (wgrad1_h2_kernel, round 5): the 1x1 weight gradient of fp32 tensors from two scaled fp16 planes per
+    operand, against float64 on the same inputs: <= 2e-6 of the largest entry (the fp32-MFMA kernel's own error beside it); every
+    tile form (128 / 64 x 128 / 64), a ragged channel tile (Cin = 96), widths that are no multiple of the 32-pixel stage, dy as a
+    channel slice of a wider tensor (the decoder's dcat halves), the fused bias sums, and the dispatch through ops.conv2d_wgrad"""
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call, ptr, stream
+    g = torch.Generator().manual_seed(cin * 13 + w)
+    x = (torch.randn(n, h, w, cin, generator=g) * 3.0).to(dev)
+    wide = torch.randn(n, h, w, 2 * cout if sliced else cout, generator=g).to(dev) * 0.01
+    dyi = img(wide, cout, cout) if sliced else img(wide)
+    dyt = wide[..., cout:] if sliced else wide
+    assert call("df_conv2d_wgrad1_h2_ok", img(x), dyi) == 1
+    dw = torch.empty(cout, 1, 1, cin, device=dev)
+    db = ops.conv2d_wgrad(img(x), dyi, 1, 1, dw, want_bias=True)               # fp32 mode -> wgrad1_h2_kernel
+    monkeypatch.setenv("DF_WGRAD1_H2", "0")     # (read once per process by the library: the fp32-MFMA kernels are called directly below)
+    splits = call("df_conv2d_wgrad_splits", img(x), dyi, 1, 1)
+    ws = torch.empty(splits * cout * cin, device=dev)
+    call("df_conv2d_wgrad_mp", img(x), dyi, 1, 1, 0, ptr(ws), splits, None, 0, None, 0, stream())
+    dw32 = torch.empty_like(dw)
+    call("df_conv2d_wgrad_reduce", ptr(ws), splits, cout, 1, cin, ptr(dw32), cin, 0, stream())
+    torch.cuda.synchronize()
+    want = torch.einsum("nhwo,nhwi->oi", dyt.cpu().double(), x.cpu().double()).reshape(cout, 1, 1, cin)
+    e2, e32 = rel_err(dw, want), rel_err(dw32, want)
+    print(f"[parity] wgrad 1x1 {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {e2:.2e} | fp32-MFMA err {e32:.2e} (vs float64)")
+    assert e2 <= 2e-6, (e2, e32)
+    check("h2 1x1 wgrad bias", db, dyt.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+    # accumulate into a strided destination (row pitch > Cin), as the packed GRU / arena layouts ask for
+    big = torch.full((cout, cin + 32), 0.5, device=dev)
+    ops.conv2d_wgrad(img(x), dyi, 1, 1, big, ld_co=cin + 32, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_err(big[:, :cin] - 0.5, want.reshape(cout, cin)) <= 4e-6 and torch.all(big[:, cin:] == 0.5)
+
+
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
 def test_wgrad_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w):
     """df_conv2d_wgrad_x3 (wgrad3_x3_kernel): the fp32 weight gradient from three bf16 planes per operand against float64 on the
