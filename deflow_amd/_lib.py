@@ -106,6 +106,9 @@ _SIGS = {
     "df_conv2d_wgrad1_h2_ok": [DfImg, DfImg],
     "df_conv2d_wgrad1_h2_splits": [DfImg, DfImg],
     "df_conv2d_wgrad1_h2": [DfImg, DfImg, P, P, P, I, P, P],
+    "df_conv2d_wgrad_s2_h2_ok": [DfImg, DfImg],
+    "df_conv2d_wgrad_s2_h2_splits": [DfImg, DfImg],
+    "df_conv2d_wgrad_s2_h2": [DfImg, DfImg, P, P, P, I, P, P],
     "df_bn_gelu_bwd_reduce": [DfImg, P, P, I, P, I, P],
     "df_bn_bwd_finalize": [P, I, I, I, L, P, P, P, P],
     "df_bn_gelu_bwd_apply": [DfImg, P, P, P, I, P, P, I, P],
@@ -148,7 +151,7 @@ _SIGS = {
     "df_adam_step_dev": [P, P, P, P, L, F, F, F, F, P, F, P],
 }
 _RESTYPE = {"df_cell_sort_ws_bytes": C.c_int64}
-_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_h2p_ok", "df_conv2d_wgrad_h2p_ok", "df_conv2d_wgrad_h2p_splits", "df_conv2d_wgrad1_h2_ok", "df_conv2d_wgrad1_h2_splits", "df_conv2d_last_dma", "df_gru_wgrad_splits", "df_gru_lean_partial_width"}  # return values, not status
+_RAW = {"df_pillar2_rows_per_band", "df_pillar2_tile", "df_version", "df_cell_sort_ws_bytes", "df_conv2d_tile_m", "df_conv2d_wgrad_splits", "df_conv2d_variant", "df_conv2d_w16_ok", "df_conv2d_x3_ok", "df_conv2d_wgrad_x3_ok", "df_conv2d_h2p_ok", "df_conv2d_wgrad_h2p_ok", "df_conv2d_wgrad_h2p_splits", "df_conv2d_wgrad1_h2_ok", "df_conv2d_wgrad1_h2_splits", "df_conv2d_wgrad_s2_h2_ok", "df_conv2d_wgrad_s2_h2_splits", "df_conv2d_last_dma", "df_gru_wgrad_splits", "df_gru_lean_partial_width"}  # return values, not status
 
 _lib: Optional[C.CDLL] = None
 

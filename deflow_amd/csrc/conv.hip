@@ -3290,6 +3290,232 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
 #endif
 }
 
+// ---- 3x3 STRIDE-2 weight gradient on the fp16 matrix pipe, fp32 tensors split in flight (round 5; df_conv2d_wgrad_s2_h2) ----------
+// The two downsampling layers' weight gradients ran on the fp32 MFMA (wgrad3_ring_kernel<16,2,2>: 113-116 TFLOP/s, 0.68 ms each).
+// This is wgrad3_x3_kernel<2>'s scheme at stride 2: a stage = 16 output pixels of one output row = 3 input rows x 33 input columns,
+// every staged element split once into two scaled fp16 planes; the input columns are stored DE-INTERLEAVED (17 even slots, then 16
+// odd ones, per row and 32-channel half), so that the 16 pixels a tap multiplies -- input columns 2 j + kx - 1 -- are CONSECUTIVE
+// 64-byte rows of the transposing-read image exactly as at stride 1 (kx = 0: even slot j, kx = 1: odd slot j, kx = 2: even slot j + 1).
+// 12 waves = (32 co x 32 ci quadrant) x kernel row, three taps each; two LDS stages of 2 x 15 KB; the next stage's elements are
+// fetched into registers while the current one is multiplied.
+__global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int P = 16, XW = 34, NE = 17, LC = 64;
+  constexpr int YB = 2 * P * 64;                        // dY image bytes of one plane: [2 halves][16 px][64 B]
+  constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows][17 even + 16 odd + 1 pad][64 B]
+  constexpr int PLB = YB + 2 * XH;                      // one plane of a stage (15104 B)
+  constexpr int STG = 2 * PLB;
+  constexpr int NYS = YB / 16, NXS = 2 * XH / 16;       // 16-byte slots: 128 + 816
+  constexpr int NIT = (NYS + NXS + 767) / 768;          // items per thread (2)
+  const float sx = df_h2_scale(*p.amax_x), sdy = df_h2_scale(*p.amax_dy);
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int quad = wave & 3, ky = wave >> 2;
+  const int wci = quad & 1, wco = quad >> 1;
+  int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+  if (p.xcd_map) {   // all (ci, co) tiles of a split on one XCD: they read the same x / dy tiles (see wgrad3_ring_kernel)
+    const int nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lg = df_xcd_swizzle(lin, nt * gridDim.z);
+    const int tile = lg % nt;
+    split = lg / nt;
+    bx = tile % gridDim.x;
+    by = tile / gridDim.x;
+  }
+  const int ci0 = bx * LC, co0 = by * LC;
+  const bool do_bias = p.bias_ws && bx == 0;
+  float bsum = 0.f;
+
+  f32x16 acc[3], acc1[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[t][e] = 0.f; acc1[t][e] = 0.f; }
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.x.ptr, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.dy.ptr, 0, p.dy_bytes, 0x00020000);
+  const int wy = p.dy.w, hx = p.x.h, wx = p.x.w;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(c_begin + p.chunks_per_split, p.total_chunks);
+  const int nst = max(c_end - c_begin, 0);
+
+  // staging items: item e of a thread = 16-byte slot (tid + 768 e) of a plane image: slots 0 .. 127 = dY ([half][px][4]), the rest
+  // = X ([half][row][slot][4]); the source is 8 consecutive fp32 channels (two 16-byte loads)
+  unsigned loff[NIT];     // lane-constant source byte offset relative to the stage's row / segment base
+  int lpx[NIT], lqy[NIT]; // dY: pixel (lqy = -100); X: input column offset xi - 1, input row offset qy - 1 (off: never in range)
+  int ldst[NIT];          // destination byte inside a plane
+#pragma unroll
+  for (int e = 0; e < NIT; ++e) {
+    const int t = tid + 768 * e;
+    if (t < NYS) {
+      const int h = t >> 6, px = (t & 63) >> 2, q = t & 3;
+      lpx[e] = px;
+      lqy[e] = -100;
+      loff[e] = (unsigned)((px * p.dy.ld + co0 + 32 * h + 8 * q) * 4);
+      ldst[e] = 16 * t;
+    } else {
+      const int s_ = t - NYS;
+      const int h = s_ / (3 * XW * 4), r = (s_ - h * 3 * XW * 4) >> 2, q = s_ & 3;
+      const int qy = r / XW, pos = r - qy * XW;
+      const int xi = pos < NE ? 2 * pos : 2 * (pos - NE) + 1;          // even slots first, then the odd ones (pos 33: padding)
+      const bool on = s_ < NXS && pos < 33 && (ci0 + 32 * h + 8 * q) < p.K;
+      lpx[e] = xi - 1;
+      lqy[e] = on ? qy - 1 : (1 << 28);
+      loff[e] = (unsigned)((((qy - 1) * wx + xi - 1) * p.x.ld + ci0 + 32 * h + 8 * q) * 4);
+      ldst[e] = s_ < NXS ? YB + 16 * s_ : -1;
+    }
+  }
+  int cur_n, cur_oy, cur_seg;
+  {
+    const WgChunk c = wg_chunk(p, c_begin < p.total_chunks ? c_begin : 0, P);
+    cur_n = c.n; cur_oy = c.oy; cur_seg = c.ox0 / P;
+  }
+  unsigned yrow = (unsigned)((df_img_base(p.dy, cur_n) + (int64_t)cur_oy * wy * p.dy.ld) * 4);
+  unsigned xrow = (unsigned)((df_img_base(p.x, cur_n) + (int64_t)(2 * cur_oy) * wx * p.x.ld) * 4);
+  const unsigned yrow_step = (unsigned)(wy * p.dy.ld * 4), xrow_step = (unsigned)(2 * wx * p.x.ld * 4);
+  const unsigned yseg_step = (unsigned)(P * p.dy.ld * 4), xseg_step = (unsigned)(2 * P * p.x.ld * 4);
+  f32x4 ra[NIT][2];
+  auto fetch = [&]() {          // the cursor's chunk -> registers, then advance the cursor
+    const int ox0 = cur_seg * P;
+    const unsigned ybase = yrow + (unsigned)cur_seg * yseg_step, xbase = xrow + (unsigned)cur_seg * xseg_step;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      unsigned v;
+      if (lqy[e] == -100) {
+        v = (ox0 + lpx[e] < wy) ? ybase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, v + 16, 0, 0));
+      } else {
+        const bool ok = (unsigned)(2 * cur_oy + lqy[e]) < (unsigned)hx && (unsigned)(2 * ox0 + lpx[e]) < (unsigned)wx;
+        v = ok ? xbase + loff[e] : DMA_BAD;
+        ra[e][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v, 0, 0));
+        ra[e][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, v + 16, 0, 0));
+      }
+    }
+    if (++cur_seg == p.chunks_per_row) {
+      cur_seg = 0;
+      yrow += yrow_step;
+      xrow += xrow_step;
+      if (++cur_oy == p.dy.h) {
+        cur_oy = 0;
+        ++cur_n;
+        yrow = (unsigned)(df_img_base(p.dy, cur_n) * 4);
+        xrow = (unsigned)(df_img_base(p.x, cur_n) * 4);
+      }
+    }
+  };
+  auto stash = [&](int buf) {   // registers -> (hi, lo) planes -> LDS
+    char* st = ldsb + buf * STG;
+#pragma unroll
+    for (int e = 0; e < NIT; ++e) {
+      if (ldst[e] >= 0) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
+        f16x8_t h, l;
+        df_h2_split(v, lqy[e] == -100 ? sdy : sx, h, l);
+        char* d = st + ldst[e];
+        *reinterpret_cast<f16x8_t*>(d) = h;
+        *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+      }
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ldsb;
+  const int tr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;    // (see wgrad3_tr_kernel)
+  const unsigned a_base = lds0 + wco * (P * 64) + (8 * kh) * 64 + tr_lane;
+  const unsigned b_base = lds0 + YB + wci * XH + (ky * XW + 8 * kh) * 64 + tr_lane;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto op8 = [](u32x2_t lo, u32x2_t hi) -> f16x8_t {
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+
+  if (nst > 0) {
+    fetch();
+    stash(0);
+  }
+  __syncthreads();
+  for (int i = 0; i < nst; ++i) {
+    if (i + 1 < nst) fetch();
+    const unsigned so = (unsigned)((i & 1) * STG);
+    const unsigned aa = a_base + so, ba = b_base + so;
+    // all 16 transposing reads of the stage first (dY + three taps, (hi, lo) x (pixels +0..3, +4..7)); offsets: +4 pixels = 256 B,
+    // lo plane = +15104 B, tap kx = 1: odd slots = +17 x 64 B, kx = 2: +64 B
+    u32x2_t fr[16];
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16\n\t"
+        "ds_read_b64_tr_b16 %1, %16 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:15104\n\t"
+        "ds_read_b64_tr_b16 %3, %16 offset:15360\n\t"
+        "ds_read_b64_tr_b16 %4, %17\n\t"
+        "ds_read_b64_tr_b16 %5, %17 offset:256\n\t"
+        "ds_read_b64_tr_b16 %6, %17 offset:15104\n\t"
+        "ds_read_b64_tr_b16 %7, %17 offset:15360\n\t"
+        "ds_read_b64_tr_b16 %8, %17 offset:1088\n\t"
+        "ds_read_b64_tr_b16 %9, %17 offset:1344\n\t"
+        "ds_read_b64_tr_b16 %10, %17 offset:16192\n\t"
+        "ds_read_b64_tr_b16 %11, %17 offset:16448\n\t"
+        "ds_read_b64_tr_b16 %12, %17 offset:64\n\t"
+        "ds_read_b64_tr_b16 %13, %17 offset:320\n\t"
+        "ds_read_b64_tr_b16 %14, %17 offset:15168\n\t"
+        "ds_read_b64_tr_b16 %15, %17 offset:15424\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(fr[0]), "=&v"(fr[1]), "=&v"(fr[2]), "=&v"(fr[3]), "=&v"(fr[4]), "=&v"(fr[5]), "=&v"(fr[6]), "=&v"(fr[7]), "=&v"(fr[8]),
+          "=&v"(fr[9]), "=&v"(fr[10]), "=&v"(fr[11]), "=&v"(fr[12]), "=&v"(fr[13]), "=&v"(fr[14]), "=&v"(fr[15])
+        : "v"(aa), "v"(ba)
+        : "memory");
+    {
+      const f16x8_t ah = op8(fr[0], fr[1]), al = op8(fr[2], fr[3]);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const f16x8_t bh = op8(fr[4 + 4 * kx], fr[5 + 4 * kx]), bl = op8(fr[6 + 4 * kx], fr[7 + 4 * kx]);
+        acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[kx], 0, 0, 0);
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[kx], 0, 0, 0);
+        acc1[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[kx], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6 (8 groups of 2 pixels): value = hi + lo / 2048 (scaled)
+      const char* stp = ldsb + (i & 1) * STG;
+      const int c = tid & 63;
+#pragma unroll
+      for (int j = 0; j < P / 8; ++j) {
+        const int el = (c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31);
+        bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+      }
+    }
+    if (i + 1 < nst) stash((i + 1) & 1);    // ring slot (i + 1) & 1 was last read in stage i - 1, behind the previous barrier
+    __syncthreads();
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(ldsb);
+    if (tid < 512) red[tid] = bsum;
+    __syncthreads();
+    if (tid < LC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[64 * w + tid];
+      p.bias_ws[(int64_t)split * p.N + co0 + tid] = t * (1.f / sdy);
+    }
+  }
+  if ((ci0 + wci * 32) < p.K) {
+    float* o = p.ws + (int64_t)split * p.N * 9 * p.K;
+    const float ix = 1.f / sx, iy = 1.f / sdy;      // exact powers of two
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int ci = ci0 + wci * 32 + li;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = (acc[kx][e] + acc1[kx][e] * H2_LO_INV) * ix * iy;
+      }
+  }
+#endif
+}
+
 // ---- 3x3 stride-1 weight gradient of PRE-SPLIT fp16x2 tensors (round 4; df_conv2d_wgrad_h2p) ------------------------------
 // wgrad3_x3_kernel<2> splits every staged fp32 element in registers (global -> registers -> ~7 VALU per element -> LDS, 5.9
 // VALU + 1.9 LDS instructions per MFMA, the matrix pipe 47 % busy).  Here BOTH operands arrive split: x and dy are "h2" images
@@ -4465,6 +4691,53 @@ extern "C" int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, con
   if (cot == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 64>, grid, lds, s, p);
   if (cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<64, 128>, grid, lds, s, p);
   return launch_wgrad_dma(wgrad1_h2_kernel<64, 64>, grid, lds, s, p);
+}
+
+// 3x3 stride-2 weight gradient, fp32 tensors, fp16x2 products (wgrad3s2_h2_kernel; round 5).  Geometry as df_conv2d_wgrad_mp's
+// stride-2 case (pad 1; Hout = (H - 1) / 2 + 1); DF_WGRAD_S2_H2=0 switches it off.  Workspace [splits][Cout][9][Cin].
+extern "C" int df_conv2d_wgrad_s2_h2_ok(df_img x, df_img dy) {
+  static const int on = getenv("DF_WGRAD_S2_H2") ? atoi(getenv("DF_WGRAD_S2_H2")) : 1;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  return on && x.elt == 0 && dy.elt == 0 && img_ok(x) && img_ok(dy) && x.n == dy.n && dy.h == (x.h - 1) / 2 + 1 && dy.w == (x.w - 1) / 2 + 1 &&
+         (x.c % 32) == 0 && (dy.c % 64) == 0 && (x.ld % 4) == 0 && (dy.ld % 4) == 0 && x.img_stride >= 0 && dy.img_stride >= 0 &&
+         x.grp_off >= 0 && dy.grp_off >= 0 && extent(x) < (int64_t)DMA_BAD && extent(dy) < (int64_t)DMA_BAD;
+}
+
+extern "C" int df_conv2d_wgrad_s2_h2_splits(df_img x, df_img dy) {
+  static const int target = getenv("DF_WGRAD_S2_H2_BLOCKS") ? atoi(getenv("DF_WGRAD_S2_H2_BLOCKS")) : 256;   // one 12-wave workgroup per CU
+  const int tiles = ((x.c + 63) / 64) * (dy.c / 64);
+  const int64_t chunks = (int64_t)dy.n * dy.h * ((dy.w + 15) / 16);
+  int64_t splits = (target + tiles - 1) / tiles;
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  const int64_t cps = (chunks + splits - 1) / splits;
+  return (int)((chunks + cps - 1) / cps);
+}
+
+extern "C" int df_conv2d_wgrad_s2_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits,
+                                     float* bias_ws, void* stream) {
+  DF_REQUIRE(x_amax && dy_amax && ws && df_aligned16(ws), DF_E_ARG);
+  DF_REQUIRE(df_conv2d_wgrad_s2_h2_ok(x, dy) == 1, DF_E_SHAPE);
+  WgradParams p;
+  p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
+  p.amax_x = x_amax; p.amax_dy = dy_amax;
+  p.stride = 2; p.pad = 1; p.K = x.c; p.N = dy.c;
+  auto extent = [](const df_img& d) {
+    return ((int64_t)(d.grp_size - 1) * d.img_stride + (int64_t)(d.n / d.grp_size - 1) * d.grp_off + (int64_t)d.h * d.w * d.ld) * 4;
+  };
+  p.x_bytes = (unsigned)extent(x);
+  p.dy_bytes = (unsigned)extent(dy);
+  p.chunks_per_row = (dy.w + 15) / 16;
+  const int64_t chunks = (int64_t)dy.n * dy.h * p.chunks_per_row;
+  DF_REQUIRE(chunks < (1ll << 31) && splits >= 1, DF_E_SHAPE);
+  p.total_chunks = (int)chunks;
+  p.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
+  static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
+  p.xcd_map = xcd_map;
+  return launch_wgrad_dma(wgrad3s2_h2_kernel, grid, 2 * 2 * 15104, reinterpret_cast<hipStream_t>(stream), p, 768);
 }
 
 // PRE-SPLIT fp16x2 tensors (round 4): x and dy are h2 images (df_img.elt = 2: per pixel and 32-channel chunk one 128-byte line

@@ -793,8 +793,10 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     # round 5: the 1x1 layers' fp32 tensors split in flight (wgrad1_h2_kernel) -- fp16x2 products instead of the fp32 MFMA
     h2_1 = bool(not pre and not t16 and not MFMA_BF16 and ks == 1 and stride == 1 and row_counts is None and _h2_on() and h2_active()
                 and call("df_conv2d_wgrad1_h2_ok", x, dy) == 1)
+    h2_s2 = bool(not pre and not t16 and not MFMA_BF16 and ks == 3 and stride == 2 and row_counts is None and _h2_on() and h2_active()
+                 and call("df_conv2d_wgrad_s2_h2_ok", x, dy) == 1)       # the stride-2 3x3 layers likewise (wgrad3s2_h2_kernel)
     splits = (call("df_conv2d_wgrad_h2p_splits", x, dy) if pre else call("df_conv2d_wgrad1_h2_splits", x, dy) if h2_1
-              else call("df_conv2d_wgrad_splits", x, dy, ks, stride))
+              else call("df_conv2d_wgrad_s2_h2_splits", x, dy) if h2_s2 else call("df_conv2d_wgrad_splits", x, dy, ks, stride))
     taps = ks * ks
     ws = _f32(splits * dy.c * taps * x.c, device=dev)
     prof = PROFILER
@@ -811,6 +813,8 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     elif h2_1:
         call("df_conv2d_wgrad1_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ptr(ws), splits, ptr(bias_ws), stream())
+    elif h2_s2:
+        call("df_conv2d_wgrad_s2_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ptr(ws), splits, ptr(bias_ws), stream())
     elif h2:     # fp32 mode: fp32-accurate product from two scaled fp16 planes per operand (wgrad3_x3_kernel<2>)
         call("df_conv2d_wgrad_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws),
              stream())
@@ -821,7 +825,7 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
              int(MFMA_BF16), stream())
     if prof is not None:
         e1.record()
-        name = ("wgrad3_h2p_kernel<4>" if pre else f"wgrad1_h2_kernel<{128 if dy.c % 128 == 0 else 64},{128 if x.c >= 128 else 64}>" if h2_1 else "wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
+        name = ("wgrad3_h2p_kernel<4>" if pre else f"wgrad1_h2_kernel<{128 if dy.c % 128 == 0 else 64},{128 if x.c >= 128 else 64}>" if h2_1 else "wgrad3s2_h2_kernel" if h2_s2 else "wgrad3_tr_kernel<4>" if t16 else "wgrad3_x3_kernel<2>" if h2 else "wgrad3_x3_kernel<3>" if x3 else f"wgrad1x1_kernel<{128 if x.c >= 128 else 64}>" if ks == 1 and dy.c % 128 == 0
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fbh'[x.elt]}{'fbh'[dy.elt]}"

@@ -310,6 +310,14 @@ int df_conv2d_wgrad1_h2_ok(df_img x, df_img dy);
 int df_conv2d_wgrad1_h2_splits(df_img x, df_img dy);
 int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits, float* bias_ws,
                         void* stream);
+/* the 3x3 STRIDE-2 (pad 1) weight gradient of fp32 x and dy with fp16x2 products (round 5, wgrad3s2_h2_kernel): the two
+ * downsampling layers' form of df_conv2d_wgrad_h2 -- elements split in flight, input columns de-interleaved in LDS so that a tap's
+ * 16 pixels are consecutive rows of the transposing-read image.  _ok / _splits / ws [splits][Cout][9][Cin] / bias_ws / reduce as
+ * above (DF_WGRAD_S2_H2=0: never).  [REF decoder.py:205,213] weight gradient of the UNet encoder's stride-2 ConvWithNorms. */
+int df_conv2d_wgrad_s2_h2_ok(df_img x, df_img dy);
+int df_conv2d_wgrad_s2_h2_splits(df_img x, df_img dy);
+int df_conv2d_wgrad_s2_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits, float* bias_ws,
+                          void* stream);
 /* bf16-STORAGE training (round 3): the 3x3 stride-1 weight gradient of BFLOAT16 x and dy (df_img.elt = 1 on both; W % 32 == 0):
  * bf16 tiles by LDS-DMA into a four-deep ring, fragments by transposing LDS reads (ds_read_b64_tr_b16), fp32 accumulation and
  * fp32 split-K partials.  splits / ws / bias_ws / df_conv2d_wgrad_reduce exactly as df_conv2d_wgrad_mp.  Replaces the weight

@@ -1270,6 +1270,36 @@ def test_wgrad_1x1_h2_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, sliced
     assert rel_err(big[:, :cin] - 0.5, want.reshape(cout, cin)) <= 4e-6 and torch.all(big[:, cin:] == 0.5)
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 2, 16, 64), (128, 256, 2, 6, 40), (32, 64, 3, 7, 33), (96, 64, 1, 2, 130), (64, 64, 1, 1, 1)])
+def test_wgrad_stride2_h2_fp32_accurate(dev, cin, cout, n, h, w):
+    """df_conv2d_wgrad_s2_h2 (wgrad3s2_h2_kernel, round 5): the 3x3 stride-2 weight gradient of fp32 tensors from two scaled fp16
+    planes per operand (input columns de-interleaved in LDS), against float64: <= 2e-6 of the largest entry, the fp32-MFMA ring
+    kernel's error beside it; odd input sizes, widths that are no multiple of the 16-pixel stage, a ragged channel tile, bias sums"""
+    import torch.nn.functional as F
+    from deflow_amd import ops
+    from deflow_amd._lib import img, call, ptr, stream
+    g = torch.Generator().manual_seed(cin * 17 + w)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    x = (torch.randn(n, h, w, cin, generator=g) * 2.0).to(dev)
+    dy = (torch.randn(n, ho, wo, cout, generator=g) * 0.02).to(dev)
+    assert call("df_conv2d_wgrad_s2_h2_ok", img(x), img(dy)) == 1
+    dw = torch.empty(cout, 3, 3, cin, device=dev)
+    db = ops.conv2d_wgrad(img(x), img(dy), 3, 2, dw, want_bias=True)          # fp32 mode -> wgrad3s2_h2_kernel
+    splits = call("df_conv2d_wgrad_splits", img(x), img(dy), 3, 2)
+    ws = torch.empty(splits * cout * 9 * cin, device=dev)
+    call("df_conv2d_wgrad_mp", img(x), img(dy), 3, 2, 1, ptr(ws), splits, None, 0, None, 0, stream())   # the fp32-MFMA kernel
+    dw32 = torch.empty_like(dw)
+    call("df_conv2d_wgrad_reduce", ptr(ws), splits, cout, 9, cin, ptr(dw32), 9 * cin, 0, stream())
+    torch.cuda.synchronize()
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), wref, stride=2, padding=1).backward(dy.cpu().permute(0, 3, 1, 2).double())
+    want = wref.grad.permute(0, 2, 3, 1)
+    e2, e32 = rel_err(dw, want), rel_err(dw32, want)
+    print(f"[parity] wgrad 3x3 s2 {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {e2:.2e} | fp32-MFMA err {e32:.2e} (vs float64)")
+    assert e2 <= 2e-6, (e2, e32)
+    check("h2 s2 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+
+
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
 def test_wgrad_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w):
     """df_conv2d_wgrad_x3 (wgrad3_x3_kernel): the fp32 weight gradient from three bf16 planes per operand against float64 on the
