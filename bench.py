@@ -510,7 +510,10 @@ def main():
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                            "all_mfma_kernels": {k: {"launches_per_step": v["launches"] / args.steps,
                                                     "ms_per_step": v["ms"] / args.steps,
-                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in mfma.items()}}
+                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                                    # input + output (+ weight) bytes once / time: a kernel under 150 TFLOP/s at >= 3.8 TB/s
+                                                    # is a small-K layer waiting for the memory system, not for the matrix pipe
+                                                    "operand_tbps": v["bytes"] / (v["ms"] * 1e-3) / 1e12} for k, v in mfma.items()}}
         # the whole fp16x2 family (every 3x3 stride-1 convolution, data gradient and weight gradient of the step): flop-weighted
         fam = [v for k, v in mfma.items() if ("_x3_" in k and (k.rstrip(">").endswith(",2") or k.endswith(",xp>"))) or "wgrad3_h2p" in k or k == "wgrad3_x3_kernel<2>"]
         if fam:

@@ -3061,19 +3061,21 @@ __global__ __launch_bounds__(768) void wgrad3_x3_kernel(WgradParams p) {
 // ([plane][32-channel half][pixel][64 B]) and a product is three v_mfma_f32_32x32x16_f16 -- 5.3 x the fp32 MFMA rate, which leaves
 // the kernel to the memory system.  COT x CIT tile (128 or 64 each), 4 waves = 2 x 2 wave tiles, 32 pixels per stage, two LDS
 // stages, the next stage's elements in registers while the current one is multiplied; two workgroups per CU.
-template <int COT, int CIT>
+// BF (bf16 MFMA mode, Trainer(dtype="bf16")): ONE bf16 plane per operand (the fp32 element rounded once), one MFMA per product, no scales.
+template <int COT, int CIT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 32;
   constexpr int HY = COT / 32, HX = CIT / 32;          // 32-channel halves of the two operands
   constexpr int HB = P * 64;                           // bytes of one half of one plane: [32 px][64 B]
   constexpr int YB = HY * HB, XB = HX * HB;
-  constexpr int PLB = YB + XB, STG = 2 * PLB;          // plane, stage (hi | lo)
+  constexpr int PLB = YB + XB, STG = (BF ? 1 : 2) * PLB;   // plane, stage (hi | lo; BF: one plane)
   constexpr int NYS = YB / 16, NXS = XB / 16;          // 16-byte slots = 8 channels of one pixel of one plane
   constexpr int NIT = (NYS + NXS) / 256, NIY = NYS / 256;
   constexpr int TCO = COT / 64, TCI = CIT / 64;        // 32-wide tiles per wave and operand
   static_assert(NYS % 256 == 0 && NXS % 256 == 0 && (COT == 64 || COT == 128) && (CIT == 64 || CIT == 128), "tile");
-  const float sx = df_h2_scale(*p.amax_x), sdy = df_h2_scale(*p.amax_dy);
+  float sx = 1.f, sdy = 1.f;
+  if constexpr (!BF) { sx = df_h2_scale(*p.amax_x); sdy = df_h2_scale(*p.amax_dy); }
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
@@ -3168,11 +3170,15 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
       float v[8];
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
-      f16x8_t h, l;
-      df_h2_split(v, e < NIY ? sdy : sx, h, l);
       char* d = st + 16 * (tid + 256 * e);            // (dY slots first, X slots behind them: YB = 16 NYS)
-      *reinterpret_cast<f16x8_t*>(d) = h;
-      *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+      if constexpr (BF) {
+        *reinterpret_cast<bf16x8_t*>(d) = pack_bf16(v);
+      } else {
+        f16x8_t h, l;
+        df_h2_split(v, e < NIY ? sdy : sx, h, l);
+        *reinterpret_cast<f16x8_t*>(d) = h;
+        *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+      }
     }
   };
 
@@ -3187,16 +3193,31 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
     v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
     return __builtin_bit_cast(f16x8_t, v);
   };
-  // one 32 x 16 operand tile = (hi, lo) x (pixels +0..3, +4..7): four transposing reads
+  // one 32 x 16 operand tile = (hi, lo) x (pixels +0..3, +4..7): four transposing reads (BF: the one plane, two reads)
   auto rd4 = [](unsigned hi_addr, unsigned lo_addr, u32x2_t (&r)[4]) {
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %4\n\t"
-        "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
-        "ds_read_b64_tr_b16 %2, %5\n\t"
-        "ds_read_b64_tr_b16 %3, %5 offset:256"
-        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
-        : "v"(hi_addr), "v"(lo_addr)
-        : "memory");
+    if constexpr (BF) {
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %2\n\t"
+          "ds_read_b64_tr_b16 %1, %2 offset:256"
+          : "=&v"(r[0]), "=&v"(r[1])
+          : "v"(hi_addr)
+          : "memory");
+    } else {
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %4\n\t"
+          "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+          "ds_read_b64_tr_b16 %2, %5\n\t"
+          "ds_read_b64_tr_b16 %3, %5 offset:256"
+          : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+          : "v"(hi_addr), "v"(lo_addr)
+          : "memory");
+    }
+  };
+  // after the stage's s_waitcnt: ties a tile's registers to this point of the (volatile, hence ordered) asm sequence, so that no
+  // product can be scheduled in front of the wait that covers its operands
+  auto pin = [](u32x2_t (&r)[4]) {
+    if constexpr (BF) asm volatile("" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+    else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
   };
 
   if (nst > 0) {
@@ -3214,35 +3235,25 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
       for (int t = 0; t < TCO; ++t) rd4(a_base + so + ks * 1024 + t * HB, a_base + so + ks * 1024 + t * HB + PLB, fa[t]);
 #pragma unroll
       for (int t = 0; t < TCI; ++t) rd4(b_base + so + ks * 1024 + t * HB, b_base + so + ks * 1024 + t * HB + PLB, fb[t]);
-      if constexpr (TCO == 2 && TCI == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
-                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])
-                     :: "memory");
-      } else if constexpr (TCO == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
-                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3])
-                     :: "memory");
-      } else if constexpr (TCI == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
-                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])
-                     :: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3])
-                     :: "memory");
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) pin(fa[t]);
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) pin(fb[t]);
 #pragma unroll
       for (int ti = 0; ti < TCO; ++ti) {
-        const f16x8_t ah = op8(fa[ti][0], fa[ti][1]), al = op8(fa[ti][2], fa[ti][3]);
 #pragma unroll
         for (int tj = 0; tj < TCI; ++tj) {
-          const f16x8_t bh = op8(fb[tj][0], fb[tj][1]), bl = op8(fb[tj][2], fb[tj][3]);
-          acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[ti][tj], 0, 0, 0);
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ti][tj], 0, 0, 0);
-          acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[ti][tj], 0, 0, 0);
+          if constexpr (BF) {
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, op8(fa[ti][0], fa[ti][1])),
+                                                                  __builtin_bit_cast(bf16x8_t, op8(fb[tj][0], fb[tj][1])), acc[ti][tj], 0, 0, 0);
+          } else {
+            const f16x8_t ah = op8(fa[ti][0], fa[ti][1]), al = op8(fa[ti][2], fa[ti][3]);
+            const f16x8_t bh = op8(fb[tj][0], fb[tj][1]), bl = op8(fb[tj][2], fb[tj][3]);
+            acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[ti][tj], 0, 0, 0);
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ti][tj], 0, 0, 0);
+            acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[ti][tj], 0, 0, 0);
+          }
         }
       }
     }
@@ -3253,7 +3264,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < P / NG; ++j) {
         const int el = (c >> 5) * (P * 32) + (g * (P / NG) + j) * 32 + (c & 31);
-        bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+        if constexpr (BF) bsum += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(stp)[el] << 16);
+        else bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
       }
     }
     if (i + 1 < nst) stash((i + 1) & 1);    // ring slot (i + 1) & 1 was last read in stage i - 1, behind the previous barrier
@@ -3282,7 +3294,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int co = co0 + (wco * TCO + ti) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            o[(int64_t)co * p.K + ci] = (acc[ti][tj][e] + acc1[ti][tj][e] * H2_LO_INV) * ix * iy;
+            o[(int64_t)co * p.K + ci] = BF ? acc[ti][tj][e] : (acc[ti][tj][e] + acc1[ti][tj][e] * H2_LO_INV) * ix * iy;
           }
         }
       }
@@ -3298,16 +3310,19 @@ __global__ __launch_bounds__(256, 2) void wgrad1_h2_kernel(WgradParams p) {
 // 64-byte rows of the transposing-read image exactly as at stride 1 (kx = 0: even slot j, kx = 1: odd slot j, kx = 2: even slot j + 1).
 // 12 waves = (32 co x 32 ci quadrant) x kernel row, three taps each; two LDS stages of 2 x 15 KB; the next stage's elements are
 // fetched into registers while the current one is multiplied.
+// BF (bf16 MFMA mode): one bf16 plane per operand, one MFMA per product, no scales.
+template <bool BF>
 __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int P = 16, XW = 34, NE = 17, LC = 64;
   constexpr int YB = 2 * P * 64;                        // dY image bytes of one plane: [2 halves][16 px][64 B]
   constexpr int XH = 3 * XW * 64;                       // one X half: [3 rows][17 even + 16 odd + 1 pad][64 B]
   constexpr int PLB = YB + 2 * XH;                      // one plane of a stage (15104 B)
-  constexpr int STG = 2 * PLB;
+  constexpr int STG = (BF ? 1 : 2) * PLB;
   constexpr int NYS = YB / 16, NXS = 2 * XH / 16;       // 16-byte slots: 128 + 816
   constexpr int NIT = (NYS + NXS + 767) / 768;          // items per thread (2)
-  const float sx = df_h2_scale(*p.amax_x), sdy = df_h2_scale(*p.amax_dy);
+  float sx = 1.f, sdy = 1.f;
+  if constexpr (!BF) { sx = df_h2_scale(*p.amax_x); sdy = df_h2_scale(*p.amax_dy); }
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
@@ -3413,11 +3428,15 @@ __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = ra[e][0][k]; v[4 + k] = ra[e][1][k]; }
-        f16x8_t h, l;
-        df_h2_split(v, lqy[e] == -100 ? sdy : sx, h, l);
         char* d = st + ldst[e];
-        *reinterpret_cast<f16x8_t*>(d) = h;
-        *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+        if constexpr (BF) {
+          *reinterpret_cast<bf16x8_t*>(d) = pack_bf16(v);
+        } else {
+          f16x8_t h, l;
+          df_h2_split(v, lqy[e] == -100 ? sdy : sx, h, l);
+          *reinterpret_cast<f16x8_t*>(d) = h;
+          *reinterpret_cast<f16x8_t*>(d + PLB) = l;
+        }
       }
     }
   };
@@ -3446,6 +3465,25 @@ __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
     // all 16 transposing reads of the stage first (dY + three taps, (hi, lo) x (pixels +0..3, +4..7)); offsets: +4 pixels = 256 B,
     // lo plane = +15104 B, tap kx = 1: odd slots = +17 x 64 B, kx = 2: +64 B
     u32x2_t fr[16];
+    if constexpr (BF) {
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\t"
+          "ds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\t"
+          "ds_read_b64_tr_b16 %3, %9 offset:256\n\t"
+          "ds_read_b64_tr_b16 %4, %9 offset:1088\n\t"
+          "ds_read_b64_tr_b16 %5, %9 offset:1344\n\t"
+          "ds_read_b64_tr_b16 %6, %9 offset:64\n\t"
+          "ds_read_b64_tr_b16 %7, %9 offset:320\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(fr[0]), "=&v"(fr[1]), "=&v"(fr[4]), "=&v"(fr[5]), "=&v"(fr[8]), "=&v"(fr[9]), "=&v"(fr[12]), "=&v"(fr[13])
+          : "v"(aa), "v"(ba)
+          : "memory");
+      const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, op8(fr[0], fr[1]));
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, op8(fr[4 + 4 * kx], fr[5 + 4 * kx])), acc[kx], 0, 0, 0);
+    } else {
     asm volatile(
         "ds_read_b64_tr_b16 %0, %16\n\t"
         "ds_read_b64_tr_b16 %1, %16 offset:256\n\t"
@@ -3468,7 +3506,6 @@ __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
           "=&v"(fr[9]), "=&v"(fr[10]), "=&v"(fr[11]), "=&v"(fr[12]), "=&v"(fr[13]), "=&v"(fr[14]), "=&v"(fr[15])
         : "v"(aa), "v"(ba)
         : "memory");
-    {
       const f16x8_t ah = op8(fr[0], fr[1]), al = op8(fr[2], fr[3]);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
@@ -3484,7 +3521,8 @@ __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < P / 8; ++j) {
         const int el = (c >> 5) * (P * 32) + ((tid >> 6) * (P / 8) + j) * 32 + (c & 31);
-        bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
+        if constexpr (BF) bsum += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(stp)[el] << 16);
+        else bsum += (float)reinterpret_cast<const _Float16*>(stp)[el] + (float)reinterpret_cast<const _Float16*>(stp + PLB)[el] * H2_LO_INV;
       }
     }
     if (i + 1 < nst) stash((i + 1) & 1);    // ring slot (i + 1) & 1 was last read in stage i - 1, behind the previous barrier
@@ -3510,7 +3548,7 @@ __global__ __launch_bounds__(768) void wgrad3s2_h2_kernel(WgradParams p) {
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         const int ci = ci0 + wci * 32 + li;
-        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = (acc[kx][e] + acc1[kx][e] * H2_LO_INV) * ix * iy;
+        o[((int64_t)co * 9 + ky * 3 + kx) * p.K + ci] = BF ? acc[kx][e] : (acc[kx][e] + acc1[kx][e] * H2_LO_INV) * ix * iy;
       }
   }
 #endif
@@ -4665,7 +4703,7 @@ extern "C" int df_conv2d_wgrad1_h2_splits(df_img x, df_img dy) {
 
 extern "C" int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits, float* bias_ws,
                                    void* stream) {
-  DF_REQUIRE(x_amax && dy_amax && ws && df_aligned16(ws), DF_E_ARG);
+  DF_REQUIRE(((x_amax && dy_amax) || (!x_amax && !dy_amax)) && ws && df_aligned16(ws), DF_E_ARG);   // both NULL: the bf16 one-plane form
   DF_REQUIRE(df_conv2d_wgrad1_h2_ok(x, dy) == 1, DF_E_SHAPE);
   WgradParams p;
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
@@ -4687,6 +4725,12 @@ extern "C" int df_conv2d_wgrad1_h2(df_img x, df_img dy, const float* x_amax, con
   p.xcd_map = xcd_map;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)2 * 2 * (cot + cit) * 64;      // two stages x two planes x (COT + CIT) / 32 halves x 32 px x 64 B
+  if (!x_amax) {
+    if (cot == 128 && cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 128, true>, grid, lds / 2, s, p);
+    if (cot == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 64, true>, grid, lds / 2, s, p);
+    if (cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<64, 128, true>, grid, lds / 2, s, p);
+    return launch_wgrad_dma(wgrad1_h2_kernel<64, 64, true>, grid, lds / 2, s, p);
+  }
   if (cot == 128 && cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 128>, grid, lds, s, p);
   if (cot == 128) return launch_wgrad_dma(wgrad1_h2_kernel<128, 64>, grid, lds, s, p);
   if (cit == 128) return launch_wgrad_dma(wgrad1_h2_kernel<64, 128>, grid, lds, s, p);
@@ -4718,7 +4762,7 @@ extern "C" int df_conv2d_wgrad_s2_h2_splits(df_img x, df_img dy) {
 
 extern "C" int df_conv2d_wgrad_s2_h2(df_img x, df_img dy, const float* x_amax, const float* dy_amax, float* ws, int splits,
                                      float* bias_ws, void* stream) {
-  DF_REQUIRE(x_amax && dy_amax && ws && df_aligned16(ws), DF_E_ARG);
+  DF_REQUIRE(((x_amax && dy_amax) || (!x_amax && !dy_amax)) && ws && df_aligned16(ws), DF_E_ARG);   // both NULL: the bf16 one-plane form
   DF_REQUIRE(df_conv2d_wgrad_s2_h2_ok(x, dy) == 1, DF_E_SHAPE);
   WgradParams p;
   p.x = x; p.dy = dy; p.ws = ws; p.row_counts = nullptr; p.rows_per_seg = 1; p.bias_ws = bias_ws; p.bf16 = 0;
@@ -4737,7 +4781,8 @@ extern "C" int df_conv2d_wgrad_s2_h2(df_img x, df_img dy, const float* x_amax, c
   dim3 grid((x.c + 63) / 64, dy.c / 64, splits);
   static const int xcd_map = getenv("DF_WGRAD_XCD") ? atoi(getenv("DF_WGRAD_XCD")) : 1;
   p.xcd_map = xcd_map;
-  return launch_wgrad_dma(wgrad3s2_h2_kernel, grid, 2 * 2 * 15104, reinterpret_cast<hipStream_t>(stream), p, 768);
+  if (!x_amax) return launch_wgrad_dma(wgrad3s2_h2_kernel<true>, grid, 2 * 15104, reinterpret_cast<hipStream_t>(stream), p, 768);
+  return launch_wgrad_dma(wgrad3s2_h2_kernel<false>, grid, 2 * 2 * 15104, reinterpret_cast<hipStream_t>(stream), p, 768);
 }
 
 // PRE-SPLIT fp16x2 tensors (round 4): x and dy are h2 images (df_img.elt = 2: per pixel and 32-channel chunk one 128-byte line

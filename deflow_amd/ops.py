@@ -593,7 +593,10 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
             elif (wide and bn == 64 and seg64 and y.h % seg64 == 0 and m_rows % 512 == 0 and (epi != EPI_STATS or rpg % 512 == 0)
                     and m_rows // 512 >= 512):
                 name = f"conv_halo_x3_kernel<512,64,8,1,{seg64},8,1,{'true' if x.elt else 'false'}>"
-        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag))
+        # operand bytes of the call (input + output images once, the weights once): what an HBM-bound small-K layer is priced against
+        esz = lambda d: (4, 2, 4)[d.elt]
+        obytes = float(x.n * x.h * x.w * x.c * esz(x) + y.n * y.h * y.w * y.c * esz(y) * (2 if accumulate else 1) + w_ohwi.numel() * 4)
+        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), flops, e0, e1, tag, obytes))
     return fused_bn
 
 
@@ -791,9 +794,10 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
         assert ks == 3 and stride == 1 and row_counts is None and call("df_conv2d_wgrad_h2p_ok", x, dy, ks, stride) == 1
     t16 = bool(x.elt == 1 and dy.elt == 1)
     # round 5: the 1x1 layers' fp32 tensors split in flight (wgrad1_h2_kernel) -- fp16x2 products instead of the fp32 MFMA
-    h2_1 = bool(not pre and not t16 and not MFMA_BF16 and ks == 1 and stride == 1 and row_counts is None and _h2_on() and h2_active()
+    fly = (h2_active() and _h2_on()) or (MFMA_BF16 and os.environ.get("DF_WGRAD_BF_FLY", "1") != "0")   # (bf16 mode: the one-plane forms)
+    h2_1 = bool(not pre and not t16 and ks == 1 and stride == 1 and row_counts is None and fly
                 and call("df_conv2d_wgrad1_h2_ok", x, dy) == 1)
-    h2_s2 = bool(not pre and not t16 and not MFMA_BF16 and ks == 3 and stride == 2 and row_counts is None and _h2_on() and h2_active()
+    h2_s2 = bool(not pre and not t16 and ks == 3 and stride == 2 and row_counts is None and fly
                  and call("df_conv2d_wgrad_s2_h2_ok", x, dy) == 1)       # the stride-2 3x3 layers likewise (wgrad3s2_h2_kernel)
     splits = (call("df_conv2d_wgrad_h2p_splits", x, dy) if pre else call("df_conv2d_wgrad1_h2_splits", x, dy) if h2_1
               else call("df_conv2d_wgrad_s2_h2_splits", x, dy) if h2_s2 else call("df_conv2d_wgrad_splits", x, dy, ks, stride))
@@ -812,9 +816,11 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
     elif t16:      # bf16-storage mode: both tensors bfloat16 in memory (transposing-read kernel, 3x3 stride 1 only)
         call("df_conv2d_wgrad_bf16", x, dy, ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws), stream())
     elif h2_1:
-        call("df_conv2d_wgrad1_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ptr(ws), splits, ptr(bias_ws), stream())
+        call("df_conv2d_wgrad1_h2", x, dy, None if MFMA_BF16 else ptr(amax_of(x, dev)), None if MFMA_BF16 else ptr(amax_of(dy, dev)),
+             ptr(ws), splits, ptr(bias_ws), stream())
     elif h2_s2:
-        call("df_conv2d_wgrad_s2_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ptr(ws), splits, ptr(bias_ws), stream())
+        call("df_conv2d_wgrad_s2_h2", x, dy, None if MFMA_BF16 else ptr(amax_of(x, dev)), None if MFMA_BF16 else ptr(amax_of(dy, dev)),
+             ptr(ws), splits, ptr(bias_ws), stream())
     elif h2:     # fp32 mode: fp32-accurate product from two scaled fp16 planes per operand (wgrad3_x3_kernel<2>)
         call("df_conv2d_wgrad_h2", x, dy, ptr(amax_of(x, dev)), ptr(amax_of(dy, dev)), ks, stride, ks // 2, ptr(ws), splits, ptr(bias_ws),
              stream())
@@ -829,7 +835,9 @@ def conv2d_wgrad(x: DfImg, dy: DfImg, ks: int, stride: int, dw: torch.Tensor, ld
                 else (_wgrad3_name(stride) if ks == 3 else f"wgrad_kernel<{ks},{stride},32>"))
         # ^ mirrors df_conv2d_wgrad's dispatch (DMA form for 3x3 stride 1)
         tag = f"wgrad {ks}x{ks} s{stride} {x.c}->{dy.c} @{dy.h}x{dy.w} x{dy.n} {'fbh'[x.elt]}{'fbh'[dy.elt]}"
-        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag))
+        esz = lambda d: (4, 2, 4)[d.elt]
+        prof.records.append((name + ("/bf16" if MFMA_BF16 else ""), 2.0 * dy.n * dy.h * dy.w * taps * x.c * dy.c, e0, e1, tag,
+                             float(x.n * x.h * x.w * x.c * esz(x) + dy.n * dy.h * dy.w * dy.c * esz(dy))))
     if want_bias and os.environ.get("DF_FUSE_REDUCE", "1") != "0":   # weight + bias partials in one launch
         db = _f32(dy.c, device=dev)
         call("df_conv2d_wgrad_reduce_bias", ptr(ws), splits, dy.c, taps, x.c, dw.data_ptr() + 4 * dw_off,

@@ -304,7 +304,8 @@ int df_conv2d_wgrad_h2(df_img x, df_img dy, const float* x_amax, const float* dy
  * (x_amax / dy_amax as for df_conv2d_h2), three MFMAs per product, so that the kernel runs at the memory system's pace instead of the
  * fp32 MFMA's.  _ok: 1 if the form takes the call (same geometry, Cin % 32 == 0, Cout % 64 == 0, DMA-addressable tensors;
  * DF_WGRAD1_H2=0: never); _splits: its split-K count; ws [splits][Cout][Cin], bias_ws [splits][Cout] or NULL, then
- * df_conv2d_wgrad_reduce(_bias) as for df_conv2d_wgrad_mp.  [REF decoder.py:205,213] weight gradient of the UNet's 1x1 convolutions
+ * df_conv2d_wgrad_reduce(_bias) as for df_conv2d_wgrad_mp.  x_amax = dy_amax = NULL: the bf16-MFMA training mode's form (ONE bf16
+ * plane per operand, one MFMA per product; also for df_conv2d_wgrad_s2_h2).  [REF decoder.py:205,213] weight gradient of the UNet's 1x1 convolutions
  * (the reference's backbone: scripts/network/models/basic/unet.py UpsampleSkip u1 / u3 through torch autograd). */
 int df_conv2d_wgrad1_h2_ok(df_img x, df_img dy);
 int df_conv2d_wgrad1_h2_splits(df_img x, df_img dy);

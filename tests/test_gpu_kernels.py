@@ -1268,6 +1268,14 @@ def test_wgrad_1x1_h2_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w, sliced
     ops.conv2d_wgrad(img(x), dyi, 1, 1, big, ld_co=cin + 32, accumulate=True)
     torch.cuda.synchronize()
     assert rel_err(big[:, :cin] - 0.5, want.reshape(cout, cin)) <= 4e-6 and torch.all(big[:, cin:] == 0.5)
+    # bf16 MFMA mode: the one-plane form = exact products of the bf16-rounded operands
+    with ops.mfma_bf16(True, False):
+        dwb = torch.empty(cout, 1, 1, cin, device=dev)
+        dbb = ops.conv2d_wgrad(img(x), dyi, 1, 1, dwb, want_bias=True)
+    torch.cuda.synchronize()
+    wantb = torch.einsum("nhwo,nhwi->oi", dyt.bfloat16().cpu().double(), x.bfloat16().cpu().double()).reshape(cout, 1, 1, cin)
+    assert rel_err(dwb, wantb) <= 2e-6, rel_err(dwb, wantb)
+    check("bf16 1x1 wgrad bias", dbb, dyt.bfloat16().cpu().double().sum((0, 1, 2)).float(), 2e-6)
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 2, 16, 64), (128, 256, 2, 6, 40), (32, 64, 3, 7, 33), (96, 64, 1, 2, 130), (64, 64, 1, 1, 1)])
@@ -1298,6 +1306,14 @@ def test_wgrad_stride2_h2_fp32_accurate(dev, cin, cout, n, h, w):
     print(f"[parity] wgrad 3x3 s2 {cin}->{cout} @{h}x{w}x{n}: fp16x2 err {e2:.2e} | fp32-MFMA err {e32:.2e} (vs float64)")
     assert e2 <= 2e-6, (e2, e32)
     check("h2 s2 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+    with ops.mfma_bf16(True, False):      # bf16 MFMA mode: the one-plane form = exact products of the bf16-rounded operands
+        dwb = torch.empty(cout, 3, 3, cin, device=dev)
+        dbb = ops.conv2d_wgrad(img(x), img(dy), 3, 2, dwb, want_bias=True)
+    torch.cuda.synchronize()
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.bfloat16().cpu().permute(0, 3, 1, 2).double(), wref, stride=2, padding=1).backward(dy.bfloat16().cpu().permute(0, 3, 1, 2).double())
+    assert rel_err(dwb, wref.grad.permute(0, 2, 3, 1)) <= 2e-6
+    check("bf16 s2 wgrad bias", dbb, dy.bfloat16().cpu().double().sum((0, 1, 2)).float(), 2e-6)
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 8, 64), (128, 128, 2, 5, 32), (256, 128, 1, 4, 96), (64, 64, 3, 2, 256), (32, 64, 2, 6, 128)])
