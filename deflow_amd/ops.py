@@ -506,12 +506,12 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
              ks, stride, ks // 2, mode, epi, ptr(scale), ptr(shift), ptr(stats), 0, ptr(ya), stream())
     elif pre:      # 1x1 (or stride-2) convolution with a pre-split OUTPUT: the fp32-input kernels, fp16x2 on the fragments when x has a bound
         wa = None
-        if h2f:
+        wp = _wprep_planes(w_ohwi) if h2f else None
+        if h2f and wp is None:      # (the in-kernel weight split, DF_CONV_H2F_WP=0: needs the weights' bound)
             wa = W_AMAX
             if wa is None:
                 wa = amax_slot(w_ohwi.device)
                 call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
-        wp = _wprep_planes(w_ohwi) if h2f else None
         if wp is not None:      # the step's WeightPrep holds this layer's planes: no weight split in the kernel (conv_dma_kernel<.., H2, BP>)
             call("df_conv2d_h2f_wp", x, ptr(w_ohwi), ptr(wp[0]), ptr(x._amax), ptr(wp[1]), ptr(bias), y, ptr(y._amax), ks, stride, ks // 2, mode,
                  epi, ptr(scale), ptr(shift), ptr(stats), 0, None, stream())
@@ -526,11 +526,11 @@ def conv2d(x: DfImg, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], y: DfIm
              ptr(scale), ptr(shift), ptr(stats), int(accumulate), ptr(ya), stream())
     elif h2f:
         # 1x1 / stride-2 convolutions whose input already carries a bound: fp16x2 on the fragments of the DMA-tile kernel
+        wp = _wprep_planes(w_ohwi)
         wa = W_AMAX
-        if wa is None:
+        if wp is None and wa is None:      # (the in-kernel weight split, DF_CONV_H2F_WP=0: needs the weights' bound)
             wa = amax_slot(w_ohwi.device)
             call("df_absmax", img(w_ohwi.reshape(1, 1, -1, w_ohwi.shape[-1])), ptr(wa), stream())
-        wp = _wprep_planes(w_ohwi)
         if wp is not None:
             call("df_conv2d_h2f_wp", x, ptr(w_ohwi), ptr(wp[0]), ptr(x._amax), ptr(wp[1]), ptr(bias), y, None, ks, stride, ks // 2, mode, epi,
                  ptr(scale), ptr(shift), ptr(stats), int(accumulate), ptr(ya), stream())

@@ -124,8 +124,8 @@ BIG_CONV_CASES = [  # cin, cout, k, stride, n, h, w, forward kernel, dgrad kerne
     (64, 64, 3, 1, 2, 32, 256, "conv_halo_x3_kernel<256,64,4,2,1,4,2>", "conv_halo_x3_kernel<256,64,4,2,1,4,2>", "wgrad3_x3_kernel<2>"),
     (128, 64, 3, 1, 2, 64, 128, "conv_halo_x3_kernel<128,64,4,2,1,8,2>", "conv_halo_x3_kernel<128,128,2,4,1,4,2>", "wgrad3_x3_kernel<2>"),
     (256, 128, 3, 1, 3, 64, 64, "conv_halo_x3_kernel<128,128,2,4,2,4,2>", "conv_halo_x3_kernel<128,128,2,4,2,4,2>", "wgrad3_x3_kernel<2>"),
-    (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1x1_kernel<128>"),
-    (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad3_ring_kernel<16,2,2>"),
+    (512, 256, 1, 1, 2, 64, 128, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,128,2,4>", "wgrad1_h2_kernel<128,128>"),
+    (64, 128, 3, 2, 2, 128, 256, "conv_dma_kernel<128,128,2,4>", "conv_dma_kernel<128,64,4,2>", "wgrad3s2_h2_kernel"),
 ]
 
 
