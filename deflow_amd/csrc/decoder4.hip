@@ -636,9 +636,6 @@ extern "C" int df_gru_xtab(df_gru_weights wts, float* xtab, void* stream) {
 
 extern "C" int df_gru_lean_partial_width(void) { return PW4; }
 
-int df_launch_gru_fwd5(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts, int B, int N,
-                       int num_iters, df_gru_weights wts, const float* xtab, float* flow, float* hsave, void* stream);
-
 extern "C" int df_gru_lean_fwd(df_img before, df_img after, const int32_t* coords, const float* offs, const int32_t* counts, int B,
                                int N, int num_iters, df_gru_weights wts, const float* xtab, float* flow, float* hsave, int mfma_bf16,
                                void* stream) {
@@ -649,11 +646,8 @@ extern "C" int df_gru_lean_fwd(df_img before, df_img after, const int32_t* coord
   DF_REQUIRE(wts.w_zr && wts.w_q && wts.w_1 && wts.w_2 && wts.b_2 && df_aligned16(wts.w_zr) && df_aligned16(wts.w_q) &&
                  df_aligned16(wts.w_1) && df_aligned16(xtab) && (!hsave || df_aligned16(hsave)),
              DF_E_ARG);
-  // DF_GRU_WS=1 (bf16x2 mode only): the weight-stationary experiment of csrc/decoder5.hip -- exact, not faster (see its header)
-  const char* ws_env = getenv("DF_GRU_WS");           // (read per call: the tests switch it inside one process)
-  const bool ws_on = ws_env != nullptr && ws_env[0] == '1';
-  if (mfma_bf16 == 3 && ws_on)
-    return df_launch_gru_fwd5(before, after, coords, offs, counts, B, N, num_iters, wts, xtab, flow, hsave, stream);
+  // (the weight-stationary forward experiment of round 5 is NOT part of the library: tools/experiments/decoder5_ws.hip -- exact only
+  //  with matrix-pipe drains after every tile, then no faster than this kernel, and without them one wrong tile in some launches)
   Gru4Params p;
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;
   p.N = N; p.T = num_iters; p.w = wts; p.xtab = xtab; p.flow = flow; p.hsave = hsave;

@@ -104,6 +104,11 @@ def main():
                          "the default generator's pc1 / pose1 / gt flow differ in the last bit between hosts, which is enough to move "
                          "points across 0.1 m voxel edges (found with the configs[4] digest: deep-layer gradients off by percents on "
                          "the GPU box although every kernel was right)")
+    ap.add_argument("--weights", default=None,
+                    help="a state_dict (torch.save) to take instead of the seeded initialisation -- the CONDITIONED weights of round 5 "
+                         "(tests/helpers/conditioned_weights.py: 50 fp32 Adam steps of the HIP trainer, dumped on the GPU box)")
+    ap.add_argument("--out", default=None, help="output file name under tests/golden/ (default: derived from the shape)")
+    ap.add_argument("--only64", type=int, default=0, help="1: float64 oracle only (no fp32-oracle error fields)")
     args = ap.parse_args()
     grid, n_pts, B = args.grid, args.n_pts, args.batch
     torch.set_num_threads(args.threads)
@@ -116,6 +121,8 @@ def main():
     ref = O.DeFlow(**cfg).train()
     sd = copy.deepcopy(ref.state_dict())
     del ref
+    if args.weights:
+        sd = {k: v.clone() for k, v in torch.load(args.weights, map_location="cpu").items()}
     # (the point spread follows the metric extent of the grid, as synth_batch's grid_hw does for the 0.2 m voxels)
     batch = synth_batch(B, n_pts, seed=args.seed, grid_hw=(int(round(grid * args.voxel / 0.2)),) * 2,
                         exact=bool(args.exact_synth))
@@ -123,7 +130,8 @@ def main():
          "init_seed": args.init_seed, "threads": args.threads, "exact_synth": args.exact_synth}
     outs = {}
     spill_root = os.environ.get("DF_DIGEST_SPILL", "/tmp/df_digest_spill")
-    for tag in ("32", "64"):                       # one precision at a time, its tape released before the next
+    d["weights"] = os.path.basename(args.weights) if args.weights else ""
+    for tag in (("64",) if args.only64 else ("32", "64")):                       # one precision at a time, its tape released before the next
         m = O.DeFlow(**cfg)
         m.load_state_dict(sd)
         m = (m.double() if tag == "64" else m).train()
@@ -136,6 +144,8 @@ def main():
                      {k: p.grad.detach().double() for k, p in m.named_parameters()}, float(loss.detach()))
         del res, loss, m
         print(tag, "loss", outs[tag][2], flush=True)
+    if args.only64:
+        outs["32"] = outs["64"]          # (error fields of the fp32 oracle read 0: not measured)
     (res32, g32, l32), (res64, g64, l64) = outs["32"], outs["64"]
     d["loss32"], d["loss64"] = l32, l64
     for b in range(B):
@@ -156,7 +166,7 @@ def main():
         den = float(a.norm() * g.norm())
         d[f"grad.{k}.e32_cos"] = 0.0 if den == 0 else max(0.0, 1.0 - float(torch.dot(a.reshape(-1), g.reshape(-1))) / den)
     name = f"bs16_{grid}_digest.npz" if (B, args.iters) == (16, 4) else f"bs{B}_{grid}_it{args.iters}_digest.npz"
-    out = os.path.join(ROOT, "tests", "golden", name)
+    out = os.path.join(ROOT, "tests", "golden", args.out or name)
     np.savez_compressed(out, **d)
     print("wrote", out, os.path.getsize(out), "bytes")
 

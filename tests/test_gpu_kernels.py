@@ -593,7 +593,7 @@ def _load_head(cls, g, dev, **kw):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("form", ["lean_ws", "lean", "full"])   # round 5: weight-stationary forward / weight-streaming lean kernels / round 4's
+@pytest.mark.parametrize("form", ["lean", "full"])   # round 5's lean kernels (the default) / round 4's (DF_GRU_LEAN=0)
 @pytest.mark.parametrize("iters", [1, 4, 8, 16])       # 16: [REF assets/slurm/1_train.sh:50] (model.target.num_iters=16 ablation)
 def test_gru_decoder_golden(dev, golden_dir, iters, form, monkeypatch):
     """REAL reference vectors: ConvGRUDecoder forward + all gradients ([REF decoder.py:141-199]).  Each tensor is measured
@@ -603,7 +603,6 @@ def test_gru_decoder_golden(dev, golden_dir, iters, form, monkeypatch):
     import parity
     from deflow_amd.decoder import ConvGRUDecoder
     monkeypatch.setenv("DF_GRU_LEAN", "0" if form == "full" else "1")
-    monkeypatch.setenv("DF_GRU_WS", "1" if form == "lean_ws" else "0")
     g = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}.npz")))
     g64 = dict(np.load(os.path.join(golden_dir, f"g2_grudecoder_it{iters}_f64.npz")))
     t = lambda a: torch.from_numpy(a)

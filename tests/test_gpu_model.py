@@ -2,6 +2,7 @@
 reference-generated orchestration golden (G5), and size-independent properties at the BASELINE config sizes."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -751,6 +752,72 @@ def test_configs4_shape_training_step(dev, monkeypatch, golden_dir):
     in the projection form of _bs16_case; then the bf16 training mode (bf16 MFMA operands + bf16 storage) against the same FLOAT64
     digests at the stated bound BF16_GRAD_RMS (round 3 compared it with the HIP fp32 step: a self-comparison)."""
     _bs16_case(dev, monkeypatch, 1024, 160000, "cfg4_train", golden_dir, digest="bs4_1024_it8_digest.npz", bf16=True)
+
+
+BF16_GRAD_RMS_CONDITIONED = 3e-2     # bf16 training mode on CONDITIONED weights: per-tensor rms-relative error bound of every parameter gradient
+
+
+def test_bf16_gradients_on_conditioned_weights(dev, golden_dir):
+    """the bf16 training mode's gradients against FLOAT64 at weights a run would have, not at the initialisation
+    (where test_configs4_shape_training_step states 1e-1): 50 fp32 Adam steps of the HIP trainer (tests/helpers/conditioned_weights.py;
+    loss 6.37 -> 4.5, BatchNorm running statistics moved), then ONE step at BASELINE configs[4]'s per-GPU shape (4 pairs, 1024 x 1024,
+    160 000 points, 8 GRU iterations) in bf16 mode (bf16 MFMA operands + bf16 storage) against the float64 oracle's digest for those
+    weights (oracle/gen_digest_bs16.py --weights, generated once in the build container from the GPU box's dump of the same 50 steps:
+    the engine is deterministic).  Per tensor: 16 random-sign projections of the error, each N(0, ||e||^2):
+        |proj(bf16) - proj(fp64)| <= 4.5 x 3e-2 x ||g_fp64||      and the gradient norm within 3e-2;
+    the fp32 step on the same weights is checked against the same digest at 1e-4 first (the weights ARE the digest's)."""
+    import deflow_amd
+    import parity
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    from conditioned_weights import conditioned_state
+    from oracle.gen_digest_bs16 import project
+    from deflow_amd.synth import synth_batch
+    from deflow_amd.optim import Trainer
+    from deflow_amd import ops
+    dg = dict(np.load(os.path.join(golden_dir, "bs4_1024_it8_w50_digest.npz")))
+    grid, n_pts, B, voxel, iters = int(dg["grid"]), int(dg["n_pts"]), int(dg["batch"]), float(dg["voxel"]), int(dg["iters"])
+    assert (grid, n_pts, B, iters) == (1024, 160000, 4, 8)
+    sd, losses = conditioned_state(dev)
+    assert losses[-1] < 0.8 * losses[0], losses[::7]
+    half = 0.5 * voxel * grid
+    cfg = dict(voxel_size=[voxel, voxel, 6], point_cloud_range=[-half, -half, -3, half, half, 3], grid_feature_size=[grid, grid], num_iters=iters)
+    bd = to_dev(synth_batch(B, n_pts, seed=int(dg["seed"]), grid_hw=(int(round(grid * voxel / 0.2)),) * 2, exact=True), dev)
+    loss64 = float(dg["loss64"])
+
+    def step(dtype):
+        m = deflow_amd.DeFlow(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(dev).train()
+        tr = Trainer(m, lr=0.0, dtype=dtype)
+        with ops.mfma_bf16(dtype == "bf16", dtype == "bf16" and tr.bf16_store), torch.no_grad():
+            tr.flat.zero_grad(); tr.sink.begin()
+            loss = tr._forward_backward(bd)
+        torch.cuda.synchronize()
+        out = {}
+        for k, p in m.named_parameters():
+            if parity.is_bn_shadowed_bias(k):
+                continue
+            l2 = float(dg[f"grad.{k}.l2"])
+            dp = np.abs(project("grad." + k, p.grad).numpy() - dg[f"grad.{k}.proj"]).max()
+            out[k] = (dp / max(l2, 1e-300), abs(float(p.grad.double().norm()) - l2) / max(l2, 1e-300))
+        return float(loss), out
+
+    l32, e32 = step("fp32")
+    assert abs(l32 - loss64) <= 1e-4 * abs(loss64), (l32, loss64)
+    w32 = max(e32.items(), key=lambda kv: kv[1][0])
+    assert w32[1][0] <= 4.5 * 1e-4, ("the regenerated weights are not the digest's", w32)
+    l16, e16 = step("bf16")
+    worst = max(e16.items(), key=lambda kv: kv[1][0])
+    worst_n = max(e16.items(), key=lambda kv: kv[1][1])
+    for k, (dp, dn) in e16.items():
+        parity.record("cfg4_w50_bf16", "grad " + k, max_proj_err_over_l2=dp, norm_err=dn, rms_bound=BF16_GRAD_RMS_CONDITIONED,
+                      ok=dp <= 4.5 * BF16_GRAD_RMS_CONDITIONED and dn <= BF16_GRAD_RMS_CONDITIONED)
+    print(f"[parity] conditioned weights (50 fp32 steps), configs[4] shape: fp32 worst projection error / ||g|| {w32[1][0]:.2e} ({w32[0]}); "
+          f"bf16 loss {l16:.5f} / {loss64:.5f}, worst projection error / ||g|| {worst[1][0]:.3e} ({worst[0]}), worst norm error "
+          f"{worst_n[1][1]:.3e} ({worst_n[0]}) -- bound 4.5 x {BF16_GRAD_RMS_CONDITIONED} / {BF16_GRAD_RMS_CONDITIONED}")
+    assert abs(l16 - loss64) <= 2e-3 * abs(loss64), (l16, loss64)
+    bad = [(k, v) for k, v in e16.items() if not (v[0] <= 4.5 * BF16_GRAD_RMS_CONDITIONED and v[1] <= BF16_GRAD_RMS_CONDITIONED)]
+    assert not bad, bad[:6]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
