@@ -392,7 +392,8 @@ class ConvGRUDecoder(nn.Module):
                 call("df_gru_lean_wgrad", ptr(hs), ptr(gpl), ptr(ps.counts), B, N, T, ptr(ws), nsplit, 3 if x2 else (1 if bf else 0), s)
             dW_all = torch.empty(384, 192, **f32)
             call("df_conv2d_wgrad_reduce", ptr(ws), nsplit, 384, 1, 128, ptr(dW_all), 192, 0, s)
-            nsp1 = 128
+            # (round 5: 128 -> 1024 split-K workgroups -- 128 left half the CUs idle and 2.5 MB in flight: 0.42 ms for 0.8 GB of planes)
+            nsp1 = int(os.environ.get("DF_GRU_HEAD_SPLITS", "1024"))
             ws1 = torch.empty(nsp1, 32, 128, **f32)
             with ops.timed("gru_head_wgrad", flops=2.0 * 32 * 192 * B * N, bytes=B * N * 4.0 * (32 + 192)):
                 call("df_gru_lean_head_wgrad", ptr(dpre1), hs.data_ptr() + 4 * T * BN * 128, ptr(ps.counts), B, N, ptr(ws1), nsp1, s)
