@@ -21,7 +21,33 @@ def _f32(*shape, device) -> torch.Tensor:
 def ohwi(w: torch.Tensor) -> torch.Tensor:
     """Conv weight [O,I,kh,kw] -> contiguous [O,kh,kw,I] memory (free when the parameter is channels_last)."""
     v = w.detach().permute(0, 2, 3, 1)
-    return v if v.is_contiguous() else v.contiguous()
+    if v.is_contiguous():
+        v._df_keep = True       # a VIEW of the parameter: stable address, shared version counter -- the per-tensor caches may key on it
+        return v
+    # a parameter that is NOT channels_last (a plain nn.Module nobody converted): the contiguous copy is kept while the parameter is
+    # unchanged, so that its transposes / fp16 planes are too (one copy per parameter, replaced when an optimizer writes it)
+    try:
+        key, epoch = (w.data_ptr(), tuple(w.shape)), (w._version, WEIGHT_GEN[0])
+    except RuntimeError:
+        return v.contiguous()
+    hit = _OHWI_CACHE.get(key)
+    if hit is not None and hit[1] == epoch:
+        return hit[0]
+    c = v.contiguous()
+    c._df_keep = True
+    if hit is not None:         # the superseded copy's transpose and planes go with it
+        ck = (hit[0].data_ptr(), tuple(hit[0].shape))
+        old_t = _WT_CACHE.pop(ck, None)
+        if old_t is not None:
+            _PLANE_CACHE.pop((old_t[0].data_ptr(), tuple(old_t[0].shape)), None)
+        _PLANE_CACHE.pop(ck, None)
+    if len(_OHWI_CACHE) > 256:
+        _OHWI_CACHE.clear()
+    _OHWI_CACHE[key] = (c, epoch, w)
+    return c
+
+
+_OHWI_CACHE: dict = {}
 
 
 class KernelProfiler:
@@ -408,12 +434,11 @@ def _split_h2(w_ohwi: torch.Tensor):
     if wa is None:
         # outside a trainer step (inference, plain autograd): planes are kept per weight tensor until it changes -- an eval-mode forward
         # split every 3x3 layer's weights on every call (round 5: 14 df_split_h2 + 21 df_absmax launches of the 95 of a B = 1 forward)
-        try:
-            key = (w_ohwi.data_ptr(), w_ohwi._version, PARAM_GEN[0], tuple(w_ohwi.shape))
-        except RuntimeError:        # inference-mode tensors do not track versions
-            key = None
+        # ONE entry per weight tensor (keyed by address and shape, validated by its write epoch): a changed tensor replaces its entry,
+        # so plain-autograd training does not pile up a triple per layer and step until a clear
+        key, epoch = _cache_key(w_ohwi)
         hit = _PLANE_CACHE.get(key) if key is not None else None
-        if hit is not None:
+        if hit is not None and hit[3] == epoch:
             return hit[0], hit[1]
         # (a bound of its own tensor, NOT a pooled slot: amax_pool_reset() recycles those between steps)
         wa = torch.zeros(1, dtype=torch.float32, device=w_ohwi.device)
@@ -421,9 +446,9 @@ def _split_h2(w_ohwi: torch.Tensor):
         w2 = torch.empty(2 * w_ohwi.numel(), dtype=torch.float16, device=w_ohwi.device)
         call("df_split_h2", ptr(w_ohwi), ptr(wa), ptr(w2), w_ohwi.numel(), stream())
         if key is not None:
-            if len(_PLANE_CACHE) > 128:
+            if len(_PLANE_CACHE) > 256:
                 _PLANE_CACHE.clear()
-            _PLANE_CACHE[key] = (w2, wa, w_ohwi)     # (the tensor is kept: its address cannot be reused while cached)
+            _PLANE_CACHE[key] = (w2, wa, w_ohwi, epoch)     # (the tensor is kept: its address cannot be reused while cached)
         return w2, wa
     w2 = torch.empty(2 * w_ohwi.numel(), dtype=torch.float16, device=w_ohwi.device)
     call("df_split_h2", ptr(w_ohwi), ptr(wa), ptr(w2), w_ohwi.numel(), stream())
@@ -431,6 +456,21 @@ def _split_h2(w_ohwi: torch.Tensor):
 
 
 _PLANE_CACHE: dict = {}
+_WT_CACHE: dict = {}
+
+
+def _cache_key(t: torch.Tensor):
+    """-> ((address, shape), write epoch) of a weight tensor for the per-tensor caches of non-trainer callers; (None, None) for
+    tensors that do not track versions (inference mode)"""
+    # only tensors MARKED as having a stable identity (`_df_keep`): ops.ohwi's view of a channels_last parameter and the transposes
+    # weight_transpose keeps for those.  Anything else -- a per-call contiguous copy, the decoder's packed gate matrices, a gradient
+    # passed through weight_transpose -- is a fresh tensor whose address may repeat with version 0: never cached
+    if not getattr(t, "_df_keep", False):
+        return None, None
+    try:
+        return (t.data_ptr(), tuple(t.shape)), (t._version, WEIGHT_GEN[0])
+    except RuntimeError:
+        return None, None
 
 
 def _wprep_planes(w_ohwi: torch.Tensor):
@@ -609,6 +649,10 @@ def conv_tile_m(rows_per_group: int, cout: int) -> int:
 # plus PARAM_GEN, which every HIP-side writer that bypasses autograd's counters bumps (Adam on the flat arena, the
 # running-statistics update of a training forward).
 PARAM_GEN = [0]
+# ... and WEIGHT_GEN, bumped only where WEIGHTS are written that way (the arena's Adam kernel, a captured step's replay): the epoch of the
+# per-tensor weight caches (ohwi copies, transposes, fp16 planes) -- the running-statistics updates of a training forward bump
+# PARAM_GEN eighteen times per step and would void them for nothing
+WEIGHT_GEN = [0]
 
 
 def folded_bn(bn) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -769,9 +813,23 @@ def weight_transpose(w_ohwi: torch.Tensor) -> torch.Tensor:
         hit = WPREP.wt(w_ohwi)
         if hit is not None:
             return hit
+    key = epoch = None
+    if W_AMAX is None:      # outside a trainer step: the transpose of an unchanged weight tensor is kept (and with it the fp16 planes
+        key, epoch = _cache_key(w_ohwi)      # _split_h2 keeps for THAT tensor) -- a backward made ~30 fresh copies that never hit
+        hit = _WT_CACHE.get(key) if key is not None else None
+        if hit is not None and hit[2] == epoch:
+            return hit[0]
     co, kh, kw, ci = w_ohwi.shape
     wt = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=w_ohwi.device)
     call("df_weight_transpose", ptr(w_ohwi), ptr(wt), co, kh * kw, ci, stream())
+    if key is not None:
+        old = _WT_CACHE.get(key)
+        if old is not None:      # the superseded transpose's planes go with it
+            _PLANE_CACHE.pop(_cache_key(old[0])[0], None)
+        if len(_WT_CACHE) > 256:
+            _WT_CACHE.clear()
+        wt._df_keep = True
+        _WT_CACHE[key] = (wt, w_ohwi, epoch)
     return wt
 
 

@@ -247,6 +247,7 @@ class FlatAdam:
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
         ops.PARAM_GEN[0] += 1  # the kernel writes the parameter arena behind autograd's version counters
+        ops.WEIGHT_GEN[0] += 1
         f = self.flat
         if self.step_dev is not None:   # graph-capturable form: the step number lives on the device (Trainer.capture)
             self.step_dev.add_(1)
@@ -428,6 +429,7 @@ class Trainer:
         # the captured launch sequence was RECORDED, not executed: undo the host-side counter
         self.opt.step_count = snap[3]
         ops.PARAM_GEN[0] += 1
+        ops.WEIGHT_GEN[0] += 1
 
     def step_captured(self, batch=None) -> torch.Tensor:
         """Replay the captured step (optionally on a new batch of the captured shapes).  -> loss tensor of the replay"""
@@ -451,6 +453,7 @@ class Trainer:
                 works.clear()
         self.opt.step_count += 1
         ops.PARAM_GEN[0] += 1
+        ops.WEIGHT_GEN[0] += 1
         return self._graph_loss
 
     def _side_on(self) -> Optional[bool]:

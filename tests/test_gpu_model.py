@@ -754,6 +754,57 @@ def test_configs4_shape_training_step(dev, monkeypatch, golden_dir):
     _bs16_case(dev, monkeypatch, 1024, 160000, "cfg4_train", golden_dir, digest="bs4_1024_it8_digest.npz", bf16=True)
 
 
+def test_autograd_callers_keep_one_transpose_and_plane_set_per_weight(dev):
+    """plain-autograd training (no Trainer): the transposed weights and the fp16 planes of every conv layer are kept per weight tensor
+    while it is unchanged and REPLACED when an optimizer writes it (a backward made ~30 fresh transposes that never hit
+    the cache and pinned a triple each until a 128-entry clear).  Three steps with torch.optim.SGD: the caches stop growing after
+    the first step, a repeated backward on unchanged weights launches no transpose / split, and the gradients equal those of a run
+    with the caches emptied before every step, bit for bit."""
+    import copy
+    from deflow_amd import ops
+    _, base = build_pair(dev, 31, decoder_option="gru", num_iters=2)
+    batch = to_dev(make_batch(2, 1500, 4100), dev)
+
+    def run(clear):
+        m = copy.deepcopy(base).train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+        sizes, grads = [], []
+        for _ in range(3):
+            if clear:
+                ops._WT_CACHE.clear(); ops._PLANE_CACHE.clear()
+            opt.zero_grad()
+            res = m(batch)
+            loss = sum((f ** 2).sum() for f in res["flow"])
+            loss.backward()
+            grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+            sizes.append((len(ops._WT_CACHE), len(ops._PLANE_CACHE)))
+            opt.step()
+        return sizes, grads, m
+
+    ops._WT_CACHE.clear(); ops._PLANE_CACHE.clear()
+    sizes, g_cached, m = run(False)
+    assert sizes[0][0] > 10 and sizes[1] == sizes[0] and sizes[2] == sizes[0], sizes        # one entry per weight tensor, replaced in place
+    # unchanged weights: a second forward + backward finds every transpose and plane set
+    names = []
+    real = ops.call
+    ops.call = lambda name, *a: (names.append(name), real(name, *a))[1]
+    try:
+        res = m(batch)
+        sum((f ** 2).sum() for f in res["flow"]).backward()
+        first = [n for n in names if n in ("df_weight_transpose", "df_split_h2")]
+        names.clear()
+        res = m(batch)
+        sum((f ** 2).sum() for f in res["flow"]).backward()
+        again = [n for n in names if n in ("df_weight_transpose", "df_split_h2")]
+    finally:
+        ops.call = real
+    # (what remains: the GRU decoder's three packed gate matrices, built and transposed per call)
+    assert first and "df_split_h2" not in again and len(again) <= 3, (len(first), again[:6])
+    _, g_clear, _ = run(True)
+    for a, b in zip(g_cached, g_clear):
+        assert torch.equal(a, b)
+
+
 BF16_GRAD_RMS_CONDITIONED = 5e-2     # bf16 training mode on CONDITIONED weights: per-tensor rms-relative error bound of every parameter gradient (round 5: worst projection 0.177 ||g|| = 3.9e-2 x 4.5, worst norm error 4.3e-2, both on the GRU head; median tensor 1.0e-2 / 1.6e-2 -- the 3e-2 VERDICT r4 asked for does not hold for the head's small tensors)
 
 
