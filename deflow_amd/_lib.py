@@ -46,7 +46,7 @@ _SIGS = {
     "df_pillar2_scan": [P, I, I, I, P, P, P, P],
     "df_pillar2_scatter": [P, I, I, DfGeom, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_pillar2_band": [P, P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P],
-    "df_pillar2_band_sp": [P, P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P, P],
+    "df_pillar2_band_sp": [P, P, P, P, P, I, DfGeom, I, I, P, P, I, I, DfImg, P, P, P, P, P, P, P, P],
     "df_cell_sort_ws_bytes": [L],
     "df_cell_sort": [P, L, L, P, P, P, P],
     "df_pfn_bn_finalize": [P, I, I, P, P, P, F, F, P, P, P, P],

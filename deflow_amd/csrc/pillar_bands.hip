@@ -247,6 +247,7 @@ struct P2Band {
   int bn_stride, mode, S;
   int dbg;   // timing ablations (env DF_P2_DBG): bit 0 = no pillar loop, bit 1 = no zero stores, bit 2 = no sort / copy
   uint32_t* occ;   // round 5, PERSISTENT canvas (df_pillar2_band_sp): [S][NB][64] occupancy words of the previous call, updated in place
+  unsigned* amax_out;   // optional (df_pillar2_band_sp): max of the canvas values this call writes (>= 0 after the ReLU), atomic max of the bit pattern
 };
 
 // BC = LDS cell-table size (cells per band <= BC): 2048, or 1024 for thin bands -- 24.7 KB of LDS instead of 32.9, i.e. 6
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   pfn_load_w(c, a.w_pfn, sub);
   if (CANVAS) pfn_load_bn(c, a.bn_ss + (int64_t)s * a.bn_stride, sub);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float cmax = 0.f;
   // list of the band's occupied cells (the ranking scratch is free now): the pillar loop below then keeps all 32 lane
   // groups busy instead of having most of them skip empty cells while one walks a pillar
 #pragma unroll
@@ -536,7 +538,13 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
         for (int kk = 0; kk < 4; ++kk) r[kk] = r[kk] / cntf;
       }
       st4(op + (int64_t)cell * a.out.ld + 4 * sub, r);
+      cmax = fmaxf(cmax, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
     }
+  }
+  if (CANVAS && a.amax_out) {   // one atomic per wavefront: the bound an fp16x2 consumer of the canvas scales by (evaluation forwards)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+    if (lane == 0 && cmax > 0.f) atomicMax(a.amax_out, __builtin_bit_cast(unsigned, cmax));
   }
   if (STATS) {
     bar();   // `red` aliases the point image the pillar loop above was still reading
@@ -621,7 +629,7 @@ static int pillar2_band_impl(const uint32_t* in_key, const uint32_t* in_idx, con
                              const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                              const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                              uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
-                             void* stream);
+                             float* amax_out, void* stream);
 
 extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
                                const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
@@ -629,27 +637,28 @@ extern "C" int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, c
                                uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial,
                                void* stream) {
   return pillar2_band_impl(in_key, in_idx, in_pts, tot, bucket0, S, g, rows_per_band, flags, w_pfn, bn_ss, bn_sample_stride, mode, out,
-                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, nullptr, stream);
+                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, nullptr, nullptr, stream);
 }
 
 // PERSISTENT-canvas form of a canvas-writing band call (flags & 4): `out` must be zero wherever the previous call with the same
 // (S, grid, rows_per_band) and the same `occ` left no pillar (initially: out all zero, occ all zero); only the occupied cells and the
 // cells occupied last time are written, occ [S][bands][64] u32 is updated in place.  Same results as df_pillar2_band on such a buffer.
+// amax_out (optional, zero before the call): receives max of the canvas values written (they are >= 0: the feature net ends in a ReLU).
 extern "C" int df_pillar2_band_sp(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
                                   const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                                   const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                                   uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
-                                  void* stream) {
+                                  float* amax_out, void* stream) {
   DF_REQUIRE(occ && (flags & 4), DF_E_ARG);
   return pillar2_band_impl(in_key, in_idx, in_pts, tot, bucket0, S, g, rows_per_band, flags, w_pfn, bn_ss, bn_sample_stride, mode, out,
-                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, occ, stream);
+                           key_sorted, idx_sorted, pts_sorted, cell_rng, stats_partial, occ, amax_out, stream);
 }
 
 static int pillar2_band_impl(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
                              const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                              const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                              uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
-                             void* stream) {
+                             float* amax_out, void* stream) {
   P2Geom q;
   const bool sort = flags & 1, stats = flags & 2, canvas = flags & 4;
   DF_REQUIRE(in_key && in_pts && tot && bucket0 && w_pfn && S > 0 && (mode == 0 || mode == 1), DF_E_ARG);
@@ -664,7 +673,7 @@ static int pillar2_band_impl(const uint32_t* in_key, const uint32_t* in_idx, con
   P2Band a;
   a.in_key = in_key; a.in_idx = in_idx; a.in_pts = in_pts; a.tot = tot; a.bucket0 = bucket0; a.key_sorted = key_sorted; a.idx_sorted = idx_sorted;
   a.pts_sorted = pts_sorted; a.cell_rng = cell_rng; a.w_pfn = w_pfn; a.bn_ss = bn_ss; a.partial = stats_partial; a.out = out;
-  a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S; a.occ = occ;
+  a.bn_stride = bn_sample_stride; a.mode = mode; a.S = S; a.occ = occ; a.amax_out = reinterpret_cast<unsigned*>(amax_out);
   static const int dbg = getenv("DF_P2_DBG") ? atoi(getenv("DF_P2_DBG")) : 0;
   a.dbg = dbg;
   const dim3 grid(q.NB, S);

@@ -102,20 +102,29 @@ class DeFlow(nn.Module):
         self.timer[1].start("Voxelization")
         # fp16x2 training: an a-priori bound of max |canvas| comes out of the feature net's BatchNorm finalisation (one slot, both clouds)
         emb.canvas_bound = ops.amax_slot(dev) if (train and save and ops.h2_active() and ops.SYNC is None) else None
+        # every other forward on a persistent canvas (evaluation, no-grad training forwards): the band pass MEASURES the canvas maximum
+        # as it writes (one atomic per wavefront), so that the first encoder conv and the skip conv on the canvas take their fp16x2
+        # forms there too -- they ran on the fp32 MFMA for want of a bound.  From B = 8 up only (measured, tools/bench_infer.py: B = 16
+        # forward 21.45 -> 21.05 ms; at B = 1 the eager forward does not move and its HIP-graph replay gets 3 % SLOWER -- the fp16x2
+        # DMA-tile forms of those two layers do not beat the fp32 MFMA on one pair's pixels).  DF_CANVAS_AMAX=0: never
+        measured = ops.amax_slot(dev) if (persist and B >= 8 and emb.canvas_bound is None and ops.h2_active()
+                                          and os.environ.get("DF_CANVAS_AMAX", "1") != "0") else None
         if merged:
             # no tape to keep (inference, no-grad forwards): both clouds go through the pillar pipeline as ONE set of 2B
             # samples writing the two channel halves of bstar -- half the launches of the ~15-kernel pipeline, which is
             # what a B = 1 forward spends there.  Same arithmetic sample by sample (BatchNorm statistics are per sample).
             both = emb.pillarize(torch.cat([pc0s, pc1s], 0), DfImg(bstar.data_ptr(), 2 * B, emb.H, emb.W, 32, 64, B,
-                                                                  bstar.stride(0), 32), train, need_cells=False, occ=occs[0])
+                                                                  bstar.stride(0), 32), train, need_cells=False, occ=occs[0], amax=measured)
             p0, p1 = both.split(B)
         else:
-            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save, occ=occs[0])
-            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save, occ=occs[1])
+            p0 = emb.pillarize(pc0s, img(bstar, 32, 0), train, need_cells=save, occ=occs[0], amax=measured)
+            p1 = emb.pillarize(pc1s, img(bstar, 32, 32), train, need_cells=save, occ=occs[1], amax=measured)
         self.timer[1].stop()
         if emb.canvas_bound is not None:
             bstar._df_amax = (emb.canvas_bound, _ver(bstar))
             emb.canvas_bound = None
+        elif measured is not None:
+            bstar._df_amax = (measured, _ver(bstar))
         self.timer[2].start("Encoder")
         tape: Optional[list] = [] if save else None
         if self.inference_dtype == "bf16" and not train and not save:

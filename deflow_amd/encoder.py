@@ -98,16 +98,18 @@ class DynamicEmbedder(nn.Module):
         return self.feature_net.pfn_layers[0][1]
 
     # -- engine ------------------------------------------------------------------------------
-    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool = True, occ: Optional[torch.Tensor] = None) -> PillarState:
+    def pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool = True, occ: Optional[torch.Tensor] = None,
+                  amax: Optional[torch.Tensor] = None) -> PillarState:
         """pts [B,N,3] f32 contiguous on the GPU; writes the WHOLE [B,H,W,32] canvas `out` (zeros included: the canvas needs no
         prior fill).  need_cells: also leave the dense per-cell [start, end) table the backward kernels read.
         occ (round 5): the PERSISTENT-canvas form -- `out` is a buffer this embedder wrote last time with the same `occ`
         ([S][bands][64] int32 occupancy words from `occ_alloc`, zero at first together with the buffer): only occupied cells and the
-        cells occupied last time are written (df_pillar2_band_sp); the result is the same canvas."""
+        cells occupied last time are written (df_pillar2_band_sp); the result is the same canvas.  amax (with occ; a zeroed device scalar,
+        shared by the calls that fill one canvas): receives the maximum canvas value written."""
         B, N, _ = pts.shape
         # algorithmic traffic of the stage (SURVEY 8(d)): the points once in, the dense 32-channel canvas once out
         with ops.timed("pillarise_fwd", bytes=B * (N * 12.0 + 32.0 * self.H * self.W * 4.0), tag=f"B={B} N={N}"):
-            return self._pillarize(pts, out, train, need_cells, occ)
+            return self._pillarize(pts, out, train, need_cells, occ, amax)
 
     def bands(self, S: int) -> Tuple[int, int]:
         """(rows per band, bands per sample) of the band pipeline for a set of S samples"""
@@ -150,7 +152,8 @@ class DynamicEmbedder(nn.Module):
             bn._df_fold_ss = c
         return c[1], 0
 
-    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool, occ: Optional[torch.Tensor] = None) -> PillarState:
+    def _pillarize(self, pts: torch.Tensor, out: DfImg, train: bool, need_cells: bool, occ: Optional[torch.Tensor] = None,
+                   amax: Optional[torch.Tensor] = None) -> PillarState:
         """Band-bucketed pipeline (csrc/pillar_bands.hip): hist -> scan -> scatter -> band (4 launches; training 6)."""
         assert pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous()
         S, N, _ = pts.shape
@@ -163,7 +166,7 @@ class DynamicEmbedder(nn.Module):
             if occ is None:
                 call("df_pillar2_band", *a, s)
             else:
-                call("df_pillar2_band_sp", *a, ptr(occ), s)
+                call("df_pillar2_band_sp", *a, ptr(occ), ptr(amax), s)
         ncol = NB + 1
         nblk = (N + call("df_pillar2_tile") - 1) // call("df_pillar2_tile")
         i32 = dict(dtype=torch.int32, device=dev)

@@ -87,12 +87,14 @@ int df_pillar2_band(const uint32_t* in_key, const uint32_t* in_idx, const float*
  * same (S, grid, rows_per_band, occ) left no pillar -- initially all zero, occ all zero.  Only the occupied cells and the cells that
  * were occupied last time and are empty now are written (the dense form streams 128 B of zeros into every empty cell: 87 % of the
  * stage's bytes); occ [S][bands][64] u32 (one bit per cell of a band) is read and rewritten in place by the band's workgroup.
+ * amax_out (optional device scalar, ZERO before the call; several calls into one canvas may share it): receives the maximum of the
+ * canvas values written (they are >= 0: the feature net ends in a ReLU) -- the bound an fp16x2 consumer of the canvas scales by.
  * Replaces the zero-initialised canvas of PointPillarsScatter [REF deflow.py:82-83 -> embedder] kept across calls. */
 int df_pillar2_band_sp(const uint32_t* in_key, const uint32_t* in_idx, const float* in_pts, const int32_t* tot,
                        const int32_t* bucket0, int S, df_pillar_geom g, int rows_per_band, int flags, const float* w_pfn,
                        const float* bn_ss, int bn_sample_stride, int mode, df_img out, uint32_t* key_sorted,
                        uint32_t* idx_sorted, float* pts_sorted, int32_t* cell_rng, float* stats_partial, uint32_t* occ,
-                       void* stream);
+                       float* amax_out, void* stream);
 
 /* (the first-generation forward entry points df_pillar_keys / _scan / _compact / _sort / _gather_sorted / _cells, df_pfn_stats
  * and df_pfn_canvas -- a library radix sort and separate kernels over a zero-filled canvas -- were retired in round 3: the band
