@@ -144,6 +144,9 @@ _SIGS = {
     "df_linear_decoder_bwd": [DfImg, DfImg, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "df_ego_transform": [P, P, I, I, P, P, P],
     "df_deflow_loss_fwd": [P, P, P, I, I, P, I, P],
+    "df_wloss_fwd": [P, P, P, I, I, I, P, P, I, P, I, P],
+    "df_wloss_finalize": [P, I, I, P, P, P],
+    "df_wloss_bwd": [P, P, P, I, I, I, P, P, I, P, P, F, P, I, P],
     "df_deflow_loss_finalize": [P, I, I, P, P, P],
     "df_deflow_loss_bwd": [P, P, P, I, I, P, P, F, P, I, P],
     "df_gather_gt": [P, P, P, P, I, I, P, I, P],

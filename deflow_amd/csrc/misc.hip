@@ -120,6 +120,86 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- the two ABLATION losses of the reference's loss_fn switch as kernels (round 5; [REF assets/slurm/1_train.sh:53-60], README.md:68:
+// the fastflow3d baseline trains with ff3dLoss).  Both are  sum over samples of  mean over valid points of  w_i |est_i - gt_i| :
+//   KIND 0, ff3dLoss       w = 0.1 for background points (class 0), 1.0 for the rest; the class of compact row i is cls[b, idx_c[b, i]]
+//   KIND 1, zeroflowLoss   w = clamp(1.8 (10 |gt|) - 0.8, 0.1, 1.0)
+// (definitions recalled from FastFlow3D / ZeroFlow as in deflow_amd/losses.py and oracle/ref_torch.py: the upstream source is absent).
+// Valid rows as for deflowLoss: i < counts[b], est and gt finite.  partial [B][nblk][2] = (sum w err, rows); bins [B][2].
+template <int KIND>
+__device__ __forceinline__ float wloss_weight(const float* g, const int64_t* cls, const int64_t* idx_c, int64_t row, int64_t b, int Ncls) {
+  if (KIND == 0) {
+    int64_t j = idx_c[row];
+    j = j < 0 ? 0 : (j >= Ncls ? Ncls - 1 : j);
+    return cls[b * Ncls + j] > 0 ? 1.f : 0.1f;
+  }
+  const float speed = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) * 10.f;
+  return fminf(fmaxf(1.8f * speed - 0.8f, 0.1f), 1.0f);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void wloss_fwd_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                        const int32_t* __restrict__ counts, int N, const int64_t* __restrict__ cls,
+                                                        const int64_t* __restrict__ idx_c, int Ncls, float* __restrict__ partial) {
+  __shared__ float red[4][2];
+  const int b = blockIdx.y, cnt = counts[b];
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const int64_t row = (int64_t)b * N + i;
+    const float* e = est + row * 3;
+    const float* g = gt + row * 3;
+    if (!row_finite(e, g)) continue;
+    const float dx = e[0] - g[0], dy = e[1] - g[1], dz = e[2] - g[2];
+    acc0 += sqrtf(dx * dx + dy * dy + dz * dz) * wloss_weight<KIND>(g, cls, idx_c, row, b, Ncls);
+    acc1 += 1.f;
+  }
+  for (int off = 32; off > 0; off >>= 1) { acc0 += __shfl_down(acc0, off); acc1 += __shfl_down(acc1, off); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = acc0; red[threadIdx.x >> 6][1] = acc1; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    partial[((int64_t)b * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void wloss_finalize_kernel(const float* __restrict__ partial, int B, int nblk, float* __restrict__ bins, float* __restrict__ loss) {
+  if (threadIdx.x != 0) return;     // B x nblk x 2 numbers: one thread, fixed order
+  double total = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double sm = 0.0, cn = 0.0;
+    for (int k = 0; k < nblk; ++k) { sm += (double)partial[((int64_t)b * nblk + k) * 2]; cn += (double)partial[((int64_t)b * nblk + k) * 2 + 1]; }
+    bins[b * 2] = (float)sm;
+    bins[b * 2 + 1] = (float)cn;
+    if (cn > 0.0) total += sm / cn;
+  }
+  loss[0] = (float)total;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void wloss_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                        const int32_t* __restrict__ counts, int N, const int64_t* __restrict__ cls,
+                                                        const int64_t* __restrict__ idx_c, int Ncls, const float* __restrict__ bins,
+                                                        const float* __restrict__ gscale_ptr, float gscale, float* __restrict__ dest) {
+  const int b = blockIdx.y, cnt = counts[b];
+  const float gs = gscale_ptr ? gscale * gscale_ptr[0] : gscale;
+  const float c = bins[b * 2 + 1];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) {
+    const int64_t row = (int64_t)b * N + i;
+    const float* e = est + row * 3;
+    const float* g = gt + row * 3;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (row_finite(e, g)) {
+      const float dx = e[0] - g[0], dy = e[1] - g[1], dz = e[2] - g[2];
+      const float err = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (err > 0.f && c > 0.f) {
+        const float s = gs * wloss_weight<KIND>(g, cls, idx_c, row, b, Ncls) / (err * c);
+        o0 = dx * s; o1 = dy * s; o2 = dz * s;
+      }
+    }
+    float* d = dest + row * 3;
+    d[0] = o0; d[1] = o1; d[2] = o2;
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_gt_kernel(const float* __restrict__ flow, const float* __restrict__ pflow,
                                                         const int64_t* __restrict__ idx_c,
                                                         const int32_t* __restrict__ counts, int N,
@@ -185,6 +265,38 @@ extern "C" int df_deflow_loss_finalize(const float* bins_partial, int B, int nbl
   DF_REQUIRE(bins_partial && bins && loss && B > 0 && nblk > 0 && B * 6 <= 1024, DF_E_ARG);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bins_partial, B,
                      nblk, bins, loss);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_wloss_fwd(const float* est, const float* gt, const int32_t* counts, int B, int N, int kind, const int64_t* cls,
+                            const int64_t* idx_c, int Ncls, float* partial, int nblk, void* stream) {
+  DF_REQUIRE(est && gt && counts && partial && B > 0 && N > 0 && nblk > 0 && (kind == 0 || kind == 1), DF_E_ARG);
+  DF_REQUIRE(kind == 1 || (cls && idx_c && Ncls > 0), DF_E_ARG);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (kind == 0) hipLaunchKernelGGL(wloss_fwd_kernel<0>, dim3(nblk, B), dim3(256), 0, s, est, gt, counts, N, cls, idx_c, Ncls, partial);
+  else hipLaunchKernelGGL(wloss_fwd_kernel<1>, dim3(nblk, B), dim3(256), 0, s, est, gt, counts, N, cls, idx_c, Ncls, partial);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_wloss_finalize(const float* partial, int B, int nblk, float* bins, float* loss, void* stream) {
+  DF_REQUIRE(partial && bins && loss && B > 0 && nblk > 0, DF_E_ARG);
+  hipLaunchKernelGGL(wloss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), partial, B, nblk, bins, loss);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+extern "C" int df_wloss_bwd(const float* est, const float* gt, const int32_t* counts, int B, int N, int kind, const int64_t* cls,
+                            const int64_t* idx_c, int Ncls, const float* bins, const float* gscale_dev, float gscale, float* dest,
+                            int nblk, void* stream) {
+  DF_REQUIRE(est && gt && counts && bins && dest && B > 0 && N > 0 && nblk > 0 && (kind == 0 || kind == 1), DF_E_ARG);
+  DF_REQUIRE(kind == 1 || (cls && idx_c && Ncls > 0), DF_E_ARG);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (kind == 0)
+    hipLaunchKernelGGL(wloss_bwd_kernel<0>, dim3(nblk, B), dim3(256), 0, s, est, gt, counts, N, cls, idx_c, Ncls, bins, gscale_dev, gscale, dest);
+  else
+    hipLaunchKernelGGL(wloss_bwd_kernel<1>, dim3(nblk, B), dim3(256), 0, s, est, gt, counts, N, cls, idx_c, Ncls, bins, gscale_dev, gscale, dest);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

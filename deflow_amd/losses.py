@@ -6,8 +6,9 @@ Their definitions live in the absent OpenSceneFlow submodule (``src/lossfuncs.py
   zeroflowLoss  mean over points of |est - gt| * clamp(1.8 * speed - 0.8, 0.1, 1.0),  speed = |gt| * 10 (m/s at 10 Hz)
 
 each per sample, summed over the batch like deflowLoss in the trainer.  deflowLoss -- the north-star loss -- has its own
-HIP kernels (autograd.DeflowLossFn); these two are a handful of device-side elementwise torch ops on the padded
-[B, N, 3] flow tensor (0.3 % of a step's bytes) with torch autograd providing d(loss)/d(est)."""
+HIP kernels (autograd.DeflowLossFn).  Round 5: the Trainer's direct step evaluates these two with HIP kernels as well
+(csrc/misc.hip: df_wloss_fwd / _finalize / _bwd, the same definitions); the torch form below serves autograd callers
+(Trainer.loss_on_last_forward) and is the kernels' twin in tests/test_gpu_model.py::test_ablation_losses_vs_oracle."""
 from __future__ import annotations
 
 from typing import Optional

@@ -531,19 +531,26 @@ class Trainer:
                 call("df_deflow_loss_bwd", ptr(flow), ptr(gt), ptr(st["counts0"]), B, N, ptr(bins), ptr(self._one), 1.0, ptr(dflow),
                      nblk, stream())
                 loss = loss[0]
-            else:   # the ablation losses are a few torch ops on [B,N,3] tensors: autograd for them alone
-                from . import losses
-                leaf = flow.detach().requires_grad_(True)
-                with torch.enable_grad():
-                    if self.loss_fn == "zeroflowLoss":
-                        loss = losses.zeroflow_loss(leaf, gt, st["counts0"])
-                    else:
-                        cls = batch.get("flow_category_indices")
-                        if cls is not None:
-                            cls = torch.gather(cls.long(), 1, st["idx_c0"].clamp(0, cls.shape[1] - 1))
-                        loss = losses.ff3d_loss(leaf, gt, st["counts0"], cls)
-                    dflow, = torch.autograd.grad(loss, leaf)
-                loss = loss.detach()
+            else:   # the ablation losses: df_wloss_* (round 5; the torch form of losses.py stays for autograd callers and as the test's twin)
+                kind = 1 if self.loss_fn == "zeroflowLoss" else 0
+                cls = None
+                if kind == 0:
+                    cls = batch.get("flow_category_indices")
+                    if cls is None:
+                        raise ValueError("loss_fn=ff3dLoss needs batch['flow_category_indices'] (labelled scene files)")
+                    cls = cls.to(device=dev, dtype=torch.int64).contiguous()
+                nblk = max(1, min(32, (N + 255) // 256))
+                partial = torch.empty(B, nblk, 2, dtype=torch.float32, device=dev)
+                idx_c = st["idx_c0"]
+                call("df_wloss_fwd", ptr(flow), ptr(gt), ptr(st["counts0"]), B, N, kind, ptr(cls), ptr(idx_c), 0 if cls is None else cls.shape[1],
+                     ptr(partial), nblk, stream())
+                bins = torch.empty(B, 2, dtype=torch.float32, device=dev)
+                loss = torch.empty(1, dtype=torch.float32, device=dev)
+                call("df_wloss_finalize", ptr(partial), B, nblk, ptr(bins), ptr(loss), stream())
+                dflow = torch.empty_like(flow)
+                call("df_wloss_bwd", ptr(flow), ptr(gt), ptr(st["counts0"]), B, N, kind, ptr(cls), ptr(idx_c), 0 if cls is None else cls.shape[1],
+                     ptr(bins), None, 1.0, ptr(dflow), nblk, stream())
+                loss = loss[0]
             deflow_backward(model, st.pop("engine"), dflow.contiguous(), self.flat.params, self.sink)
         return loss
 

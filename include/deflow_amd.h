@@ -521,6 +521,16 @@ int df_deflow_loss_fwd(const float* est, const float* gt, const int32_t* counts,
 int df_deflow_loss_finalize(const float* bins_partial, int B, int nblk, float* bins, float* loss, void* stream);
 int df_deflow_loss_bwd(const float* est, const float* gt, const int32_t* counts, int B, int N, const float* bins,
                        const float* gscale_dev /*nullable*/, float gscale, float* dest, int nblk, void* stream);
+/* the ablation losses of the reference's loss_fn switch (round 5; [REF assets/slurm/1_train.sh:53-60], README.md:68): kind 0 = ff3dLoss
+ * (weight 0.1 on background points -- class cls[b, idx_c[b, i]] == 0 of compact row i; cls [B, Ncls] int64 -- 1.0 elsewhere), kind 1 =
+ * zeroflowLoss (weight clamp(1.8 * 10 |gt| - 0.8, 0.1, 1.0); cls / idx_c unused): sum over samples of the mean over valid rows of
+ * w |est - gt|.  fwd -> partial [B, nblk, 2]; finalize -> bins [B, 2] = (sum w err, rows), loss[0]; bwd -> dest as df_deflow_loss_bwd. */
+int df_wloss_fwd(const float* est, const float* gt, const int32_t* counts, int B, int N, int kind, const int64_t* cls,
+                 const int64_t* idx_c, int Ncls, float* partial, int nblk, void* stream);
+int df_wloss_finalize(const float* partial, int B, int nblk, float* bins, float* loss, void* stream);
+int df_wloss_bwd(const float* est, const float* gt, const int32_t* counts, int B, int N, int kind, const int64_t* cls,
+                 const int64_t* idx_c, int Ncls, const float* bins, const float* gscale_dev /*nullable*/, float gscale, float* dest,
+                 int nblk, void* stream);
 /* trainer gt: gt[b,i] = flow[b, idx_c[b,i]] - pose_flow[b, idx_c[b,i]] for i < counts[b] */
 int df_gather_gt(const float* flow, const float* pose_flow, const int64_t* idx_c, const int32_t* counts,
                  int B, int N, float* gt, int nblk, void* stream);

@@ -1127,7 +1127,8 @@ def test_training_from_scene_files(dev, tmp_path, capsys):
 
 
 @pytest.mark.parametrize("loss_fn", ["ff3dLoss", "zeroflowLoss"])
-def test_ablation_losses_vs_oracle(dev, loss_fn):
+@pytest.mark.parametrize("path", ["autograd", "kernels"])
+def test_ablation_losses_vs_oracle(dev, loss_fn, path):
     """loss_fn=ff3dLoss / zeroflowLoss ([REF 1_train.sh:58-78]) on a labelled batch of the scene fixtures: the trainer's
     loss on the padded device tensors and the gradients it sends back through the engine vs the oracle's per-sample form."""
     from oracle import ref_torch as O
@@ -1144,13 +1145,25 @@ def test_ablation_losses_vs_oracle(dev, loss_fn):
     tr = Trainer(mine, lr=2e-4, loss_fn=loss_fn)
     bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     tr.flat.zero_grad(); tr.sink.begin()
-    mine.forward_padded(bd)
-    loss_m = tr.loss_on_last_forward(bd)
-    loss_m.backward()
+    if path == "autograd":      # the torch form of deflow_amd/losses.py through the autograd engine
+        mine.forward_padded(bd)
+        loss_m = tr.loss_on_last_forward(bd)
+        loss_m.backward()
+    else:                       # the Trainer's direct step: df_wloss_fwd / _finalize / _bwd (round 5)
+        names = []
+        from deflow_amd import optim as _optim
+        real = _optim.call
+        _optim.call = lambda name, *a: (names.append(name), real(name, *a))[1]
+        try:
+            with torch.no_grad():
+                loss_m = tr._forward_backward(bd)
+        finally:
+            _optim.call = real
+        assert {"df_wloss_fwd", "df_wloss_finalize", "df_wloss_bwd"} <= set(names), [n for n in names if "loss" in n]
     st = mine.last_state
     m0 = st["counts0"].tolist()
     res_m = {"flow": [st["flow"][b, :m0[b]] for b in range(len(m0))]}
-    parity.check_step(f"ablation_{loss_fn}", mine, res_m, loss_m.detach(), o32, o64)   # fp64 three-way bound, every gradient
+    parity.check_step(f"ablation_{loss_fn}_{path}", mine, res_m, loss_m.detach(), o32, o64)   # fp64 three-way bound, every gradient
 
 
 @pytest.mark.parametrize("train", [False, True])
