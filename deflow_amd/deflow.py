@@ -75,6 +75,10 @@ class DeFlow(nn.Module):
     # ------------------------------------------------------------------------------------------------
     def _run(self, pc0s: torch.Tensor, pc1s: torch.Tensor, train: bool, save: bool):
         """Engine: pillarise both clouds into one [B,H,W,64] buffer, UNet, decoder.  -> padded flow, state."""
+        with ops.deferred_tracked():      # (the 18 num_batches_tracked increments of a training forward: one launch at the end)
+            return self._run_impl(pc0s, pc1s, train, save)
+
+    def _run_impl(self, pc0s: torch.Tensor, pc1s: torch.Tensor, train: bool, save: bool):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device

@@ -142,7 +142,7 @@ class DynamicEmbedder(nn.Module):
                 call("df_pfn_bn_finalize2", ptr(partial), B, nbs, ptr(counts), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                      bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn_ss),
                      ptr(self._lin.weight.detach()) if cb is not None else None, self.geom, ptr(cb), s)
-            bn.num_batches_tracked.add_(B)
+            ops.bump_tracked(bn.num_batches_tracked, B)
             ops.PARAM_GEN[0] += 1
             return bn_ss, 128
         c = getattr(bn, "_df_fold_ss", None)

@@ -71,6 +71,36 @@ class KernelProfiler:
 
 PROFILER: Optional[KernelProfiler] = None
 
+# BatchNorm's num_batches_tracked counters: 18 one-element `add_` launches per training forward when done layer by layer.  Inside
+# `deferred_tracked()` (DeFlow._run) the increments are collected and applied by ONE multi-tensor launch at the end of the forward.
+_TRACKED: Optional[list] = None
+
+
+def bump_tracked(t: torch.Tensor, k: int) -> None:
+    if _TRACKED is None:
+        t.add_(k)
+    else:
+        _TRACKED.append((t, int(k)))
+
+
+class deferred_tracked:
+    def __enter__(self):
+        global _TRACKED
+        self.prev = _TRACKED
+        _TRACKED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _TRACKED
+        pend, _TRACKED = _TRACKED, self.prev
+        if pend:
+            acc: dict = {}          # (a tensor may come twice -- the feature net's counter, once per cloud: one entry each for the launch)
+            for t, k in pend:
+                e = acc.setdefault(id(t), [t, 0])
+                e[1] += k
+            torch._foreach_add_([e[0] for e in acc.values()], [e[1] for e in acc.values()])
+        return False
+
 # Mixed-precision switch of the convolution kernels (forward, data gradient, weight gradient): True = MFMA operands rounded
 # to bf16 as they leave LDS, fp32 accumulation, all tensors still fp32 (df_conv2d_mp / df_conv2d_wgrad_mp).  Set by
 # optim.Trainer(dtype="bf16") around its forward + backward (BASELINE configs[4]: "bf16 MFMA" training); False everywhere else.

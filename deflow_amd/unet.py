@@ -96,7 +96,7 @@ def _cwn_forward(m: ConvWithNorms, x: DfImg, z: DfImg, n_imgs: int, groups: int,
     zb = z._amax if z.elt == 2 else None       # (zero-initialised slot: the h2 tensor was created with it)
     ops.bn_finalize(partial, tiles_pg, groups, C, rows_pg, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
                     bn.running_mean, bn.running_var, bn_ss, y_amax=ya if zb is not None else None, z_bound=zb)
-    bn.num_batches_tracked.add_(groups)
+    ops.bump_tracked(bn.num_batches_tracked, groups)
     ops.bn_gelu_apply(y, bn_ss, ipg, z)
     if ya is not None:
         y._df_yamax = ya
