@@ -139,6 +139,7 @@ _SIGS = {
     "df_gru_head_wgrad": [P, P, P, P, I, I, P, I, P],
     "df_gru_wgrad": [P, P, P, I, I, I, P, I, P],
     "df_gather_bwd": [P, P, P, P, I, I, DfImg, DfImg, I, I, I, P],
+    "df_gather_bwd_m": [P, P, P, P, I, I, DfImg, DfImg, I, I, P, P],
     "df_small_outer": [P, I, I, P, I, I, P, I, I, L, P, I, P],
     "df_linear_decoder_fwd": [DfImg, DfImg, P, P, P, I, I, P, P, P, P, P, P, P, P],
     "df_linear_decoder_bwd": [DfImg, DfImg, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -544,9 +544,11 @@ __global__ __launch_bounds__(256) void gather_bwd_batched_kernel(const float* __
                                                                  const uint32_t* __restrict__ idx_sorted,
                                                                  const int32_t* __restrict__ cell_rng,
                                                                  const int32_t* __restrict__ cpos, int N, int ncell, int BN,
-                                                                 df_img dbefore, df_img dafter, int acc_before, int acc_after) {
+                                                                 df_img dbefore, df_img dafter, int acc_before, int acc_after,
+                                                                 unsigned* __restrict__ amax_after) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int LPC = BOTH ? 32 : 16, CPP = 256 / LPC;      // lanes per cell, cells per pass of the workgroup
+  constexpr int LPC = BOTH ? 32 : 16, CPP = 256 / LPC;
+  float amx = 0.f;      // max |d(after)| this lane wrote (df_gather_bwd_m: the bound of dv an fp16x2 consumer scales by)      // lanes per cell, cells per pass of the workgroup
   const int b = blockIdx.y, sub = threadIdx.x & (LPC - 1), grp = threadIdx.x / LPC;
   const bool is_after = !BOTH || sub >= 16;
   const df_img& im = is_after ? dafter : dbefore;
@@ -594,21 +596,52 @@ __global__ __launch_bounds__(256) void gather_bwd_batched_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int cell = cell0 + grp + CPP * u;
-      if (cell < ncell) st4(op + (int64_t)cell * ld, a[u]);
+      if (cell < ncell) {
+        st4(op + (int64_t)cell * ld, a[u]);
+        if (is_after) amx = fmaxf(amx, fmaxf(fmaxf(fabsf(a[u][0]), fabsf(a[u][1])), fmaxf(fabsf(a[u][2]), fabsf(a[u][3]))));
+      }
     }
+  }
+  if (amax_after) {     // one atomic per wavefront
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    // (compare first: half a million wavefronts hitting one address with an unconditional atomic cost 3 ms; after the first few the
+    //  load alone answers)
+    const unsigned mb = __builtin_bit_cast(unsigned, amx);
+    if ((threadIdx.x & 63) == 0 && mb > __atomic_load_n(amax_after, __ATOMIC_RELAXED)) atomicMax(amax_after, mb);
   }
 #endif
 }
 
+static int gather_bwd_impl(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos, int B, int N,
+                           df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after, int nblk, float* amax_after,
+                           void* stream);
+
 extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
                              int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
                              int nblk, void* stream) {
+  return gather_bwd_impl(dh0, idx_sorted, cell_rng, cpos, B, N, dbefore, dafter, accumulate_before, accumulate_after, nblk, nullptr, stream);
+}
+
+// the MEASURING form (round 5): amax_after (a zeroed device scalar) receives max |d(after)| of what this call writes -- the step's
+// backward asked for that bound with a df_absmax pass over the 1 GB image (0.25 ms at B = 16).  Not with accumulate_after.
+extern "C" int df_gather_bwd_m(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
+                               int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int nblk, float* amax_after,
+                               void* stream) {
+  DF_REQUIRE(amax_after != nullptr, DF_E_ARG);
+  return gather_bwd_impl(dh0, idx_sorted, cell_rng, cpos, B, N, dbefore, dafter, accumulate_before, 0, nblk, amax_after, stream);
+}
+
+static int gather_bwd_impl(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos, int B, int N,
+                           df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after, int nblk, float* amax_after,
+                           void* stream) {
   DF_REQUIRE(dh0 && idx_sorted && cell_rng && cpos && dafter.ptr && B > 0 && N > 0 && nblk > 0, DF_E_ARG);
   DF_REQUIRE(dafter.n == B && dafter.c == 64 && (dafter.ld % 4) == 0, DF_E_SHAPE);
   if (dbefore.ptr)
     DF_REQUIRE(dbefore.n == B && dbefore.c == 64 && dbefore.h == dafter.h && dbefore.w == dafter.w && (dbefore.ld % 4) == 0,
                DF_E_SHAPE);
   static const int batched = getenv("DF_GATHER_BWD_V1") ? 0 : 1;   // A/B: the one-cell-at-a-time kernel
+  DF_REQUIRE(!amax_after || (batched && (int64_t)B * N < (1 << 29) && (int64_t)dafter.h * dafter.w < (1 << 28)), DF_E_SHAPE);   // (the batched kernel measures)
   const int64_t ncell = (int64_t)dafter.h * dafter.w;
   if (batched && (int64_t)B * N < (1 << 29) && ncell < (1 << 28)) {   // (32-bit byte offsets of the buffer loads)
     constexpr int U = 4;
@@ -616,11 +649,11 @@ extern "C" int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const
     if (dbefore.ptr) {
       const int nb = (int)min((int64_t)8192, (ncell + 8 * U - 1) / (8 * U));
       hipLaunchKernelGGL((gather_bwd_batched_kernel<U, true>), dim3(nb, B), dim3(256), 0, st, dh0, idx_sorted, cell_rng, cpos, N,
-                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after);
+                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after, reinterpret_cast<unsigned*>(amax_after));
     } else {
       const int nb = (int)min((int64_t)8192, (ncell + 16 * U - 1) / (16 * U));
       hipLaunchKernelGGL((gather_bwd_batched_kernel<U, false>), dim3(nb, B), dim3(256), 0, st, dh0, idx_sorted, cell_rng, cpos, N,
-                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after);
+                         (int)ncell, B * N, dbefore, dafter, accumulate_before, accumulate_after, reinterpret_cast<unsigned*>(amax_after));
     }
     DF_CHECK_LAUNCH();
     return DF_OK;

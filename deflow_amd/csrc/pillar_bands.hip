@@ -544,7 +544,8 @@ __global__ __launch_bounds__(256) void p2_band_kernel(P2Band a, P2Geom q) {
   if (CANVAS && a.amax_out) {   // one atomic per wavefront: the bound an fp16x2 consumer of the canvas scales by (evaluation forwards)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
-    if (lane == 0 && cmax > 0.f) atomicMax(a.amax_out, __builtin_bit_cast(unsigned, cmax));
+    const unsigned mb = __builtin_bit_cast(unsigned, cmax);      // (compare first: most wavefronts then skip the atomic)
+    if (lane == 0 && mb > __atomic_load_n(a.amax_out, __ATOMIC_RELAXED)) atomicMax(a.amax_out, mb);
   }
   if (STATS) {
     bar();   // `red` aliases the point image the pillar loop above was still reading

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import DfGruWeights, DfGruWeightsT, DfImg, call, img, ptr, stream
+from ._lib import DfGruWeights, DfGruWeightsT, DfImg, call, img, ptr, stream, ver
 
 
 class ConvGRU(nn.Module):
@@ -378,8 +378,18 @@ class ConvGRUDecoder(nn.Module):
         ncell = dafter.h * dafter.w
         if dbefore is None:   # the caller evaluates d(before) sparsely from dh0 (df_pillar_input_grad)
             dbefore = DfImg(0, 0, 0, 0, 0, 0, 1, 0, 0)
-        call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
-             int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
+        src = getattr(dafter, "_src", None)
+        if (src is not None and not acc_after and ops.h2_active() and os.environ.get("DF_GATHER_BWD_V1") is None
+                and B * N < (1 << 29) and ncell < (1 << 28) and os.environ.get("DF_GATHER_AMAX", "1") != "0"):
+            # the kernel measures max |d(after)| as it writes (round 5): the UNet backward's first data gradient asked for it with a
+            # df_absmax pass over the whole image
+            am = ops.amax_slot(dh0.device)
+            call("df_gather_bwd_m", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
+                 int(acc_before), max(1, min(4096, ncell // 8)), ptr(am), s)
+            src._df_amax = (am, ver(src))
+        else:
+            call("df_gather_bwd", ptr(dh0), ptr(ps.idx_sorted), ptr(ps.cell_rng), ptr(ps.cpos), B, N, dbefore, dafter,
+                 int(acc_before), int(acc_after), max(1, min(4096, ncell // 8)), s)
         side = ops.SIDE
         if side is not None:
             side.keep.extend([hs, gpl, dpre1, sums, ps])

@@ -485,6 +485,11 @@ int df_gru_lean_finalize(const float* sums, df_gru_weights wts, float* dW_gates,
 int df_gather_bwd(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
                   int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int accumulate_after,
                   int nblk, void* stream);
+/* the same, and amax_after (a ZEROED device scalar) receives max |dafter| of what the call writes: the bound the UNet backward's first
+ * fp16x2 data gradient scales dv by, without a pass over the image (round 5).  dafter is written, never added to.  Returns DF_E_SHAPE
+ * where only the one-cell-at-a-time kernel applies (DF_GATHER_BWD_V1, > 2^29 points): call df_gather_bwd + df_absmax then. */
+int df_gather_bwd_m(const float* dh0, const uint32_t* idx_sorted, const int32_t* cell_rng, const int32_t* cpos,
+                    int B, int N, df_img dbefore, df_img dafter, int accumulate_before, int nblk, float* amax_after, void* stream);
 /* partial[blk][i*nb+j] = sum over valid rows of a[row][i] * (b ? b[row][j] : 1); row r is valid iff
  * r % rows_per_seg < counts[(r / rows_per_seg) % nseg].  na*nb <= 256.  Sum with df_colsum_finalize. */
 int df_small_outer(const float* a, int lda, int na, const float* b, int ldb, int nb, const int32_t* counts,
