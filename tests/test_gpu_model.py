@@ -1066,13 +1066,14 @@ _X3_OFF = {"DF_CONV_X3": "0", "DF_WGRAD_X3": "0"}      # the fp32-MFMA kernels t
 def test_alternate_kernel_paths(env):
     """the register-staged conv/wgrad kernels (fallback for > 4 GB tensors), the all-DMA wgrad variants, the
     first-generation GRU kernels with unfused gate weight gradients, and the side-stream weight-gradient schedule stay
-    correct: re-run the conv / ConvWithNorms / decoder / train-step parity tests in a subprocess with the override (the
+    correct: re-run the conv / ConvWithNorms / decoder parity tests and THE train-step parity test (one model test per leg: each
+    pays the CPU oracle in fp32 and float64 again) in a subprocess with the override (the
     bf16-operand tests are left out: the alternate kernel forms have no bf16 mode and run fp32 when it is requested)"""
     import subprocess
     import sys
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_gpu_kernels.py", "tests/test_gpu_model.py",
-                        "-k", "(conv or cwn or gru or train_step_vs_oracle) and not full_size and not bs16 and not bf16 and not x3 and not h2", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
+                        "-k", "(conv or cwn or gru or test_train_step_vs_oracle) and not full_size and not bs16 and not bf16 and not x3 and not h2", "-p", "no:cacheprovider"], env=e, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
