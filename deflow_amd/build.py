@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libdeflow_amd.so")
-SOURCES = ["conv.hip", "conv_bf16.hip", "elementwise.hip", "pillarize.hip", "pillar_bands.hip", "decoder.hip", "decoder3.hip", "decoder4.hip", "decoder_bf16.hip", "decoder3_bwd.hip", "decoder_wgrad.hip", "decoder_bwd.hip", "misc.hip"]
+SOURCES = ["conv.hip", "conv_wgrad.hip", "conv_bf16.hip", "elementwise.hip", "pillarize.hip", "pillar_bands.hip", "decoder.hip", "decoder3.hip", "decoder4.hip", "decoder_bf16.hip", "decoder3_bwd.hip", "decoder_wgrad.hip", "decoder_bwd.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
 # Per-file extras.  pillarize.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 instructions (v_pk_fma_f32 ...):

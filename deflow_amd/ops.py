@@ -111,7 +111,7 @@ MFMA_BF16 = False
 # encoder the conv outputs y, the activations z, and the gradients dz / dy of every 3x3 stride-1 ConvWithNorms layer live in
 # HBM as bfloat16 (BatchNorm statistics from the fp32 accumulators' rounded values, normalisation / GELU / their backward in
 # fp32 registers) -- the BatchNorm + GELU passes and the conv I/O move half the bytes, and the weight gradient reads bf16 tiles
-# with transposing LDS reads (csrc/conv.hip wgrad3_tr_kernel).  Stage inputs / outputs (the skip tensors) stay fp32.
+# with transposing LDS reads (csrc/conv_wgrad.hip wgrad3_tr_kernel).  Stage inputs / outputs (the skip tensors) stay fp32.
 BF16_STORE = False
 
 

@@ -1,7 +1,7 @@
 """FastFlow3DUNet backbone ([REF deflow.py:15,32,87-88]) built from ConvWithNorms ([REF decoder.py:202-220]).
 
 Module tree / state_dict keys follow upstream (encoder_step_{1,2,3}.N.{conv,batchnorm}, decoder_step{1,2,3}.
-{u1_u2.0,u3,u4_u5.{0,1}}, decoder_step4).  Compute is an explicit engine over HIP kernels (csrc/conv.hip,
+{u1_u2.0,u3,u4_u5.{0,1}}, decoder_step4).  Compute is an explicit engine over HIP kernels (csrc/conv.hip, csrc/conv_wgrad.hip,
 csrc/elementwise.hip) with hand-sequenced backward: NHWC activations, the two clouds batched through the
 shared encoder as 2B images with two BatchNorm statistic groups (= the reference's two encoder calls), channel
 concatenations realised by writing into slices of one buffer (no torch.cat copies), gradients that meet at a

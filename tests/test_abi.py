@@ -100,7 +100,7 @@ def test_counted_vmcnt_kernels_do_not_spill():
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "deflow_amd", "csrc")
     for fname, kernels in (("conv_bf16.hip", ["conv64_roll_bf16_kernel"]), ("decoder_wgrad.hip", ["gru_wgrad_kernel"]),
-                           ("conv.hip", ["wgrad3_tr_kernel"])):
+                           ("conv_wgrad.hip", ["wgrad3_tr_kernel", "wgrad3_h2p_kernel"])):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result", "-c",
                             os.path.join(src, fname), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
                            capture_output=True, text=True, timeout=600)
