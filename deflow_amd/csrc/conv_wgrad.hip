@@ -1784,7 +1784,15 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
       const int lpq_i = PIPE ? (int)optab[(2 * i + 1) * 768 + tid] : lpq[i];
       const unsigned loff_i = PIPE ? optab[(2 * i) * 768 + tid] : loff[i];
       const int lpx = (lpq_i & 255) - 1, lqy = (lpq_i >> 8) - 1;
-      if (op_y[i]) {                                     // (wave-uniform)
+      if constexpr (PIPE) {
+        // branch-free (round 6): the op's tensor (dY or x) picked by scalar selects -- as wave-uniform branches the three ops cost
+        // ~12 taken branches per stage and wave; a dY op has row offset 0 and an unbounded row range
+        const bool y = op_y[i];
+        const unsigned hb = y ? 0x7fffffffu : (unsigned)hx, wb = y ? (unsigned)wy : (unsigned)wx;
+        const unsigned base = y ? ybase : xbase;
+        const bool ok = (unsigned)(cur_oy + lqy) < hb && (unsigned)(ox0 + lpx) < wb;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(y ? yr : xr, (lds_ptr_t)(slot + ldst[i]), 16, ok ? base + loff_i : DMA_BAD, 0, 0, 0);
+      } else if (op_y[i]) {                              // (wave-uniform)
         const bool ok = ox0 + lpx < wy;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_ptr_t)(slot + ldst[i]), 16, ok ? ybase + loff_i : DMA_BAD, 0, 0, 0);
       } else {
@@ -1872,6 +1880,9 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
       DF_H2P_READ16(f0, a_base, b_base);
       DF_H2P_WAIT16(f0);
     }
+    // (the x operand's address as the dY operand's + a wave-uniform distance, formed where it is used: one lane register less
+    //  across the loop -- at 168 registers that is the difference between no scratch and a reload + vmcnt(0) per stage)
+    const unsigned b_delta0 = __builtin_amdgcn_readfirstlane((unsigned)(YB + wci * XH + ky * XW * 64 - wco * (P * 64)));
     for (int i = 0; i < nst; ++i) {
       // this wave's share of stage i + 1 has landed (stage i + 2, if there is one, may be in flight) ...
       if (i + 2 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -1879,10 +1890,14 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
       // ... and everyone's; every wave has also finished reading ring slot (i - 1) % D
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const unsigned so = (unsigned)((i % D) * STG) + 16 * 64;
-      const unsigned aa1 = a_base + so, ba1 = b_base + so;
+      unsigned b_delta = b_delta0;
+      asm volatile("" : "+s"(b_delta));               // (not hoistable)
+      const unsigned aa1 = a_base + so, ba1 = aa1 + b_delta;
       DF_H2P_READ16(f1, aa1, ba1);                    // (stage i, step 1) under the products of (i, 0)
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);   // (+1.5 %: a wave that has its fragments keeps the pipe against its two neighbours' scalar / DMA code)
       products(f0);
+      __builtin_amdgcn_s_setprio(0);
       DF_H2P_WAIT16(f1);
       // the DMA of stage i + 3 into the slot stage i - 1 left behind barrier i -- issued HERE, where f0 is dead: its address
       // arithmetic beside both fragment sets does not fit the 168 registers of three waves per SIMD
@@ -1890,11 +1905,13 @@ __global__ __launch_bounds__(768) void wgrad3_h2p_kernel(WgradParams p) {
       __builtin_amdgcn_sched_barrier(0);
       if (i + 1 < nst) {
         const unsigned sn = (unsigned)(((i + 1) % D) * STG);
-        const unsigned aa0 = a_base + sn, ba0 = b_base + sn;
+        const unsigned aa0 = a_base + sn, ba0 = aa0 + b_delta;
         DF_H2P_READ16(f0, aa0, ba0);                  // (stage i + 1, step 0) under the products of (i, 1)
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);   // (+1.5 %: a wave that has its fragments keeps the pipe against its two neighbours' scalar / DMA code)
       products(f1);
+      __builtin_amdgcn_s_setprio(0);
       if (do_bias && tid < 512) {   // column tid & 63, pixel group tid >> 6 (8 groups of 4 pixels): value = hi + lo / 2048 (scaled)
         const char* stp = ldsb + (i % D) * STG;
         // the lane's offset re-derived per stage from the hardware lane id (a handful of VALU): kept across the loop it is one
