@@ -72,6 +72,16 @@ def _git(args):
         return None
 
 
+def _build_info() -> dict:
+    """deflow_amd/_build_info.json (written by deflow_amd.build at build time): the git state the library was built from -- the GPU
+    box's snapshot has no .git"""
+    try:
+        with open(os.path.join(ROOT, "deflow_amd", "_build_info.json")) as f:
+            return json.load(f)
+    except Exception:   # noqa: BLE001
+        return {}
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -246,10 +256,14 @@ def main():
     numa = bind_to_gpu_numa_node(local_rank) if (world > 1 and not share_gpu) else None
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
+    # an explicit collective timeout (the default is 10 min per call -- three stuck calls outlive the driver's patience; DF_BENCH_PG_TIMEOUT
+    # seconds): a rank that never arrives then shows up as an exception in a guarded leg, not as a silent hang
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("DF_BENCH_PG_TIMEOUT", "300")))
     if use_dist and share_gpu:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
     elif use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" == RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)  # "nccl" == RCCL on ROCm
 
     import deflow_amd
     from deflow_amd import ops
@@ -313,88 +327,149 @@ def main():
         dist.all_gather(per_rank, mine)
     dt = float(t.item())
 
+    # ---- everything below the timed region is an EXTRA.  At N > 1 each extra leg runs under a wall-clock budget (DF_BENCH_LEG_BUDGET
+    # seconds per leg, default 240): a leg that hangs -- a collective one rank never joins, a capture that deadlocks on first contact with
+    # eight real devices -- must not cost the HEADLINE already measured above.  When a leg overruns, every rank's watchdog thread ends
+    # its process; rank 0 first prints the headline line with `extras_aborted` naming the leg.
+    headline = {"metric": METRIC, "value": world * args.batch * args.steps / dt, "unit": "frame-pairs/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": WORKLOAD, "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                           "points_per_cloud": N_POINTS, "bev": [GRID, GRID], "gru_iters": NUM_ITERS, "parallelism": f"dp{world}"}}
+    leg_state = {"name": None, "deadline": None, "done": []}
+
+    def _watchdog():
+        while True:
+            time.sleep(0.5)
+            dl = leg_state["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                if rank == 0:
+                    line = dict(headline)
+                    line["extras_aborted"] = {"leg": leg_state["name"], "budget_s": leg_budget, "legs_completed": list(leg_state["done"]),
+                                              "note": "an extra leg behind the timed region overran its wall-clock budget; the headline above it was "
+                                                      "measured before any extra ran"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+    leg_budget = float(os.environ.get("DF_BENCH_LEG_BUDGET", "240"))
+    if use_dist and world > 1 and not args.no_extras:
+        import threading
+        threading.Thread(target=_watchdog, daemon=True).start()
+
+    class leg:      # `with leg("name"):` arms the watchdog for one extra leg
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            leg_state["name"], leg_state["deadline"] = self.name, time.monotonic() + leg_budget
+            if os.environ.get("DF_BENCH_TEST_HANG") == self.name:      # test hook: this leg never returns (tests/test_gpu_model.py)
+                time.sleep(10 ** 6)
+
+        def __exit__(self, *exc):
+            leg_state["deadline"] = None
+            leg_state["done"].append(self.name)
+            return False
+
     exposed = None
     bf16_multi = None
     graph_multi = None
     buckets = None
     one_bucket = None
+    one_bucket_default = bool(getattr(getattr(trainer, "sink", None), "one_bucket", False))   # (read before any A/B leg flips it)
     if use_dist and trainer.collective and not args.no_extras:
         # the gradient collectives of one eager step, bucket by bucket (after the timed region): arena range, bytes, issue ->
         # complete on the device clock.  A first 8-GPU run that scales badly can then be read from this one line: which bucket is
         # late, how long each is in flight, how much of the last one sticks out behind the backward
         try:
-            trainer.sink.trace_on(True)
-            for _ in range(2):
-                trainer.step(batch)
-            torch.cuda.synchronize()
-            buckets = trainer.sink.trace_report()
+            with leg("allreduce_buckets"):
+                trainer.sink.trace_on(True)
+                for _ in range(2):
+                    trainer.step(batch)
+                torch.cuda.synchronize()
+                buckets = trainer.sink.trace_report()
         except Exception as e:      # noqa: BLE001
             buckets = {"error": f"{type(e).__name__}: {e}"[:300]}
         trainer.sink.trace_on(False)
         # fallback leg: no bucketing, ONE all-reduce of the whole arena after the backward (DF_ONE_BUCKET=1 makes it the default)
+        prev = trainer.sink.one_bucket          # (= the default every other leg runs with: read BEFORE the A/B leg flips it)
+        one_bucket_default = bool(prev)
         try:
-            prev = trainer.sink.one_bucket
-            trainer.sink.one_bucket = True
-            trainer.step(batch)
-            dt1, _, _ = timed_steps(args.steps)
-            t1_ = torch.tensor([dt1], dtype=torch.float64, device=dev)
-            dist.all_reduce(t1_, op=dist.ReduceOp.MAX)
+            with leg("one_bucket"):
+                trainer.sink.one_bucket = True
+                trainer.step(batch)
+                dt1, _, _ = timed_steps(args.steps)
+                t1_ = torch.tensor([dt1], dtype=torch.float64, device=dev)
+                dist.all_reduce(t1_, op=dist.ReduceOp.MAX)
             one_bucket = {"ms_per_step": float(t1_.item()) / args.steps * 1e3, "bytes": trainer.flat.numel * 4,
                           "note": "the same step with DF_ONE_BUCKET=1: one all-reduce of the whole gradient arena after the backward, nothing overlapped"}
-            trainer.sink.one_bucket = prev
         except Exception as e:      # noqa: BLE001
             one_bucket = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            trainer.sink.one_bucket = prev      # whatever happened: the later legs run the bucketed configuration they report
     if world > 1 and not args.no_extras:
         # BASELINE configs[4] ("bf16 MFMA, 8xMI355X"): the same data-parallel step with dtype=bf16, collectives on, timed the same way
-        trainer.mfma_bf16 = True
-        for _ in range(2):
-            trainer.step(batch)
-        dtb_, _, lossb_ = timed_steps(args.steps)
-        trainer.mfma_bf16 = False
-        tb_ = torch.tensor([dtb_], dtype=torch.float64, device=dev)
-        dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
-        bf16_multi = (float(tb_.item()), float(lossb_))
+        try:
+            with leg("bf16_training"):
+                trainer.mfma_bf16 = True
+                for _ in range(2):
+                    trainer.step(batch)
+                dtb_, _, lossb_ = timed_steps(args.steps)
+                trainer.mfma_bf16 = False
+                tb_ = torch.tensor([dtb_], dtype=torch.float64, device=dev)
+                dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+                bf16_multi = (float(tb_.item()), float(lossb_))
+        except Exception as e:      # noqa: BLE001 -- reported, never fatal for the headline
+            bf16_multi = None
+            headline.setdefault("extras_failed", {})["bf16_training"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            trainer.mfma_bf16 = False
         # how much of the gradient all-reduce is NOT hidden behind the backward: the same steps without the collectives
         # (replicas drift apart afterwards -- only timings are taken after this)
-        trainer.collective = trainer.sink.collective = False
-        dt_nc, _, _ = timed_steps(args.steps)
-        tn = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
-        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
-        exposed = (dt - float(tn.item())) / args.steps * 1e3
-        trainer.collective = trainer.sink.collective = True
+        try:
+            with leg("allreduce_exposed"):
+                trainer.collective = trainer.sink.collective = False
+                dt_nc, _, _ = timed_steps(args.steps)
+                tn = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                exposed = (dt - float(tn.item())) / args.steps * 1e3
+        except Exception as e:      # noqa: BLE001
+            headline.setdefault("extras_failed", {})["allreduce_exposed"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            trainer.collective = trainer.sink.collective = True
         # the data-parallel bf16 step as a captured PROGRAM (HIP-graph segments split at the gradient buckets, the collectives
         # between them: optim.SegmentedCapture) -- the host-free form of the step the 8-GPU deployment runs.  Last, and guarded:
         # a failure here must not take the headline with it
         try:
-            trainer.mfma_bf16 = True
-            trainer.capture(batch)
-            for _ in range(2):
-                trainer.step_captured()
-            barrier()
-            tg0 = time.perf_counter()
-            for _ in range(args.steps):
-                trainer.step_captured()
-            torch.cuda.synchronize()
-            tloc = time.perf_counter() - tg0
-            barrier()
-            tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            hosts = []
-            for _ in range(5):          # host cost of ONE replayed step with an empty queue (no back-pressure from the GPU)
-                barrier()
-                th = time.perf_counter()
-                if share_gpu:           # gloo's all_reduce blocks the host on the device: time the graph launches alone
-                    for o in trainer._program:
-                        if o[0] == "graph":
-                            o[1].replay()
-                else:
-                    trainer.step_captured()
-                hosts.append((time.perf_counter() - th) * 1e3)
-            torch.cuda.synchronize()
-            kinds = [o[0] for o in trainer._program]
-            graph_multi = {"workload": "the data-parallel bf16 step replayed as HIP-graph segments split at the gradient buckets, collectives between them",
-                           "ms_per_step": float(tg.item()) / args.steps * 1e3, "host_ms_per_step": statistics.median(hosts),
-                           "graph_segments": kinds.count("graph"), "allreduce_calls": sum(len(o[1]) for o in trainer._program if o[0] == "allreduce")}
+          with leg("hip_graph"):
+              trainer.mfma_bf16 = True
+              trainer.capture(batch)
+              for _ in range(2):
+                  trainer.step_captured()
+              barrier()
+              tg0 = time.perf_counter()
+              for _ in range(args.steps):
+                  trainer.step_captured()
+              torch.cuda.synchronize()
+              tloc = time.perf_counter() - tg0
+              barrier()
+              tg = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=dev)
+              dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+              hosts = []
+              for _ in range(5):          # host cost of ONE replayed step with an empty queue (no back-pressure from the GPU)
+                  barrier()
+                  th = time.perf_counter()
+                  if share_gpu:           # gloo's all_reduce blocks the host on the device: time the graph launches alone
+                      for o in trainer._program:
+                          if o[0] == "graph":
+                              o[1].replay()
+                  else:
+                      trainer.step_captured()
+                  hosts.append((time.perf_counter() - th) * 1e3)
+              torch.cuda.synchronize()
+              kinds = [o[0] for o in trainer._program]
+              graph_multi = {"workload": "the data-parallel bf16 step replayed as HIP-graph segments split at the gradient buckets, collectives between them",
+                             "ms_per_step": float(tg.item()) / args.steps * 1e3, "host_ms_per_step": statistics.median(hosts),
+                             "graph_segments": kinds.count("graph"), "allreduce_calls": sum(len(o[1]) for o in trainer._program if o[0] == "allreduce")}
         except Exception as e:      # noqa: BLE001 -- reported in the line, never fatal
             graph_multi = {"error": f"{type(e).__name__}: {e}"[:300]}
         trainer.mfma_bf16 = False
@@ -442,6 +517,10 @@ def main():
             out["pillar_canvas"] = {"persistent": False}
     except Exception as e:      # noqa: BLE001
         out["pillar_canvas"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    if "extras_failed" in headline:
+        out["extras_failed"] = headline["extras_failed"]
+    if leg_state["done"]:
+        out["extras_completed"] = list(leg_state["done"])
     if selfcheck is not None:
         out["rccl_selfcheck"] = selfcheck
     if per_rank is not None:
@@ -454,7 +533,7 @@ def main():
     if one_bucket is not None:
         out["one_bucket"] = one_bucket
     if use_dist:
-        out["collectives"] = {"backend": "gloo (test hook)" if share_gpu else "nccl (RCCL)", "one_bucket_default": bool(trainer.sink.one_bucket),
+        out["collectives"] = {"backend": "gloo (test hook)" if share_gpu else "nccl (RCCL)", "one_bucket_default": one_bucket_default,
                               "arena_bytes": trainer.flat.numel * 4, "ranks": world}
     if share_gpu:
         out["collective_backend"] = "gloo, all ranks on cuda:0 (DF_BENCH_SHARE_GPU test hook: not a measurement)"
@@ -549,8 +628,10 @@ def main():
                                                          "|projection error| / ||g|| over every parameter gradient (a few sigma of the rms-relative error); "
                                                          "bound 1e-4 x 4.5 sigma", **worst,
                                              "source": os.path.relpath(report, ROOT), "source_mtime": int(os.path.getmtime(report)),
-                                             "source_commit": _git(["log", "-1", "--format=%h", "--", os.path.relpath(report, ROOT)]),
-                                             "head_commit": _git(["rev-parse", "--short", "HEAD"]),
+                                             "source_commit": _git(["log", "-1", "--format=%h", "--", os.path.relpath(report, ROOT)])
+                                             or _build_info().get("profiles", {}).get(os.path.relpath(report, ROOT)),
+                                             "head_commit": _git(["rev-parse", "--short", "HEAD"]) or _build_info().get("head_commit"),
+                                             "built_from_dirty_tree": _build_info().get("dirty"),
                                              "measured_in_this_run": False}
         except Exception:   # noqa: BLE001
             pass

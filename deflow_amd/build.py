@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libdeflow_amd.so")
-SOURCES = ["conv.hip", "conv_wgrad.hip", "conv_bf16.hip", "elementwise.hip", "pillarize.hip", "pillar_bands.hip", "decoder.hip", "decoder3.hip", "decoder4.hip", "decoder_bf16.hip", "decoder3_bwd.hip", "decoder_wgrad.hip", "decoder_bwd.hip", "misc.hip"]
+SOURCES = ["conv.hip", "conv_x3p.hip", "conv_wgrad.hip", "conv_bf16.hip", "elementwise.hip", "pillarize.hip", "pillar_bands.hip", "decoder.hip", "decoder3.hip", "decoder4.hip", "decoder_bf16.hip", "decoder3_bwd.hip", "decoder_wgrad.hip", "decoder_bwd.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-result"]
 # Per-file extras.  pillarize.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 instructions (v_pk_fma_f32 ...):
@@ -86,8 +86,41 @@ def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
     return lib
 
 
+BUILD_INFO = os.path.join(HERE, "_build_info.json")
+
+
+def write_build_info() -> None:
+    """deflow_amd/_build_info.json: the git state the library was built from -- HEAD, whether the tree was dirty, and for every file
+    under profiles/ the commit that last touched it.  The GPU box's snapshot has no .git, so bench.py's staleness fields
+    (`model_error_budget.source_commit` / `head_commit`) read this file there.  Travels with the snapshot (it is
+    git-ignored like the .so: a build product)."""
+    import json
+    import time
+    root = os.path.dirname(HERE)
+
+    def git(*a):
+        try:
+            r = subprocess.run(["git", "-C", root, *a], capture_output=True, text=True, timeout=20)
+            return r.stdout.strip() if r.returncode == 0 else None
+        except Exception:   # noqa: BLE001
+            return None
+
+    head = git("rev-parse", "--short", "HEAD")
+    if head is None:
+        return                  # not a git checkout (the GPU box): keep whatever file travelled here
+    info = {"head_commit": head, "dirty": bool(git("status", "--porcelain", "--untracked-files=no")), "built_at": int(time.time()), "profiles": {}}
+    pdir = os.path.join(root, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_parity_report.jsonl") or f == "pmc_traffic.json":
+                info["profiles"]["profiles/" + f] = git("log", "-1", "--format=%h", "--", "profiles/" + f)
+    with open(BUILD_INFO, "w") as fh:
+        json.dump(info, fh, indent=1)
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(BUILD, exist_ok=True)
+    write_build_info()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force:
         for s in srcs:

@@ -20,224 +20,6 @@
 namespace {
 
 
-// BWS (compile time; only the pre-split-input 3x3 data-gradient instances carry it): the DF_EPI_BWD_STATS epilogue -- every other
-// instance keeps the round-3 epilogue byte for byte (a run-time branch here cost the dominant kernels ~5 %: more scalar registers
-// live across the main loop)
-template <int BM, int BN, int WM, int WN, bool BWS = false>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* lds,
-                                              const RowDecode& dec, int m0, int m_end, int n0, int tile_m, int tid_in = -1) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  // tid_in: the persistent kernel hands in an OPAQUE copy of threadIdx.x per tile -- otherwise the compiler hoists every lane-dependent
-  // value of this epilogue out of its tile loop and carries ~100 registers through the main loop (measured: 65 spill stores per group)
-  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, kh = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  // ---- epilogue ------------------------------------------------------------------------
-  // LDS is free now: row -> output element offset table, then the stats scratch.
-  int64_t* rowoff = reinterpret_cast<int64_t*>(lds);            // [BM]
-  float* red = lds + 2 * BM;                                    // [WM][BN][2]
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int64_t off = -1;
-    if (m < m_end) {
-      int n, oy, ox;
-      dec(m, n, oy, ox);
-      off = df_img_base(p.y, n) + ((int64_t)oy * p.y.w + ox) * p.y.ld;
-    }
-    rowoff[tid] = off;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (raw: the table is LDS traffic only)
-  float* __restrict__ yp = reinterpret_cast<float*>(p.y.ptr);
-  float amax_t = 0.f;                                           // max |y| over this thread's stored elements
-  if (p.y_bytes) {
-    // Straight-line stores: buffer stores whose offset is out of range for rows past the end (dropped by the hardware)
-    // instead of a branch per element.  With the branch the compiler had to re-wait for the bias / scale loads inside every
-    // element block -- s_waitcnt vmcnt(0), which also waits for the PREVIOUS element's store: 16 TM serialised write
-    // round trips per wave.
-    // Y16 (p.y.elt == 1, bf16-storage training): the value is rounded to bf16 (RNE) and stored as 2 bytes; the BatchNorm
-    // statistics are taken from the ROUNDED values, i.e. of the tensor the normalisation pass will actually read.
-    constexpr unsigned ROW_BAD = 0xFFFFFFFFu - (8u << 20);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y.ptr, 0, p.y_bytes, 0x00020000);
-    // YH2 (p.y.elt == 2, round 4): y is written PRE-SPLIT for an fp16x2 consumer -- per pixel and 32-channel chunk one 128-byte line
-    // [32 fp16 hi | 32 fp16 lo] of y s, s = df_h2_scale(*p.bound_y) (a bound of max |y| the caller knows before the launch).  A lane
-    // owns one channel of the chunk (li): lanes exchange halves with their neighbour (one DPP move) so that every lane still stores
-    // ONE dword per element -- even lanes the hi pair (channels li, li + 1), odd lanes the lo pair (li - 1, li).
-    constexpr bool bws = BWS;
-    const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bws ? p.bwd_y : reinterpret_cast<const float*>(p.y.ptr)), 0,
-                                                                         p.y_bytes, 0x00020000);
-    int bgrp = 0;
-    if constexpr (bws) {
-      int n_, oy_, ox_;
-      dec(m0, n_, oy_, ox_);
-      bgrp = n_ / p.y.grp_size;           // statistic group of this tile (a tile never straddles two)
-    }
-    // FULL (round 5): every row of the tile is inside the tensor (m0 + BM <= m_end -- all of this network's layers), so no element
-    // needs its "row exists" test.  With the tests, the 64 per-element conditions of a wave (64-bit lane masks) did not fit the
-    // scalar registers: they were spilled to VGPR lanes and every masked sum / max cost two v_readlane + a v_cndmask on top of its
-    // arithmetic -- ~13 of the ~32 VALU instructions per output element of the fp16x2 epilogue (ISA count, conv_halo_x3p_kernel<512,64>),
-    // while the epilogue is the part of a tile in which no wave of the workgroup issues MFMAs.
-    auto body = [&](auto y_tag, auto full_tag) {
-      constexpr int YT = decltype(y_tag)::value;
-      constexpr bool FULL = decltype(full_tag)::value;
-      constexpr bool Y16 = YT == 1, YH2 = YT == 2;
-      constexpr int ESZ = Y16 ? 2 : 4;
-      float sy = 1.f;
-      if constexpr (YH2) sy = df_h2_scale(*p.bound_y);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int co = n0 + (wn * TN + j) * 32 + li;
-        const float bia = p.bias ? p.bias[co] : 0.f;
-        float sc = 1.f, sh = 0.f;
-        if (p.epi == DF_EPI_BN_GELU) {
-          sc = p.scale[co];
-          sh = p.shift[co];
-        }
-        float s1 = 0.f, s2 = 0.f;
-        float b_sc = 1.f, b_sh = 0.f, b_mu = 0.f, b_is = 1.f;
-        if constexpr (bws) {
-          const float* ss = p.bwd_ss + (int64_t)bgrp * 4 * p.N;
-          b_sc = ss[co]; b_sh = ss[p.N + co]; b_mu = ss[2 * p.N + co]; b_is = ss[3 * p.N + co];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          unsigned ob[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
-            else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
-          }
-          float old[16];
-          if constexpr (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
-#pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], 0, 0));
-          }
-          if (p.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              if constexpr (Y16)
-                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], 0, 0) << 16);
-              else
-                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[i][j][e] + bia;
-            if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-            if (p.accumulate) v += old[e];
-            if constexpr (Y16) {
-              const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
-              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], 0, 0);
-              v = __builtin_bit_cast(float, (unsigned)h << 16);
-            } else if constexpr (YH2) {
-              const float t = v * sy;
-              const _Float16 hi = (_Float16)t;
-              const _Float16 lo = (_Float16)((t - (float)hi) * H2_LO);
-              const unsigned hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
-              const unsigned send = (li & 1) ? hb : lb;                 // odd lanes hand their hi to the even neighbour, even lanes their lo
-              const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-              const unsigned word = (li & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], 0, 0);
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
-            }
-            if (FULL || ob[e] != ROW_BAD) {
-              if constexpr (bws) {
-                const float g = v * df_gelu_grad(fmaf(old[e], b_sc, b_sh));
-                s1 += g;
-                s2 += g * ((old[e] - b_mu) * b_is);
-              } else {
-                s1 += v;
-                s2 += v * v;
-              }
-              amax_t = fmaxf(amax_t, fabsf(v));
-            }
-          }
-        }
-        if (BWS || p.epi == DF_EPI_STATS) {
-          s1 += __shfl_xor(s1, 32);
-          s2 += __shfl_xor(s2, 32);
-          if (kh == 0) {
-            const int cl = (wn * TN + j) * 32 + li;
-            red[(wm * BN + cl) * 2 + 0] = s1;
-            red[(wm * BN + cl) * 2 + 1] = s2;
-          }
-        }
-      }
-    };
-    const bool full = m0 + BM <= m_end;      // (workgroup-uniform)
-    if (full) {
-      if (p.y.elt == 2) body(std::integral_constant<int, 2>{}, std::true_type{});
-      else if (p.y.elt == 1) body(std::integral_constant<int, 1>{}, std::true_type{});
-      else body(std::integral_constant<int, 0>{}, std::true_type{});
-    } else {
-      if (p.y.elt == 2) body(std::integral_constant<int, 2>{}, std::false_type{});
-      else if (p.y.elt == 1) body(std::integral_constant<int, 1>{}, std::false_type{});
-      else body(std::integral_constant<int, 0>{}, std::false_type{});
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co = n0 + (wn * TN + j) * 32 + li;
-      const float bia = p.bias ? p.bias[co] : 0.f;
-      float sc = 1.f, sh = 0.f;
-      if (p.epi == DF_EPI_BN_GELU) {
-        sc = p.scale[co];
-        sh = p.shift[co];
-      }
-      float s1 = 0.f, s2 = 0.f;
-  #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          const int64_t off = rowoff[row];
-          float v = acc[i][j][e] + bia;
-          if (off >= 0) {
-            if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
-            if (p.accumulate) v += yp[off + co];
-            yp[off + co] = v;
-            s1 += v;
-            s2 += v * v;
-            amax_t = fmaxf(amax_t, fabsf(v));
-          }
-        }
-      }
-      if (p.epi == DF_EPI_STATS) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (kh == 0) {
-          const int cl = (wn * TN + j) * 32 + li;
-          red[(wm * BN + cl) * 2 + 0] = s1;
-          red[(wm * BN + cl) * 2 + 1] = s2;
-        }
-      }
-    }
-  }
-  if (BWS || p.epi == DF_EPI_STATS) {
-    // raw barrier: the partial sums are LDS traffic.  __syncthreads() also drains vmcnt -- every wave then waited for the acknowledgement
-    // of the tile's global stores (1-2 us of a 36-45 us workgroup) before the last 64 threads could add up eight numbers
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid < BN) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s1 += red[(w * BN + tid) * 2 + 0];
-        s2 += red[(w * BN + tid) * 2 + 1];
-      }
-      float* o = p.stats + ((int64_t)tile_m * p.stats_mul * p.N + n0 + tid) * 2;
-      o[0] = s1;
-      o[1] = s2;
-      for (int r = 1; r < p.stats_mul; ++r) {
-        o[(int64_t)r * p.N * 2] = 0.f;
-        o[(int64_t)r * p.N * 2 + 1] = 0.f;
-      }
-    }
-  }
-  if (p.amax_y) df_block_amax(amax_t, p.amax_y);                // (uniform branch)
-}
-
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
   constexpr int TM = BM / WM / 32;  // 32x32 MFMA tiles per wave along m
@@ -840,7 +622,6 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
 // Rows are 64 B (32 bf16); 16-B slots XOR-swizzled with (row >> 2) & 3: any 16 consecutive rows (a b128 service group,
 // whatever the tap shift) cover all 64 banks once.  Accumulator layout = conv_halo_kernel's, so the fp32 epilogues
 // (bias / statistics / BN+GELU / accumulate) are shared.
-constexpr int LDH = 16;   // floats per bf16 tile row
 // SEG = 1: the tile's 128 output pixels are one run of an image row (W % 128 == 0), halo = 130 pixels.  SEG = 2: W == 64, the
 // tile is two whole image rows, halo = 2 x 66 pixels (halo row 66 s + c + tx feeds output pixel (oy + s, c)); 32-row MFMA
 // blocks never straddle the two rows.
@@ -1444,294 +1225,6 @@ static int launch_conv_halo_x3(const ConvParams& p, hipStream_t s) {
   return DF_OK;
 }
 
-// ---- PERSISTENT form of conv_halo_x3_kernel<.., NP = 2, XP> (round 4; DF_CONV_PERS=0 restores the one-tile-per-workgroup form) -------
-// One workgroup per CU walks its tiles (virtual block ids blockIdx.x, + gridDim.x, ...: the same tile -> XCD placement and the same
-// side-by-side rows as the plain launch).  Per tile the plain form pays its prologue (halo + first weight stages: ~2-3 us of DMA latency
-// with an empty matrix pipe) and its epilogue (~3 us of stores) on top of 18-36 stages of ~1.2 us: ~20 % of a 64-channel layer's
-// workgroup, ~12 % of a 128-channel one.  Here the NEXT tile's first halo group and first weight stage are issued during the last
-// group of the current tile (the halo buffer and ring slot they land in are free by then), the epilogue's stores are left in flight,
-// and the remaining PD - 1 weight stages of the next tile are issued right after the epilogue -- so that every store is OLDER than
-// every load a counted wait later reasons about (outstanding <= N then bounds the loads among them whatever order stores and loads
-// retire in).  Same arithmetic per tile in the same order: bit-identical to the plain form.
-template <int BM, int BN, int WM, int WN, int SEG, int DB, bool BWS = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3p_kernel(ConvParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NP = 2;
-  constexpr int SW = BM / SEG + 2;
-  constexpr int HR = (SEG * SW + 15) / 16 * 16;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int NW = WM * WN;
-  constexpr int NAOPS = NP * HR / 16, NAO = (NAOPS + NW - 1) / NW;
-  constexpr int AP = HR * LDH, AB = NP * AP, BP = BN * LDH, BSL = NP * BP;
-  constexpr int PD = DB - 1;
-  constexpr int NBW = NP, NFA = NAO;
-  static_assert(NW == 8 && (PD == 2 || PD == 3) && (BN == 128 || BN == 64), "persistent form: the pre-split tile shapes only");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                      // [2][NP][HR][LDH]
-  float* Bs = lds + 2 * AB;             // [DB][NP][BN][LDH]
-  const float sx = df_h2_scale(*p.amax_x), sw = df_h2_scale(*p.amax_w);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, kh = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  const int hx = p.x.h, wx = p.x.w, ldx = p.x.ld;
-  const int KC = p.K / BK;
-  const bool fwd = p.mode == DF_CONV_FWD;
-  const int ntiles = p.tiles_m * p.tiles_n;
-  RowDecode dec;
-  dec.hw = p.hw_y; dec.w = p.y.w; dec.cls_mode = 0; dec.py = dec.px = 0; dec.hh = dec.wh = 0;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(p.x.ptr) - p.dshift), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-  const int brow = ((wave * 16) % BN) + (lane >> 2), bslot = (lane & 3) ^ ((lane >> 4) & 3);
-  const unsigned plane_bytes = (unsigned)((int64_t)p.N * 9 * p.K * 2);
-  // halo ops of this wave (as conv_halo_x3_kernel<XP>): op e = halo op (wave + e NW) mod NAOPS = plane pl, rows rb 16 .. + 15 -- wave-uniform,
-  // recomputed where needed (scalar); per lane only the source offset of the tile being fetched is kept (poff)
-  auto op_rb = [&](int e, int& pl, int& rb) {
-    const int jo = (wave + e * NW) % NAOPS;
-    pl = jo / (HR / 16);
-    rb = jo - pl * (HR / 16);
-  };
-  auto op_seg = [&](int j) { return SEG == 1 ? 0 : min(j / SW, SEG - 1); };
-  // ... and the cursors of the tile being FETCHED (A side: halo; B side: weights), which run ahead of the tile being multiplied
-  unsigned poff[NAO];
-  int a_oy = 0, ty_next = 0, kc_next = 0;
-  unsigned sa_next = 0;
-  unsigned boff = 0;
-  int swb_next = 0, btx = 0, bkc = 0, bty = 0;
-  const unsigned a_row = (unsigned)(wx * ldx * 4);
-  const unsigned a_row_step = a_row - (unsigned)(KC * BK * 4);
-  const int dtap = fwd ? p.K * 2 : -p.K * 2;
-  const int NG = 3 * KC, NS = 3 * NG;
-  auto tile_of = [&](int b, int& tm, int& tn) {
-    const int swz = df_xcd_swizzle(b, ntiles);
-    tn = swz % p.tiles_n;
-    tm = swz / p.tiles_n;
-  };
-  // the NEXT tile's offsets are computed at the top of a tile -- while no accumulator is live (computed inside the last group, beside
-  // 128 accumulator registers, they pushed the allocator into spilling in the main loop) -- and taken over where the cursors switch
-  unsigned poffN[NAO], boffN = 0;
-  int a_oyN = 0, rotN = 0;
-  auto prep = [&](int b) {
-    int tm, tn, n, oy, ox0;
-    tile_of(b, tm, tn);
-    dec(tm * BM, n, oy, ox0);
-    const int64_t base = df_img_base(p.x, n);
-#pragma unroll
-    for (int e = 0; e < NAO; ++e) {
-      int pl, rb;
-      op_rb(e, pl, rb);
-      const int j = rb * 16 + (lane >> 2), sg = op_seg(j);
-      const int ix = ox0 - 1 + j - sg * SW;
-      poffN[e] = (j < SEG * SW && ix >= 0 && ix < wx)
-                     ? (unsigned)((base + ((int64_t)(oy + sg - 1) * wx + ix) * ldx) * 4 + pl * 64 + ((lane & 3) ^ ((j >> 2) & 3)) * 16) + p.dshift : DMA_BAD;
-    }
-    boffN = (unsigned)(((int64_t)(tn * BN + brow) * 9 * p.K + bslot * 8) * 2);
-    a_oyN = oy;
-    rotN = (p.rot && SEG <= 2) ? (1 + 2 * oy) % 3 : 0;
-  };
-  auto take_a = [&]() {
-#pragma unroll
-    for (int e = 0; e < NAO; ++e) poff[e] = poffN[e];
-    a_oy = a_oyN;
-    sa_next = rotN * a_row;
-    ty_next = rotN;
-    kc_next = 0;
-  };
-  auto take_b = [&]() {
-    boff = boffN;
-    swb_next = (fwd ? 0 : 8 * p.K * 2) + rotN * 3 * dtap;
-    btx = 0;
-    bkc = 0;
-    bty = rotN;
-  };
-  auto fetch_a = [&](int abuf) {
-    float* a = As + abuf * AB;
-#pragma unroll
-    for (int e = 0; e < NAO; ++e) {
-      int pl, rb;
-      op_rb(e, pl, rb);
-      const int sg = op_seg(rb * 16 + (lane >> 2));
-      const unsigned v = (unsigned)(a_oy + sg - 1 + ty_next) < (unsigned)hx ? poff[e] : DMA_BAD;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(a + pl * AP + rb * 16 * LDH), 16, v, sa_next, 0, 0);
-    }
-    if (++kc_next == KC) {
-      kc_next = 0;
-      sa_next += a_row_step + BK * 4;
-      if (++ty_next == 3) {
-        ty_next = 0;
-        sa_next -= 3 * a_row;
-      }
-    } else {
-      sa_next += BK * 4;
-    }
-  };
-  int bslot_ring = 0;
-  auto issue_b = [&]() {
-    float* b = Bs + bslot_ring * BSL + ((wave * 16) % BN) * LDH;
-    const unsigned soff = (unsigned)(swb_next + btx * dtap);
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(b + pl * BP), 16, boff, soff + pl * plane_bytes, 0, 0);
-    if (++bslot_ring == DB) bslot_ring = 0;
-    if (++btx == 3) {
-      btx = 0;
-      if (++bkc == KC) {
-        bkc = 0;
-        swb_next += 3 * dtap - KC * BK * 2 + BK * 2;
-        if (++bty == 3) {
-          bty = 0;
-          swb_next -= 9 * dtap;
-        }
-      } else {
-        swb_next += BK * 2;
-      }
-    }
-  };
-#define DF_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
-#define DF_STAGE_END() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  f32x16 acc[TM][TN], acc1[TM][TN];
-  int cur_slot = 0;
-  // the products of one tap stage: halo buffer gp, tap column tx, weight ring slot cur_slot
-  auto mult = [&](auto tx_c, int gp) {
-    constexpr int tx = decltype(tx_c)::value;
-    const float* a = As + gp * AB + (wm * TM * 32 + li) * LDH + tx * LDH;
-    const float* b0 = Bs + cur_slot * BSL + (wn * TN * 32 + li) * LDH;
-    if (++cur_slot == DB) cur_slot = 0;
-    const int sb = (li >> 2) & 3;
-#pragma unroll
-    for (int q = 0; q < BK / 16; ++q) {
-      f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int sh = SEG == 1 ? 0 : 2 * ((wm * TM + i) * 32 / (BM / SEG));
-        const int sa = ((li + tx + sh) >> 2) & 3;
-        const float* ap = a + (i * 32 + sh) * LDH + (((2 * q + kh) ^ sa) * 4);
-        ah[i] = *reinterpret_cast<const f16x8_t*>(ap);
-        al[i] = *reinterpret_cast<const f16x8_t*>(ap + AP);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float* bp = b0 + j * 32 * LDH + (((2 * q + kh) ^ sb) * 4);
-        bh[j] = *reinterpret_cast<const f16x8_t*>(bp);
-        bl[j] = *reinterpret_cast<const f16x8_t*>(bp + BP);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
-        }
-    }
-  };
-  // a steady-state stage: issue (tx == 0: the next group's halo; always: weight stage s + PD), multiply, counted wait (weight stage
-  // s + 1, and at tx == 2 the halo, have landed: see conv_halo_x3_kernel), barrier
-  auto steady = [&](auto tx_c, int gp) {
-    constexpr int tx = decltype(tx_c)::value;
-    if (tx == 0) fetch_a(gp ^ 1);
-    issue_b();
-    mult(tx_c, gp);
-    constexpr int FA_IN = ((PD - 1) / 3) + (((PD - 1) % 3) > tx ? 1 : 0);
-    DF_VMCNT((PD - 1) * NBW + FA_IN * NFA);
-    DF_STAGE_END();
-  };
-  using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
-  using T2 = std::integral_constant<int, 2>;
-
-  int bid = blockIdx.x;
-  prep(bid);
-  take_a();
-  take_b();
-  fetch_a(0);
-#pragma unroll
-  for (int d = 0; d < PD; ++d) issue_b();
-  DF_VMCNT((PD - 1) * NBW);                             // the halo (issued first) and weight stage 0
-  DF_STAGE_END();
-  int gb = 0;                                           // halo buffer parity of the current tile's group 0
-  while (true) {
-    const int nbid = bid + gridDim.x;
-    const bool has_next = nbid < ntiles;
-    int tile_m, tile_n;
-    tile_of(bid, tile_m, tile_n);
-    if (has_next) prep(nbid);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
-    int g = 0;
-    for (; g < NG - 1; ++g) {                           // every issue of these groups belongs to this tile (NS - PD >= 3 NG - 3)
-      const int gp = (gb + g) & 1;
-      steady(T0{}, gp);
-      steady(T1{}, gp);
-      steady(T2{}, gp);
-    }
-    const int gp = (gb + g) & 1;
-    // last group.  With a next tile: the halo fetch is ITS group 0, and of its weight stages only stage 0 goes out before the epilogue;
-    // without: nothing is left to issue but (PD == 2) this tile's last weight stage, and the waits drain.  (One copy of the products
-    // for both cases: two copies cost the main loop 60 spill stores per group.)
-    if (has_next) {
-      take_a();
-      fetch_a(gp ^ 1);
-      if constexpr (PD == 3) take_b();
-    }
-    if (PD == 2 || has_next) issue_b();                 // PD == 2: this tile's stage NS - 1; PD == 3: the next tile's stage 0
-    mult(T0{}, gp);
-    if (has_next) DF_VMCNT((PD - 1) * NBW + NFA);       // (the steady pattern held up to here)
-    else DF_VMCNT(0);
-    DF_STAGE_END();
-    if (PD == 2 && has_next) {
-      take_b();
-      issue_b();                                        // the next tile's stage 0
-    }
-    mult(T1{}, gp);
-    if (has_next) DF_VMCNT(PD == 2 ? NBW : NFA + NBW);  // this tile's last weight stage is older than the next tile's halo / stage 0
-    else DF_VMCNT(0);
-    DF_STAGE_END();
-    mult(T2{}, gp);
-    DF_VMCNT(0);                                        // the next tile's halo group 0 and weight stage 0: nothing else is in flight
-    DF_STAGE_END();
-    {   // fold the cross terms in and take the two power-of-two scales out (exact multiplications)
-      const float ix = 1.f / sx, iw = 1.f / sw;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
-    }
-    // epilogue scratch = the halo buffer the last group just left (the other one is receiving the next tile's group 0)
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
-    conv_epilogue<BM, BN, WM, WN, BWS>(p, acc, As + gp * AB, dec, tile_m * BM, p.M, tile_n * BN, tile_m, tid_o);
-    if (!has_next) break;
-    DF_STAGE_END();                                     // every wave is done with the scratch before the next halo fetch may overwrite it
-#pragma unroll
-    for (int d = 1; d < PD; ++d) issue_b();             // next tile's weight stages 1 .. PD - 1: younger than every store of the epilogue
-    bid = nbid;
-    gb += NG;
-  }
-#undef DF_VMCNT
-#undef DF_STAGE_END
-#endif
-}
-
-template <int BM, int BN, int WM, int WN, int SEG, int DB, bool BWS = false>
-static int launch_conv_halo_x3p(const ConvParams& p, hipStream_t s) {
-  constexpr int HR = (SEG * (BM / SEG + 2) + 15) / 16 * 16;
-  const size_t lds_bytes = (size_t)(2 * 2 * HR + DB * 2 * BN) * LDH * sizeof(float);
-  DF_SET_LDS_ONCE((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS>), (int)lds_bytes);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;     // one workgroup per CU (the LDS holds one); a multiple of the 8 XCDs
-  hipLaunchKernelGGL((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS>), dim3(grid), dim3(64 * WM * WN), lds_bytes, s, p);
-  DF_CHECK_LAUNCH();
-  return DF_OK;
-}
-
 // w [n] fp32 -> two fp16 planes out2[2][n] of w s (s = df_h2_scale(*amax)): hi = fp16(w s), lo = fp16((w s - hi) 2048)
 __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ w, const float* __restrict__ amax,
                                                        _Float16* __restrict__ out2, int64_t n) {
@@ -2150,14 +1643,10 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
         p.stats_mul = 2;
         static const int pers = getenv("DF_CONV_PERS") ? atoi(getenv("DF_CONV_PERS")) : 1;
         if (xp && pers && epi == DF_EPI_BWD_STATS) {
-          if (seg == 1) return launch_conv_halo_x3p<256, 128, 4, 2, 1, 4, true>(p, s);
-          if (seg == 2) return launch_conv_halo_x3p<256, 128, 4, 2, 2, 4, true>(p, s);
-          return launch_conv_halo_x3p<256, 128, 4, 2, 4, 4, true>(p, s);
+          return df_launch_conv_halo_x3p(p, 128, seg, true, s);
         }
         if (xp && pers) {
-          if (seg == 1) return launch_conv_halo_x3p<256, 128, 4, 2, 1, 4>(p, s);
-          if (seg == 2) return launch_conv_halo_x3p<256, 128, 4, 2, 2, 4>(p, s);
-          return launch_conv_halo_x3p<256, 128, 4, 2, 4, 4>(p, s);
+          return df_launch_conv_halo_x3p(p, 128, seg, false, s);
         }
         if (xp && epi == DF_EPI_BWD_STATS) {
           if (seg == 1) return launch_conv_halo_x3<256, 128, 4, 2, 1, 4, 2, false, true, true>(p, s);
@@ -2181,8 +1670,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
         p.stats_mul = 4;
         static const int pers64 = getenv("DF_CONV_PERS") ? atoi(getenv("DF_CONV_PERS")) : 1;
         if (xp && pers64 && epi == DF_EPI_BWD_STATS)
-          return seg64 == 1 ? launch_conv_halo_x3p<512, 64, 8, 1, 1, 3, true>(p, s) : launch_conv_halo_x3p<512, 64, 8, 1, 2, 3, true>(p, s);
-        if (xp && pers64) return seg64 == 1 ? launch_conv_halo_x3p<512, 64, 8, 1, 1, 3>(p, s) : launch_conv_halo_x3p<512, 64, 8, 1, 2, 3>(p, s);
+          return df_launch_conv_halo_x3p(p, 64, seg64, true, s);
+        if (xp && pers64) return df_launch_conv_halo_x3p(p, 64, seg64, false, s);
         if (xp && epi == DF_EPI_BWD_STATS)
           return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2, false, true, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2, false, true, true>(p, s);
         if (xp) return seg64 == 1 ? launch_conv_halo_x3<512, 64, 8, 1, 1, 3, 2, false, true>(p, s) : launch_conv_halo_x3<512, 64, 8, 1, 2, 3, 2, false, true>(p, s);

@@ -114,17 +114,21 @@ __device__ __forceinline__ void offs_to_lds(float* Ow, const float* offs, int64_
   }
 }
 
-template <bool SAVE, int MODE>
-__global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd4_kernel(Gru4Params p) {
+// NWV (round 6) = waves per workgroup: 4 (64 points, two workgroups per CU: rounds 3-5) or 8 (128 points, ONE workgroup per CU).  The
+// eight-wave form moves every weight chunk L2 -> LDS once per 128 points instead of once per 64: tools/bench_gru_lean.py with the DMA
+// compiled out showed the weight stream -- its ISSUE, four 1-KB buffer_load ... lds per wave and chunk, not the wait for it: removing
+// only the waits and barriers gained 4 % -- costing 20 % of the forward and 28 % of the backward.  Same arithmetic per point.
+template <bool SAVE, int MODE, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? DF_GRU_LB : NWV == 12 ? 3 : 2) DF_GRU_ATTR void gru_fwd4_kernel(Gru4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool BF = MODE == 1 || MODE == 2, W16 = MODE == 2, X2 = MODE == 3;
-  __shared__ __attribute__((aligned(16))) float Bs[2 * BT];         // 32 KB
-  __shared__ __attribute__((aligned(16))) float As[4 * 16 * LDH];   // 33.8 KB
-  __shared__ __attribute__((aligned(16))) float Xt[XT_ROWS * 4];    // 6.6 KB
-  __shared__ __attribute__((aligned(16))) float Os[4 * 16 * 4];     // 1 KB
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BT];           // 32 KB
+  __shared__ __attribute__((aligned(16))) float As[NWV * 16 * LDH];   // 33.8 KB per four waves
+  __shared__ __attribute__((aligned(16))) float Xt[XT_ROWS * 4];      // 6.6 KB
+  __shared__ __attribute__((aligned(16))) float Os[NWV * 16 * 4];     // 1 KB per four waves
   const int b = blockIdx.y;
   const int cnt = p.counts[b];
-  const int p0 = blockIdx.x * 64;
+  const int p0 = blockIdx.x * (16 * NWV);
   if (p0 >= cnt) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,11 +149,11 @@ __global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd4_kernel(Gr
   const float* w_r = p.w.w_zr + 128 * 192 / WSC;
   const float* w_q = p.w.w_q;
 
-  WStreamT<MODE> ws;
+  WStreamT<MODE, NWV> ws;
   wstream_init(ws, Bs);
   dma_first<128, 192>(w_z, 0, Bs, ws);
 
-  for (int i = tid; i < XT_ROWS; i += 256) st4(Xt + 4 * i, ld4(p.xtab + 4 * i));
+  for (int i = tid; i < XT_ROWS; i += 64 * NWV) st4(Xt + 4 * i, ld4(p.xtab + 4 * i));
   offs_to_lds(Ow, p.offs, grow0, nvalid, lane);
   // ---- gather h0 = [before | after] -------------------------------------------------------------------------------
   {
@@ -171,11 +175,18 @@ __global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd4_kernel(Gr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  f32x4 of[4];   // this lane's four rows of (o_x, o_y, o_z)
+  f32x4 of[4];   // this lane's four rows of (o_x, o_y, o_z)  (12 waves: re-read where used -- 16 of the 168 registers)
 #pragma unroll
   for (int r = 0; r < 4; ++r) of[r] = ld4(Ow + (4 * lq + r) * 4);
   // x contribution + bias of gate g (rows 128 g ..) as the initial accumulator
   auto xinit = [&](f32x4 (&acc)[8], int g) {
+    if constexpr (NWV == 12) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        of[r] = ld4(Ow + (4 * lq + r) * 4);
+        asm volatile("" : "+v"(of[r]));   // (a fresh value per use: not kept across the GEMMs)
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const f32x4 tb = ld4(Xt + (g * 128 + 16 * t + li) * 4);
@@ -239,6 +250,10 @@ __global__ __launch_bounds__(256, DF_GRU_LB) DF_GRU_ATTR void gru_fwd4_kernel(Gr
   if (SAVE) save_rows(p.T);   // h_T
   // ---- MLP head: hid = W1[:, :128] h_T + (x table rows 384 ..) -----------------------------------------------------
   f32x4 hid[2];
+  if constexpr (NWV == 12) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) of[r] = ld4(Ow + (4 * lq + r) * 4);
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const f32x4 tb = ld4(Xt + (384 + 16 * t + li) * 4);
@@ -279,19 +294,19 @@ struct GruBwd4Params {
   float* partial;          // [blocks][PW4]
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
+template <int MODE, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void gru_bwd4_kernel(GruBwd4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool BF = MODE == 1 || MODE == 2, W16 = MODE == 2, X2 = MODE == 3;
   __shared__ __attribute__((aligned(16))) float Bs[2 * BT];
-  __shared__ __attribute__((aligned(16))) float As[4 * 16 * LDH];
+  __shared__ __attribute__((aligned(16))) float As[NWV * 16 * LDH];
   __shared__ __attribute__((aligned(16))) float Xt[XT_ROWS * 4];
-  __shared__ __attribute__((aligned(16))) float Os[4 * 16 * 4];
+  __shared__ __attribute__((aligned(16))) float Os[NWV * 16 * 4];
   constexpr int SMALL_W = 228;   // dW_2 [3][32] | d b_1 [32] | d b_2 [3] | pad | S_1[.][0..2] [3][32]
-  __shared__ float Small[4 * SMALL_W];
+  __shared__ float Small[NWV * SMALL_W];
   const int b = blockIdx.y;
   const int cnt = p.counts[b];
-  const int p0 = blockIdx.x * 64;
+  const int p0 = blockIdx.x * (16 * NWV);
   if (p0 >= cnt) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
   const float* wt_q = p.wt.wt_q;
   const float* wt_zr = p.wt.wt_zr;
 
-  WStreamT<MODE> ws;
+  WStreamT<MODE, NWV> ws;
   wstream_init(ws, Bs);
   dma_first<32, 192>(p.w.w_1, 0, Bs, ws);
 
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
       for (int r = 0; r < 4; ++r) c_lane[r * LDH + 16 * t] = v[t][r];
   };
 
-  for (int i = tid; i < XT_ROWS; i += 256) st4(Xt + 4 * i, ld4(p.xtab + 4 * i));
+  for (int i = tid; i < XT_ROWS; i += 64 * NWV) st4(Xt + 4 * i, ld4(p.xtab + 4 * i));
   offs_to_lds(Ow, p.offs, grow0, nvalid, lane);
   rows_to_lds(p.hsave + p.T * p.iter_stride, false);   // h_T
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -560,7 +575,10 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
   wave_lds_sync();
   lds_to_rows(p.dh0);
   // ---- per-workgroup partial sums (rows beyond cnt contributed exact zeros) --------------------------------------------
-  float* red = Bs;   // the weight buffers are idle now: [4 waves][PW4]
+  // [NWV waves][PW4]: four waves fit the idle weight buffers; eight take the A regions (every wave's dh0 rows have left them first)
+  float* red = NWV == 4 ? Bs : As;
+  static_assert(NWV == 4 || NWV * PW4 <= NWV * 16 * LDH, "the partials of eight waves fit the A regions");
+  if (NWV != 4) __syncthreads();
   {
     float* rw = red + wave * PW4;
 #pragma unroll
@@ -575,8 +593,11 @@ __global__ __launch_bounds__(256, 2) void gru_bwd4_kernel(GruBwd4Params p) {
     if (lane == 0) rw[1763] = 0.f;
   }
   __syncthreads();
-  for (int o = tid; o < PW4; o += 256)
-    p.partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PW4 + o] = red[o] + red[PW4 + o] + red[2 * PW4 + o] + red[3 * PW4 + o];
+  for (int o = tid; o < PW4; o += 64 * NWV) {
+    float a = red[o] + red[PW4 + o] + red[2 * PW4 + o] + red[3 * PW4 + o];
+    if (NWV == 8) a += red[4 * PW4 + o] + red[5 * PW4 + o] + red[6 * PW4 + o] + red[7 * PW4 + o];
+    p.partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PW4 + o] = a;
+  }
 #endif
 }
 
@@ -618,6 +639,15 @@ __global__ __launch_bounds__(256) void gru_lean_finalize_kernel(FinParams p) {
   }
 }
 
+// Waves per workgroup of the lean kernels (round 6; same arithmetic per point in every form, bit-identical results):
+//   backward: DF_GRU_WAVES = 4 (default: 64 points, two workgroups per CU) | 8 (128 points, one per CU -- measured equal: 5.45 vs 5.48 ms)
+//   forward:  DF_GRU_FWD_WAVES = 12 (default in bf16x2 mode: 192 points, THREE waves per SIMD at 168 registers -- 2.50 vs 2.72 ms,
+//             tools/bench_gru_lean.py) | 8 | 4
+int gru_waves() {
+  const char* e = getenv("DF_GRU_WAVES");
+  return (e && atoi(e) == 8) ? 8 : 4;
+}
+
 bool img64_ok4(const df_img& d, int B) {
   return d.ptr && df_aligned16(d.ptr) && d.n == B && d.c == 64 && (d.ld % 4) == 0 && (d.img_stride % 4) == 0 &&
          (d.grp_off % 4) == 0 && d.grp_size > 0;
@@ -652,12 +682,22 @@ extern "C" int df_gru_lean_fwd(df_img before, df_img after, const int32_t* coord
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;
   p.N = N; p.T = num_iters; p.w = wts; p.xtab = xtab; p.flow = flow; p.hsave = hsave;
   p.iter_stride = (int64_t)B * N * 128;
-  const dim3 grid((N + 63) / 64, B);
+  static const int nwv0 = getenv("DF_GRU_FWD_WAVES") ? atoi(getenv("DF_GRU_FWD_WAVES")) : 12;
+  const int nwv = (nwv0 == 12 && mfma_bf16 != 3) ? gru_waves() : (nwv0 == 12 || nwv0 == 8) ? nwv0 : 4;
+  const dim3 grid((N + 16 * nwv - 1) / (16 * nwv), B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DF_FWD4(M)                                                                                      \
   do {                                                                                                  \
-    if (hsave) hipLaunchKernelGGL((gru_fwd4_kernel<true, M>), grid, dim3(256), 0, s, p);                \
-    else hipLaunchKernelGGL((gru_fwd4_kernel<false, M>), grid, dim3(256), 0, s, p);                     \
+    if (nwv == 12 && M == 3) {                                                                          \
+      if (hsave) hipLaunchKernelGGL((gru_fwd4_kernel<true, 3, 12>), grid, dim3(768), 0, s, p);          \
+      else hipLaunchKernelGGL((gru_fwd4_kernel<false, 3, 12>), grid, dim3(768), 0, s, p);               \
+    } else if (nwv == 8) {                                                                              \
+      if (hsave) hipLaunchKernelGGL((gru_fwd4_kernel<true, M, 8>), grid, dim3(512), 0, s, p);           \
+      else hipLaunchKernelGGL((gru_fwd4_kernel<false, M, 8>), grid, dim3(512), 0, s, p);                \
+    } else {                                                                                            \
+      if (hsave) hipLaunchKernelGGL((gru_fwd4_kernel<true, M, 4>), grid, dim3(256), 0, s, p);           \
+      else hipLaunchKernelGGL((gru_fwd4_kernel<false, M, 4>), grid, dim3(256), 0, s, p);                \
+    }                                                                                                   \
   } while (0)
   switch (mfma_bf16) {
     case 0: DF_FWD4(0); break;
@@ -687,14 +727,21 @@ extern "C" int df_gru_lean_bwd(const float* dflow, const float* offs, const int3
   p.iter_stride = (int64_t)B * N * 128;
   p.plane_stride = p.iter_stride * num_iters;
   p.dh0 = dh0; p.dpre1 = dpre1; p.partial = partial;
-  const dim3 grid((N + 63) / 64, B);
+  static const int nwv = gru_waves();
+  const dim3 grid((N + 16 * nwv - 1) / (16 * nwv), B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DF_BWD4(M)                                                                                      \
+  do {                                                                                                  \
+    if (nwv == 8) hipLaunchKernelGGL((gru_bwd4_kernel<M, 8>), grid, dim3(512), 0, s, p);                \
+    else hipLaunchKernelGGL((gru_bwd4_kernel<M, 4>), grid, dim3(256), 0, s, p);                         \
+  } while (0)
   switch (mfma_bf16) {
-    case 0: hipLaunchKernelGGL(gru_bwd4_kernel<0>, grid, dim3(256), 0, s, p); break;
-    case 1: hipLaunchKernelGGL(gru_bwd4_kernel<1>, grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL(gru_bwd4_kernel<2>, grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(gru_bwd4_kernel<3>, grid, dim3(256), 0, s, p); break;
+    case 0: DF_BWD4(0); break;
+    case 1: DF_BWD4(1); break;
+    case 2: DF_BWD4(2); break;
+    default: DF_BWD4(3); break;
   }
+#undef DF_BWD4
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

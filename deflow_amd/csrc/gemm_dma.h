@@ -56,25 +56,27 @@ __device__ __forceinline__ float buf_ld1_bf16(rsrc_t r, unsigned voff) {
 
 // 32-deep k chunk `chunk` of ROWS weight rows (LDW floats apart) -> LDS buffer, all four waves cooperating: one DMA
 // instruction moves 8 rows x 128 B, wave w takes row groups w, w + 4, ...  voff = WStream::voff<LDW>.
-template <int ROWS, int LDW>
+// NWV = waves of the workgroup sharing the weight stream (4; 8 in the lean decoder's 128-point form, round 6)
+template <int ROWS, int LDW, int NWV = 4>
 __device__ __forceinline__ void dma_chunk(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
   const rsrc_t r = make_rsrc(W, 0x7fffffffu);
 #pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
-                                             (unsigned)((i * 32 * LDW + chunk * 32) * 4), 0, 0);
+  for (int i = 0; i < (ROWS + 8 * NWV - 1) / (8 * NWV); ++i)
+    if (NWV == 4 || wave * 8 + 8 * NWV * i < ROWS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + NWV * i) * 256), 16, voff,
+                                               (unsigned)((i * 8 * NWV * LDW + chunk * 32) * 4), 0, 0);
 }
 
 // The same for PRE-CAST bf16 weights (W points at bf16 data, LDW in elements): a row of the chunk is 64 B, one DMA instruction
 // moves 16 rows, the four waves cover 64 rows per pass.  voff = WStream::voff16<LDW>.
-template <int ROWS, int LDW>
+template <int ROWS, int LDW, int NWV = 4>
 __device__ __forceinline__ void dma_chunk16(const float* __restrict__ W, int chunk, float* Bbuf, int wave, unsigned voff) {
   const rsrc_t r = make_rsrc(W, 0x7fffffffu);
 #pragma unroll
-  for (int i = 0; i < (ROWS + 63) / 64; ++i)
-    if (wave * 16 + 64 * i < ROWS)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + 4 * i) * 256), 16, voff,
-                                               (unsigned)((i * 64 * LDW + chunk * 32) * 2), 0, 0);
+  for (int i = 0; i < (ROWS + 16 * NWV - 1) / (16 * NWV); ++i)
+    if (wave * 16 + 16 * NWV * i < ROWS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(Bbuf + (wave + NWV * i) * 256), 16, voff,
+                                               (unsigned)((i * 16 * NWV * LDW + chunk * 32) * 2), 0, 0);
 }
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -102,8 +104,9 @@ __device__ __forceinline__ bf16x8_t pack_bf16(const f32x4 lo, const f32x4 hi) {
 // has the fp32 exponent range.  The weights arrive pre-split per optimizer step as rows of [hi (LDW) | lo (LDW)] bf16 -- the
 // byte pitch of the fp32 row, so ROW offsets in floats are those of the fp32 layout and COLUMN offsets halve -- and go to LDS as
 // two 8 KB tiles per chunk (one weight buffer, exactly); the A operand is split in registers once per chunk.
-template <int MODE>
+template <int MODE, int NWV_ = 4>
 struct WStreamT {   // the weight-chunk pipeline state shared by consecutive GEMMs
+  static constexpr int NWV = NWV_;
   static constexpr bool BF = MODE != 0;
   static constexpr bool W16 = MODE >= 2;
   static constexpr bool X2 = MODE == 3;
@@ -127,15 +130,15 @@ using WStream = WStreamT<0>;
 template <int ROWS, int LDW, class WS>
 __device__ __forceinline__ void dma_chunk_x2(const float* __restrict__ W, int chunk, float* Bbuf, const WS& ws) {
   static_assert(ROWS <= 128, "two 8 KB plane tiles per weight buffer");
-  dma_chunk16<ROWS, 2 * LDW>(W, chunk, Bbuf, ws.wave, ws.template voff16<2 * LDW>());
-  dma_chunk16<ROWS, 2 * LDW>(W + LDW / 2, chunk, Bbuf + BT / 2, ws.wave, ws.template voff16<2 * LDW>());
+  dma_chunk16<ROWS, 2 * LDW, WS::NWV>(W, chunk, Bbuf, ws.wave, ws.template voff16<2 * LDW>());
+  dma_chunk16<ROWS, 2 * LDW, WS::NWV>(W + LDW / 2, chunk, Bbuf + BT / 2, ws.wave, ws.template voff16<2 * LDW>());
 }
 // the first chunk of a kernel's first GEMM, in the stream's mode
 template <int ROWS, int LDW, class WS>
 __device__ __forceinline__ void dma_first(const float* __restrict__ W, int chunk, float* Bbuf, const WS& ws) {
   if constexpr (WS::X2) dma_chunk_x2<ROWS, LDW>(W, chunk, Bbuf, ws);
-  else if constexpr (WS::W16) dma_chunk16<ROWS, LDW>(W, chunk, Bbuf, ws.wave, ws.template voff16<LDW>());
-  else dma_chunk<ROWS, LDW>(W, chunk, Bbuf, ws.wave, ws.template voff<LDW>());
+  else if constexpr (WS::W16) dma_chunk16<ROWS, LDW, WS::NWV>(W, chunk, Bbuf, ws.wave, ws.template voff16<LDW>());
+  else dma_chunk<ROWS, LDW, WS::NWV>(W, chunk, Bbuf, ws.wave, ws.template voff<LDW>());
 }
 
 // acc[t] += A[16, 32 NCH] * W[ROWS, chunks c0 .. c0 + NCH)^T.  A fragments: LDS (a_lane, chunk c at +32 c) or the x
@@ -176,8 +179,8 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
       return;
     }
     if constexpr (WS::W16) {
-      if (c + 1 < NCH) dma_chunk16<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff16<LDW>());
-      else if (Wn) dma_chunk16<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff16<LDW_NEXT>());
+      if (c + 1 < NCH) dma_chunk16<ROWS, LDW, WS::NWV>(W, c0 + c + 1, nb, ws.wave, ws.template voff16<LDW>());
+      else if (Wn) dma_chunk16<ROWS_NEXT, LDW_NEXT, WS::NWV>(Wn, cn, nb, ws.wave, ws.template voff16<LDW_NEXT>());
       const float* bb = ws.b_lane16 + ((ws.par + c) & 1) * BT;
       const bf16x8_t a8 = pack_bf16(a0, a1);
 #pragma unroll
@@ -187,8 +190,8 @@ __device__ __forceinline__ void gemm(const float* __restrict__ W, int c0, const 
       __syncthreads();
       return;
     }
-    if (c + 1 < NCH) dma_chunk<ROWS, LDW>(W, c0 + c + 1, nb, ws.wave, ws.template voff<LDW>());
-    else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT>(Wn, cn, nb, ws.wave, ws.template voff<LDW_NEXT>());
+    if (c + 1 < NCH) dma_chunk<ROWS, LDW, WS::NWV>(W, c0 + c + 1, nb, ws.wave, ws.template voff<LDW>());
+    else if (Wn) dma_chunk<ROWS_NEXT, LDW_NEXT, WS::NWV>(Wn, cn, nb, ws.wave, ws.template voff<LDW_NEXT>());
     const float* bb = ws.b_lane + ((ws.par + c) & 1) * BT;
     if constexpr (WS::BF) {
       const bf16x8_t a8 = pack_bf16(a0, a1);

@@ -33,9 +33,16 @@ from .h5scene import H5File
 
 
 class HDF5Dataset:
-    def __init__(self, directory: str, max_open_files: int = 8):
+    def __init__(self, directory: str, max_open_files: int = 8, eval: bool = False):
+        """``eval=True`` (the evaluation entry): read ``index_eval.pkl`` -- the frames of the official validation benchmark, the ones
+        that carry an ``eval_mask`` -- when the directory has one, as upstream's dataset does for ``av2_mode=val`` (recalled: the
+        module is in the absent submodule); ``index_total.pkl`` lists every sweep of every scene."""
         self.directory = directory
-        with open(os.path.join(directory, "index_total.pkl"), "rb") as f:
+        name = "index_total.pkl"
+        if eval and os.path.exists(os.path.join(directory, "index_eval.pkl")):
+            name = "index_eval.pkl"
+        self.index_file = name
+        with open(os.path.join(directory, name), "rb") as f:
             self.data_index: List[Sequence] = [list(e) for e in pickle.load(f)]
         self._files: "OrderedDict[str, H5File]" = OrderedDict()
         self._lock = threading.Lock()
@@ -108,8 +115,13 @@ def collate_fn_pad(batch: List[Dict[str, object]]) -> Dict[str, object]:
         res["flow_category_indices"] = _pad([b["flow_category_indices"][k] for b, k in zip(batch, keep0)], 0)
     if "ego_motion" in batch[0]:
         res["ego_motion"] = torch.stack([b["ego_motion"].float() for b in batch])
-    if "eval_mask" in batch[0]:
-        res["eval_mask"] = _pad([b["eval_mask"][k] for b, k in zip(batch, keep0)], False)
+    if any("eval_mask" in b for b in batch):
+        # per SAMPLE: upstream's preprocessing writes the mask on the official evaluation frames only, so a batch of the
+        # validation split mixes frames with and without one.  A frame without a mask gets an all-True one (every valid point
+        # counts) and has_eval_mask = False, which lets the evaluation skip it where the benchmark would.
+        res["eval_mask"] = _pad([(b["eval_mask"][k] if "eval_mask" in b else torch.ones(int(k.sum()), dtype=torch.bool))
+                                 for b, k in zip(batch, keep0)], False)
+        res["has_eval_mask"] = torch.tensor(["eval_mask" in b for b in batch], dtype=torch.bool)
     return res
 
 

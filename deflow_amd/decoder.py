@@ -166,7 +166,11 @@ class ConvGRUDecoder(nn.Module):
         W, keep = self._weights()
         bf = bool(ops.MFMA_BF16) and not os.environ.get("DF_GRU_V1")   # (the first-generation kernels are fp32 only)
         x2 = (not bf) and self._x2_on()
-        xtab = self._xtab(W) if self._lean_on() else None
+        # (the lean weight-gradient pass addresses a plane with 32-bit byte offsets: B * N * 512 < 2^31, ~4.19 M rows.  Beyond that a
+        #  SAVING forward takes the round-4 kernels, whose backward has the generic fallback -- not a DF_E_SHAPE in the backward after
+        #  the forward has kept only the lean planes)
+        lean = self._lean_on() and not (save and B * N * 512 >= (1 << 31))
+        xtab = self._xtab(W) if lean else None
         if bf:
             W, keep = self._weights16(W, keep)
         elif x2:

@@ -9,6 +9,7 @@ valid-point counts) happens per forward, after every kernel has been queued.
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 from typing import Dict, Optional
 
@@ -44,6 +45,63 @@ def cal_pose0to1(pose0: torch.Tensor, pose1: torch.Tensor, form: Optional[str] =
 
 
 _CANVASES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> {shape key: (canvas, occupancy words)}: persistent canvases
+# ... and who used an entry last: {"stream", "event" (recorded behind the forward's last reader; None under capture), "captured", "tick"}.
+# A persistent canvas is ONE buffer per (model, shape): two forwards of a model that may overlap on the GPU -- another stream, a second host
+# thread driving its own stream -- must not share it.  A forward takes the entry only on the stream that used it last, or once that
+# use has finished (event.query()); otherwise it falls back to a fresh dense canvas, as every forward did before round 5.  Entries
+# whose address a HIP graph may hold (created or used under capture) are never evicted, nothing is evicted during a capture, and
+# eviction removes the least recently used entry -- not the whole store.
+_CANVAS_META: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_CANVAS_LOCK = threading.Lock()
+_CANVAS_MAX = 4          # a handful of shapes at most (train / eval batch sizes)
+
+
+def _canvas_take(model, key, make):
+    """-> (canvas, occs) of the persistent entry for `key`, or None when the entry is busy elsewhere (the caller then writes a dense canvas)"""
+    stream = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
+    with _CANVAS_LOCK:
+        store = _CANVASES.setdefault(model, {})    # (outside the module's __dict__: deepcopy / pickling must not drag 1 GB buffers along)
+        meta = _CANVAS_META.setdefault(model, {})
+        ent, m = store.get(key), meta.get(key)
+        if ent is None:
+            if len(store) >= _CANVAS_MAX and not capturing:
+                free = [k for k in store if not meta[k]["captured"] and (meta[k]["event"] is None or meta[k]["event"].query())]
+                if free:
+                    old = min(free, key=lambda k: meta[k]["tick"])
+                    del store[old], meta[old]
+            ent = store[key] = make()
+            m = meta[key] = {"stream": stream, "event": None, "captured": capturing, "tick": 0, "busy": False, "owner": 0}
+        else:
+            same = m["stream"] == stream
+            if m["busy"] and m["owner"] != threading.get_ident():
+                return None                         # another host thread is inside a forward (or a trainer step) on this entry
+            if not same:
+                ev = m["event"]
+                if capturing:
+                    pass                            # (the capturer ordered its stream behind the earlier work: cap_stream.wait_stream(...))
+                elif m["captured"] or (ev is not None and not ev.query()):
+                    return None                     # in flight on another stream, or frozen into a graph that replays elsewhere
+                m["stream"] = stream
+            m["captured"] = m["captured"] or capturing
+        m["busy"] = True
+        m["owner"] = threading.get_ident()
+        m["tick"] = max((x["tick"] for x in meta.values()), default=0) + 1
+        return ent
+
+
+def _canvas_release(model, key):
+    with _CANVAS_LOCK:
+        m = _CANVAS_META.get(model, {}).get(key)
+        if m is None:
+            return
+        m["busy"] = False
+        if torch.cuda.is_current_stream_capturing():
+            m["event"] = None
+        else:
+            if m["event"] is None:
+                m["event"] = torch.cuda.Event()
+            m["event"].record(torch.cuda.current_stream())
 
 
 class DeFlow(nn.Module):
@@ -70,7 +128,9 @@ class DeFlow(nn.Module):
         ckpt = load_checkpoint(ckpt_path)["state_dict"]
         state_dict = {k[len("model."):]: v for k, v in ckpt.items() if k.startswith("model.")}
         print("\nLoading... model weight from: ", ckpt_path, "\n")
-        return self.load_state_dict(state_dict=state_dict, strict=False)
+        res = self.load_state_dict(state_dict=state_dict, strict=False)
+        ops.invalidate_weight_caches()      # (load_state_dict bumps the version counters the caches check; belt and braces)
+        return res
 
     # ------------------------------------------------------------------------------------------------
     def _run(self, pc0s: torch.Tensor, pc1s: torch.Tensor, train: bool, save: bool):
@@ -79,6 +139,16 @@ class DeFlow(nn.Module):
             return self._run_impl(pc0s, pc1s, train, save)
 
     def _run_impl(self, pc0s: torch.Tensor, pc1s: torch.Tensor, train: bool, save: bool):
+        ckey = [None]
+        try:
+            return self._run_canvas(pc0s, pc1s, train, save, ckey)
+        finally:
+            if ckey[0] is not None and not save:
+                # a no-grad forward is done with the canvas when its decoder has been queued.  (The trainer's step keeps reading it
+                # in the backward: optim.Trainer steps one stream, one thread -- its entry is never offered to anybody else.)
+                _canvas_release(self, ckey[0])
+
+    def _run_canvas(self, pc0s: torch.Tensor, pc1s: torch.Tensor, train: bool, save: bool, ckey_out: list):
         emb = self.embedder
         B = pc0s.shape[0]
         dev = pc0s.device
@@ -89,15 +159,15 @@ class DeFlow(nn.Module):
         # be alive) get a fresh, fully written buffer as before.  DF_CANVAS_PERSIST=0: always the dense form.
         persist = ((not save) or getattr(self, "_persist_canvas", False)) and os.environ.get("DF_CANVAS_PERSIST", "1") != "0"
         occs = (None, None)
+        ckey = None
         if persist:
-            key = (B, emb.H, emb.W, str(dev), merged, emb.bands(2 * B if merged else B))
-            store = _CANVASES.setdefault(self, {})    # (outside the module's __dict__: deepcopy / pickling must not drag 1 GB buffers along)
-            pc = store.get(key)
-            if pc is None:
-                if len(store) >= 4:          # a handful of shapes at most (train / eval batch sizes)
-                    store.clear()
-                pc = store[key] = (torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev),
-                                            (emb.occ_alloc(2 * B, dev), None) if merged else (emb.occ_alloc(B, dev), emb.occ_alloc(B, dev)))
+            ckey = (B, emb.H, emb.W, str(dev), merged, emb.bands(2 * B if merged else B))
+            pc = _canvas_take(self, ckey, lambda: (torch.zeros(B, emb.H, emb.W, 64, dtype=torch.float32, device=dev),
+                                                   (emb.occ_alloc(2 * B, dev), None) if merged else (emb.occ_alloc(B, dev), emb.occ_alloc(B, dev))))
+            if pc is None:       # the entry is in use on another stream / by another thread: this forward writes its own dense canvas
+                persist, ckey = False, None
+            ckey_out[0] = ckey
+        if persist:
             bstar, occs = pc
             ops.wrote(bstar)      # (whatever max |x| record the previous forward's consumers left on the tensor is void)
         else:

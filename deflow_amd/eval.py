@@ -71,7 +71,7 @@ def main(argv=None):
     B = int(cfg["batch_size"])
     if cfg["val_data"] != "synthetic":
         from .data import HDF5Dataset, SceneLoader, ShardedSampler
-        ds = HDF5Dataset(str(cfg["val_data"]))
+        ds = HDF5Dataset(str(cfg["val_data"]), eval=True)      # index_eval.pkl (the benchmark's frames) when the directory has one
         batches = SceneLoader(ds, B, ShardedSampler(len(ds), shuffle=False), device=dev,
                               num_workers=max(0, int(cfg["num_workers"])), drop_last=False)
     else:

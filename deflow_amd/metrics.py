@@ -182,7 +182,13 @@ def evaluate_batch(res: dict, batch: dict, official: Optional[OfficialMetrics] =
     ``flow_is_valid`` (points without a usable label are left out), ``flow_category_indices`` (0 = no annotation) and, for the
     official validation split, ``eval_mask`` (the benchmark's point mask)."""
     acc: Dict[str, list] = {}
+    # frames WITHOUT the benchmark's mask in a batch where other frames carry one (``has_eval_mask`` from the collate function) are not
+    # official evaluation frames: they are left out, as an evaluation over upstream's index_eval.pkl never sees them
+    has = batch.get("has_eval_mask")
+    skip = (~has.bool()).tolist() if has is not None and bool(has.any()) else None
     for b in range(len(res["flow"])):
+        if skip is not None and skip[b]:
+            continue
         vi = res["pc0_valid_point_idxes"][b]
         pf = res["pose_flow"][b][vi]
         est, gt = pf + res["flow"][b].detach(), batch["flow"][b][vi]

@@ -685,6 +685,17 @@ PARAM_GEN = [0]
 WEIGHT_GEN = [0]
 
 
+def invalidate_weight_caches() -> None:
+    """Void every per-tensor weight cache (fp16 planes, transposes, OHWI copies) and every folded BatchNorm.  The caches are validated by
+    (tensor._version, WEIGHT_GEN): writers that go through autograd's version counters -- optimizer.step() in eager PyTorch,
+    load_state_dict, parameter.copy_() -- need nothing.  Writers that BYPASS the counters must call this (or bump the generations) after
+    they write: a user-captured CUDA-graph replay of a torch optimizer step, raw-pointer writes into the parameter arena, another
+    library updating the weights in place.  FlatAdam.step / step_captured and the trainer's graph replay do it themselves;
+    load_from_checkpoint calls it for good measure."""
+    WEIGHT_GEN[0] += 1
+    PARAM_GEN[0] += 1
+
+
 def folded_bn(bn) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     key = (PARAM_GEN[0], bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.running_var.data_ptr(), bn.eps)

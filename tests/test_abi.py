@@ -88,26 +88,30 @@ def test_entry_points_reject_bad_arguments_without_launching(lib_path):
     assert lib.df_conv2d_wgrad(bad, ok64, 3, 1, 1, P(0), 1, P(0), 0, P(0), P(0)) < 0
 
 
-def test_counted_vmcnt_kernels_do_not_spill():
-    """kernels that keep LDS-DMA in flight across barriers order it with COUNTED s_waitcnt vmcnt(n); a register spill would add
-    scratch loads/stores (VMEM operations on the same counter) and silently break the count -- the compiler must report no
-    scratch for them"""
-    import re
+def test_counted_vmcnt_kernels_have_no_scratch_traffic_in_their_loops():
+    """kernels that keep LDS-DMA in flight across barriers order it with COUNTED s_waitcnt vmcnt(n).  A register spill reloaded inside
+    such a loop is a VMEM operation on the same counter, and the compiler follows it with s_waitcnt vmcnt(0): the prefetched ring is
+    drained once per stage (round 6 found that in the dominant weight-gradient kernel -- correct, and its four-deep ring worth nothing).
+    The compiled ISA of these kernels must have no scratch instruction inside any loop (spills in the prologue / epilogue are harmless);
+    tools/scan_scratch_in_loops.py does the scan."""
     import shutil
     import subprocess
+    import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from scan_scratch_in_loops import scan
     src = os.path.join(ROOT, "deflow_amd", "csrc")
-    for fname, kernels in (("conv_bf16.hip", ["conv64_roll_bf16_kernel"]), ("decoder_wgrad.hip", ["gru_wgrad_kernel"]),
-                           ("conv_wgrad.hip", ["wgrad3_tr_kernel", "wgrad3_h2p_kernel"])):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result", "-c",
-                            os.path.join(src, fname), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"],
-                           capture_output=True, text=True, timeout=600)
+    # (the exit block of wgrad3_h2p's loop holds one reload the scanner's backward-branch test counts as "in a loop": allowed as 1)
+    for fname, kernels in (("conv_bf16.hip", {"conv64_roll_bf16_kernel": 0}), ("decoder_wgrad.hip", {"gru_wgrad_kernel": 0, "gru_wgrad4_kernel": 0}),
+                           ("conv_wgrad.hip", {"wgrad3_tr_kernel": 0, "wgrad3_h2p_kernelILi4ELb1": 1})):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result", "-S",
+                            os.path.join(src, fname), "-o", "-", "--cuda-device-only"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
-        blocks = re.split(r"remark: Function Name: ", r.stderr)
-        for k in kernels:
-            blk = next(b for b in blocks if k in b.split("\n", 1)[0])
-            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
-            spills = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
-            assert scratch == 0 and spills == 0, (k, scratch, spills)
+        found = scan(r.stdout)
+        for k, allowed in kernels.items():
+            hits = {name: v for name, v in found.items() if k in name}
+            assert hits, (fname, k)
+            for name, (n_in, tot) in hits.items():
+                assert n_in <= allowed, (name, n_in, tot)

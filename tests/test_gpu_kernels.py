@@ -612,7 +612,7 @@ def test_gru_decoder_golden(dev, golden_dir, iters, form, monkeypatch):
     infos = [{"voxel_coords": t(g[f"vc{i}"]), "point_offsets": t(g[f"off{i}"])} for i in range(3)]
     flows = m(before, after, infos)
     assert [f.shape[0] for f in flows] == [333, 0, 1]
-    tag = f"gru_golden_it{iters}" + ("" if form == "lean_ws" else "_" + form)
+    tag = f"gru_golden_it{iters}_{form}"
     for i in (0, 2):
         parity.three_way(tag, f"flow{i}", flows[i], t(g[f"flow{i}"]), t(g64[f"flow{i}"]))
     loss = sum((f * t(g[f"gflow{i}"]).to(dev)).sum() for i, f in enumerate(flows))

@@ -1638,6 +1638,25 @@ def test_bench_line_contract(dev):
     assert "cpu_baseline" not in d   # --no-cpu-baseline
 
 
+def test_bench_hung_extra_leg_still_prints_the_headline(dev):
+    """at N > 1 every extra leg behind the timed region runs under a wall-clock budget; a leg that hangs (test hook:
+    the one-bucket leg sleeps forever on both ranks) ends the run with the HEADLINE line, `extras_aborted` naming the leg -- not with
+    the driver's timeout and no line at all."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DF_BENCH_SHARE_GPU="1", DF_BENCH_TEST_HANG="one_bucket", DF_BENCH_LEG_BUDGET="20")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"],
+                       capture_output=True, text=True, cwd=root, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads(lines[0])
+    import bench as _bench
+    assert d["metric"] == _bench.METRIC and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["workload"] == _bench.WORKLOAD
+    assert d["extras_aborted"]["leg"] == "one_bucket" and "allreduce_buckets" in d["extras_aborted"]["legs_completed"]
+
+
 def test_bench_two_ranks_share_the_gpu(dev):
     """`python bench.py --gpus 2` started bare -- the way the driver starts it -- with the real kernels: the file launches its own
     two ranks, both on this box's one GPU with gloo carrying the collectives (DF_BENCH_SHARE_GPU test hook; RCCL refuses two ranks

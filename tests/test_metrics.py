@@ -164,3 +164,63 @@ def test_evaluate_batch_feeds_the_official_tables():
     _same(ref.result(1), om.result(1), 1e-9)
     _same(ref.result(2), om.result(2), 1e-9)
     assert m["n"] == int((valid & em)[k].sum())
+
+
+def test_mixed_eval_mask_batch_scores_only_the_benchmark_frames(tmp_path):
+    """upstream writes ``eval_mask`` on the official evaluation frames only, so a validation batch mixes frames with and
+    without one.  collate_fn_pad handles the mask per SAMPLE (no KeyError whichever frame comes first, no silently ignored masks);
+    evaluate_batch leaves the frames without a mask out of the tables; HDF5Dataset(eval=True) prefers index_eval.pkl."""
+    import pickle
+    from deflow_amd.data import HDF5Dataset, collate_fn_pad
+    from deflow_amd.metrics import OfficialMetrics, evaluate_batch
+    rng = np.random.default_rng(11)
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.asarray(a)).to(dt)
+
+    def item(n, with_mask):
+        est, rigid, pc0, gt, valid, cats = _frame(rng, n)
+        it = {"scene_id": "s", "timestamp": 0, "pc0": t(pc0), "gm0": torch.zeros(n, dtype=torch.bool), "pose0": torch.eye(4),
+              "pc1": t(pc0), "gm1": torch.zeros(n, dtype=torch.bool), "pose1": torch.eye(4), "flow": t(gt),
+              "flow_is_valid": t(valid, torch.bool), "flow_category_indices": t(cats, torch.uint8)}
+        it["gm0"][::7] = True                                      # a few ground points: the mask is cut like every per-point field
+        if with_mask:
+            it["eval_mask"] = t(rng.random(n) < 0.7, torch.bool)
+        return it, est, rigid
+
+    items = [item(90, False), item(120, True), item(60, False)]
+    for order in ([0, 1, 2], [1, 0, 2]):                            # the frame WITHOUT a mask first, and the frame with one first
+        batch = collate_fn_pad([items[i][0] for i in order])
+        assert batch["has_eval_mask"].tolist() == [items[i][0].get("eval_mask") is not None for i in order]
+        assert batch["eval_mask"].shape == batch["flow_is_valid"].shape
+        for row, i in enumerate(order):
+            it = items[i][0]
+            keep = ~it["gm0"]
+            want = it["eval_mask"][keep] if "eval_mask" in it else torch.ones(int(keep.sum()), dtype=torch.bool)
+            assert torch.equal(batch["eval_mask"][row, : int(keep.sum())], want)
+            assert not batch["eval_mask"][row, int(keep.sum()):].any()
+        # a "model result" that keeps every non-padding point
+        res = {"flow": [], "pc0_valid_point_idxes": [], "pose_flow": []}
+        for row, i in enumerate(order):
+            it, est, rigid = items[i]
+            keep = ~it["gm0"]
+            n = int(keep.sum())
+            res["pc0_valid_point_idxes"].append(torch.arange(n))
+            pf = torch.zeros(batch["pc0"].shape[1], 3)
+            pf[:n] = t(rigid)[keep]
+            res["pose_flow"].append(pf)
+            res["flow"].append((t(est) - t(rigid))[keep])
+        om_all, om_one = OfficialMetrics(), OfficialMetrics()
+        evaluate_batch(res, batch, om_all)
+        row1 = order.index(1)
+        one = {k: (v[row1:row1 + 1] if isinstance(v, torch.Tensor) else [v[row1]]) for k, v in batch.items()}
+        res1 = {k: [v[row1]] for k, v in res.items()}
+        evaluate_batch(res1, one, om_one)
+        _same(om_one.result(1), om_all.result(1), 0.0)              # only the frame with the mask was scored
+        _same(om_one.result(2), om_all.result(2), 0.0)
+    # a batch in which NO frame has a mask scores every frame (a split without the benchmark's masks)
+    b2 = collate_fn_pad([items[0][0], items[2][0]])
+    assert "eval_mask" not in b2 and "has_eval_mask" not in b2
+    # index_eval.pkl wins under eval=True
+    pickle.dump([["s", 1], ["s", 2], ["s", 3]], open(tmp_path / "index_total.pkl", "wb"))
+    pickle.dump([["s", 2]], open(tmp_path / "index_eval.pkl", "wb"))
+    assert len(HDF5Dataset(str(tmp_path))) == 3 and len(HDF5Dataset(str(tmp_path), eval=True)) == 1
+    assert HDF5Dataset(str(tmp_path), eval=True).index_file == "index_eval.pkl"
