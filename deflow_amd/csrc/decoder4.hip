@@ -394,13 +394,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void gru_bwd4_kernel(GruBwd4Params p) 
 
   // S_g of the three gates: column sums of the gate-gradient plane sitting in the A region, plain and weighted with the rows'
   // offsets (lane j owns columns j and j + 64)
+  // Eight-wave form (round 6): five of the six S accumulators (z, r: both column halves; q: the first) live in wave-private LDS
+  // ([gate][column half][lane] float4, 5 KB per wave: the one-workgroup-per-CU form has the room for exactly that) instead of 20 of
+  // the 24 registers -- at 256 registers the four-wave form spills 16 and
+  // reloads them inside the iteration loop (20 scratch instructions per iteration, each reload behind an s_waitcnt vmcnt(0) that
+  // also drains the weight DMA in flight).
+  constexpr bool SG_LDS = NWV == 8;
+  __shared__ __attribute__((aligned(16))) float SgL[SG_LDS ? NWV * 5 * 64 * 4 : 4];
+  float* sgl = SgL + (SG_LDS ? wave * (5 * 64 * 4) : 0);
   float sg[3][2][4];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) sg[g][c][d] = 0.f;
+      if (SG_LDS && g * 2 + c < 5) st4(sgl + ((g * 2 + c) * 64 + lane) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
   auto colsum = [&](int g) {
     float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 4   // (fully unrolled the scheduler hoists all 48 LDS reads: 96 registers on top of four live planes)
@@ -416,9 +426,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void gru_bwd4_kernel(GruBwd4Params p) 
       s[1][3] += v1;
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 2; ++c) {
+      if (SG_LDS && g * 2 + c < 5) {
+        float* q_ = sgl + ((g * 2 + c) * 64 + lane) * 4;
+        const f32x4 o = ld4(q_);
+        st4(q_, f32x4{o[0] + s[c][0], o[1] + s[c][1], o[2] + s[c][2], o[3] + s[c][3]});
+      } else {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) sg[g][c][d] += s[c][d];
+        for (int d = 0; d < 4; ++d) sg[g][c][d] += s[c][d];
+      }
+    }
   };
 
   // ---- MLP head backward -------------------------------------------------------------------------------------------
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void gru_bwd4_kernel(GruBwd4Params p) 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        st4(rw + (g * 128 + c * 64 + lane) * 4, f32x4{sg[g][c][0], sg[g][c][1], sg[g][c][2], sg[g][c][3]});
+        st4(rw + (g * 128 + c * 64 + lane) * 4, (SG_LDS && g * 2 + c < 5) ? ld4(sgl + ((g * 2 + c) * 64 + lane) * 4) : f32x4{sg[g][c][0], sg[g][c][1], sg[g][c][2], sg[g][c][3]});
     const float* sm = Small + wave * SMALL_W;
     if (lane < 32) st4(rw + (384 + lane) * 4, f32x4{sm[132 + lane], sm[164 + lane], sm[196 + lane], sm[96 + lane]});
     for (int o = lane; o < 96; o += 64) rw[1664 + o] = sm[o];
@@ -640,12 +657,13 @@ __global__ __launch_bounds__(256) void gru_lean_finalize_kernel(FinParams p) {
 }
 
 // Waves per workgroup of the lean kernels (round 6; same arithmetic per point in every form, bit-identical results):
-//   backward: DF_GRU_WAVES = 4 (default: 64 points, two workgroups per CU) | 8 (128 points, one per CU -- measured equal: 5.45 vs 5.48 ms)
+//   backward: DF_GRU_WAVES = 8 (default: 128 points, one workgroup per CU, five of the six S accumulators in LDS: no scratch traffic
+//             in the iteration loop -- 5.26 vs 5.60 ms) | 4 (64 points, two workgroups per CU: rounds 3-5; 20 scratch instructions per iteration)
 //   forward:  DF_GRU_FWD_WAVES = 12 (default in bf16x2 mode: 192 points, THREE waves per SIMD at 168 registers -- 2.50 vs 2.72 ms,
 //             tools/bench_gru_lean.py) | 8 | 4
 int gru_waves() {
   const char* e = getenv("DF_GRU_WAVES");
-  return (e && atoi(e) == 8) ? 8 : 4;
+  return (e && atoi(e) == 4) ? 4 : 8;
 }
 
 bool img64_ok4(const df_img& d, int B) {

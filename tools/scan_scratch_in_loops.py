@@ -22,23 +22,17 @@ def scan(text: str) -> dict:
         m = re.match(r"(_Z\w+):", part)
         if not m:
             continue
-        lines = part.split("\n")
-        labels = {}
-        for i, l in enumerate(lines):
-            mm = re.match(r"^(\.LBB\d+_\d+):", l)
-            if mm:
-                labels[mm.group(1)] = i
-        loops = []
-        for i, l in enumerate(lines):
-            mm = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
-            if mm and mm.group(1) in labels and labels[mm.group(1)] <= i:      # a backward branch closes a loop
-                loops.append((labels[mm.group(1)], i))
+        # LLVM's asm printer annotates every basic block that lies in a loop: the header ("; =>This Inner Loop Header: Depth=1") and the
+        # others ("; in Loop: Header=BB3_7 Depth=1"), on label lines (".LBB3_9: ; in Loop ...") and on fall-through block comments
+        # ("; %bb.12: ; in Loop ...").  A scratch instruction is in a loop iff its block is.
+        in_loop = False
         n_in = tot = 0
-        for i, l in enumerate(lines):
-            if re.match(r"^\s+scratch_", l):
+        for l in part.split("\n"):
+            if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+                in_loop = "Loop" in l
+            elif re.match(r"^\s+scratch_", l):
                 tot += 1
-                if any(a <= i <= b for a, b in loops):
-                    n_in += 1
+                n_in += in_loop
         out[m.group(1)] = (n_in, tot)
     return out
 
