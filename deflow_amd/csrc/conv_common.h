@@ -115,7 +115,10 @@ inline bool img_ok(const df_img& d, bool any16 = false) {
 // BWS (compile time; only the pre-split-input 3x3 data-gradient instances carry it): the DF_EPI_BWD_STATS epilogue -- every other
 // instance keeps the round-3 epilogue byte for byte (a run-time branch here cost the dominant kernels ~5 %: more scalar registers
 // live across the main loop)
-template <int BM, int BN, int WM, int WN, bool BWS = false>
+// PRE (round 6; conv_halo_x3p_kernel): acc already holds t = (y + bias) s, s = the plane output's scale (1 for an fp32 output): no bias
+// add and no scaling here; the statistics and the maximum are taken of t and scaled back by 1 / s once per channel (a power of two
+// commutes with every rounding of the sums -- bit-identical to the plain form)
+template <int BM, int BN, int WM, int WN, bool BWS = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* lds,
                                               const RowDecode& dec, int m0, int m_end, int n0, int tile_m, int tid_in = -1) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -175,8 +178,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       constexpr int ESZ = Y16 ? 2 : 4;
       float sy = 1.f;
       if constexpr (YH2) sy = df_h2_scale(*p.bound_y);
+      // PRE: a row's byte offset (with the lane's part folded in) is formed ONCE per (row tile, element) instead of once per column tile
+      // too; the column tile's part rides in the buffer instruction's scalar offset
+      unsigned rbase[PRE ? TM : 1][16];
+      if constexpr (PRE) {
+        const unsigned lane_b = YH2 ? (unsigned)((li & 1) * 64 + (li >> 1) * 4) : (unsigned)(li * ESZ);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+            rbase[i][e] = (FULL || off >= 0) ? (unsigned)(off * ESZ) + lane_b : ROW_BAD;
+          }
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
+        const unsigned soff = PRE ? (unsigned)((n0 + (wn * TN + j) * 32) * ESZ) : 0u;     // (workgroup- and wave-uniform)
         const int co = n0 + (wn * TN + j) * 32 + li;
         const float bia = p.bias ? p.bias[co] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -195,44 +212,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           unsigned ob[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
-            else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
+            if constexpr (PRE) {
+              ob[e] = rbase[i][e];
+            } else {
+              const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+              if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
+              else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
+            }
           }
           float old[16];
           if constexpr (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], 0, 0));
+            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], soff, 0));
           }
           if (p.accumulate) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               if constexpr (Y16)
-                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], 0, 0) << 16);
+                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], soff, 0) << 16);
               else
-                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
+                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], soff, 0));
             }
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            float v = acc[i][j][e] + bia;
-            if (p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
+            float v = PRE ? acc[i][j][e] : acc[i][j][e] + bia;
+            if (!PRE && p.epi == DF_EPI_BN_GELU) v = df_gelu(v * sc + sh);
             if (p.accumulate) v += old[e];
             if constexpr (Y16) {
               const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
-              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], soff, 0);
               v = __builtin_bit_cast(float, (unsigned)h << 16);
             } else if constexpr (YH2) {
-              const float t = v * sy;
+              const float t = PRE ? v : v * sy;
               const _Float16 hi = (_Float16)t;
               const _Float16 lo = (_Float16)((t - (float)hi) * H2_LO);
               const unsigned hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
               const unsigned send = (li & 1) ? hb : lb;                 // odd lanes hand their hi to the even neighbour, even lanes their lo
               const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
               const unsigned word = (li & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], soff, 0);
             } else {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], soff, 0);
             }
             if (FULL || ob[e] != ROW_BAD) {
               if constexpr (bws) {
@@ -248,6 +269,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           }
         }
         if (BWS || p.epi == DF_EPI_STATS) {
+          if constexpr (PRE) {               // sums of t = y s -> sums of y (BWS: s2 = sum g xhat is linear in g, the plain one quadratic)
+            const float isy = 1.f / sy;
+            s1 *= isy;
+            s2 *= BWS ? isy : isy * isy;
+          }
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
           if (kh == 0) {
@@ -257,6 +283,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           }
         }
       }
+      if constexpr (PRE) amax_t *= 1.f / sy;
     };
     const bool full = m0 + BM <= m_end;      // (workgroup-uniform)
     if (full) {

@@ -16,7 +16,7 @@ namespace {
 // and the remaining PD - 1 weight stages of the next tile are issued right after the epilogue -- so that every store is OLDER than
 // every load a counted wait later reasons about (outstanding <= N then bounds the loads among them whatever order stores and loads
 // retire in).  Same arithmetic per tile in the same order: bit-identical to the plain form.
-template <int BM, int BN, int WM, int WN, int SEG, int DB, bool BWS = false, int SCHED = 1>
+template <int BM, int BN, int WM, int WN, int SEG, int DB, bool BWS = false, int SCHED = 1, bool EPI = true>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3p_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NP = 2;
@@ -285,19 +285,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3p_kernel(ConvParams 
     mult(T2{}, gp);
     DF_VMCNT(0);                                        // the next tile's halo group 0 and weight stage 0: nothing else is in flight
     DF_STAGE_END();
-    {   // fold the cross terms in and take the two power-of-two scales out (exact multiplications)
-      const float ix = 1.f / sx, iw = 1.f / sw;
+    // epilogue scratch = the halo buffer the last group just left (the other one is receiving the next tile's group 0)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const float ix = 1.f / sx, iw = 1.f / sw;
+    // EPI (round 6; bit-identical to the plain form): the fold of the cross-term accumulator, the two operand scales, the bias and -- for a
+    // plane output -- the output scale are TWO fused multiply-adds per element here (every factor but the bias is a power of two:
+    // (acc + acc1 / 2048) ix iw + b and fma(fma(acc1, 1 / 2048, acc), ix iw, b) round the same sum once; t = y s likewise as
+    // fma(., ix iw s, b s)), and the shared epilogue takes the values as they are (PRE): five instructions per output element less in a
+    // phase that is VALU-bound and in which no wave of the workgroup issues a product (13 / 22 % of a 256 x 128 / 512 x 64 workgroup's
+    // time, profiles/r06_conv_experiments.txt).  Not for bf16 outputs and the folded BatchNorm + GELU epilogue (inference).
+    if constexpr (EPI) {     // (the launcher picks this instance only for outputs PRE covers; ONE inlined epilogue per instance: two
+                             //  copies cost the K loop hundreds of spill instructions)
+      const float sy = p.y.elt == 2 ? df_h2_scale(*p.bound_y) : 1.f;
+      const float fs = ix * iw * sy;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = tile_n * BN + (wn * TN + j) * 32 + li;
+        const float bs = (p.bias ? p.bias[co] : 0.f) * sy;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(fmaf(acc1[i][j][e], H2_LO_INV, acc[i][j][e]), fs, bs);
+      }
+      conv_epilogue<BM, BN, WM, WN, BWS, true>(p, acc, As + gp * AB, dec, tile_m * BM, p.M, tile_n * BN, tile_m, tid_o);
+    } else {
+      // fold the cross terms in and take the two power-of-two scales out (exact multiplications), then the shared epilogue
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
+      conv_epilogue<BM, BN, WM, WN, BWS>(p, acc, As + gp * AB, dec, tile_m * BM, p.M, tile_n * BN, tile_m, tid_o);
     }
-    // epilogue scratch = the halo buffer the last group just left (the other one is receiving the next tile's group 0)
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
-    conv_epilogue<BM, BN, WM, WN, BWS>(p, acc, As + gp * AB, dec, tile_m * BM, p.M, tile_n * BN, tile_m, tid_o);
     if (!has_next) break;
     DF_STAGE_END();                                     // every wave is done with the scratch before the next halo fetch may overwrite it
 #pragma unroll
@@ -323,14 +344,20 @@ static int launch_conv_halo_x3p(const ConvParams& p, hipStream_t s) {
   // 512 x 64 tiles (five DMA instructions per wave and stage) and loses 2 % on the 256 x 128 ones (three) -- default: 3 for BN = 64.
   static const int sched_env = getenv("DF_X3P_SCHED") ? atoi(getenv("DF_X3P_SCHED")) : -1;
   const int sched = sched_env >= 0 ? sched_env : (BN == 64 ? 3 : 0);
-#define DF_X3P_GO(S)                                                                                                      \
+#define DF_X3P_GO(S, E)                                                                                                   \
   do {                                                                                                                   \
-    DF_SET_LDS_ONCE((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS, S>), (int)lds_bytes);                            \
-    hipLaunchKernelGGL((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS, S>), dim3(grid), dim3(64 * WM * WN), lds_bytes, s, p); \
+    DF_SET_LDS_ONCE((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS, S, E>), (int)lds_bytes);                         \
+    hipLaunchKernelGGL((conv_halo_x3p_kernel<BM, BN, WM, WN, SEG, DB, BWS, S, E>), dim3(grid), dim3(64 * WM * WN), lds_bytes, s, p); \
   } while (0)
-  if (sched == 0) DF_X3P_GO(0);
-  else if (sched == 3) DF_X3P_GO(3);
-  else DF_X3P_GO(1);
+  static const int lean_env = getenv("DF_X3P_EPI") ? atoi(getenv("DF_X3P_EPI")) : 1;      // 0: fold, then the plain shared epilogue (A/B; bit-identical)
+  // the pre-biased / pre-scaled epilogue form covers fp32 and plane outputs with the bias / statistics epilogues (training, every layer
+  // of it); bf16 outputs, the folded BatchNorm + GELU epilogue (inference) and accumulation into planes take the plain instance
+  const bool lean_epi = lean_env && p.y_bytes && p.y.elt != 1 && p.epi != DF_EPI_BN_GELU && !(p.y.elt == 2 && p.accumulate);
+  if (!lean_epi) {
+    if (sched == 3) DF_X3P_GO(3, false);
+    else DF_X3P_GO(0, false);
+  } else if (sched == 3) DF_X3P_GO(3, true);
+  else DF_X3P_GO(0, true);
 #undef DF_X3P_GO
   DF_CHECK_LAUNCH();
   return DF_OK;

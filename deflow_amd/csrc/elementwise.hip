@@ -333,26 +333,47 @@ __global__ __launch_bounds__(256) void bn_gelu_apply8_kernel(const float* __rest
   const int hw = z.h * z.w;
   const int c8s = df_pow2_shift(C8), hws = df_pow2_shift(hw);
   const float zs = df_h2_scale(__builtin_bit_cast(float, *bound));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = df_udiv(i, C8, c8s);
-    const int c = (int)(i - m * C8) * 8;
-    const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
-    const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
-    const f32x4 v0 = ld4(y + m * z.c + c), v1 = ld4(y + m * z.c + c + 4);
-    const f32x4 sc0 = ld4(ss + c), sc1 = ld4(ss + c + 4), sh0 = ld4(ss + z.c + c), sh1 = ld4(ss + z.c + c + 4);
-    f16x8e_t hi, lo;
+  // two element groups per iteration (round 6): four 16-byte loads in flight per thread before the first erf -- the pass ran at
+  // 5.1 TB/s with two (DF_STREAM_UNROLL=1 at build time restores that)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+#ifndef DF_STREAM_UNROLL
+#define DF_STREAM_UNROLL 2
+#endif
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total8; i0 += DF_STREAM_UNROLL * stride) {
+    f32x4 v0[DF_STREAM_UNROLL], v1[DF_STREAM_UNROLL];
+    int64_t mm[DF_STREAM_UNROLL];
+    int cc[DF_STREAM_UNROLL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float t0 = df_gelu(v0[k] * sc0[k] + sh0[k]) * zs, t1 = df_gelu(v1[k] * sc1[k] + sh1[k]) * zs;
-      hi[k] = (_Float16)t0;
-      lo[k] = (_Float16)((t0 - (float)hi[k]) * 2048.f);
-      hi[4 + k] = (_Float16)t1;
-      lo[4 + k] = (_Float16)((t1 - (float)hi[4 + k]) * 2048.f);
+    for (int u = 0; u < DF_STREAM_UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      const int64_t ic = i < total8 ? i : i0;           // (a clamped, repeated load instead of a branch; its result is not stored)
+      mm[u] = df_udiv(ic, C8, c8s);
+      cc[u] = (int)(ic - mm[u] * C8) * 8;
+      v0[u] = ld4(y + mm[u] * z.c + cc[u]);
+      v1[u] = ld4(y + mm[u] * z.c + cc[u] + 4);
     }
-    const int64_t idx = df_img_base(z, n) + (int64_t)pix * z.ld + c;
-    char* b = reinterpret_cast<char*>(z.ptr) + (idx & ~31ll) * 4 + (idx & 31) * 2;
-    *reinterpret_cast<f16x8e_t*>(b) = hi;
-    *reinterpret_cast<f16x8e_t*>(b + 64) = lo;
+#pragma unroll
+    for (int u = 0; u < DF_STREAM_UNROLL; ++u) {
+      if (i0 + u * stride >= total8) break;
+      const int64_t m = mm[u];
+      const int c = cc[u];
+      const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
+      const float* ss = bn_ss + (int64_t)(n / imgs_per_group) * 4 * z.c;
+      const f32x4 sc0 = ld4(ss + c), sc1 = ld4(ss + c + 4), sh0 = ld4(ss + z.c + c), sh1 = ld4(ss + z.c + c + 4);
+      f16x8e_t hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t0 = df_gelu(v0[u][k] * sc0[k] + sh0[k]) * zs, t1 = df_gelu(v1[u][k] * sc1[k] + sh1[k]) * zs;
+        hi[k] = (_Float16)t0;
+        lo[k] = (_Float16)((t0 - (float)hi[k]) * 2048.f);
+        hi[4 + k] = (_Float16)t1;
+        lo[4 + k] = (_Float16)((t1 - (float)hi[4 + k]) * 2048.f);
+      }
+      const int64_t idx = df_img_base(z, n) + (int64_t)pix * z.ld + c;
+      char* b = reinterpret_cast<char*>(z.ptr) + (idx & ~31ll) * 4 + (idx & 31) * 2;
+      *reinterpret_cast<f16x8e_t*>(b) = hi;
+      *reinterpret_cast<f16x8e_t*>(b + 64) = lo;
+    }
   }
 }
 
@@ -523,25 +544,36 @@ __global__ __launch_bounds__(256) void bn_gelu_bwd_apply_kernel(df_img dz, const
     const float* ss = bn_ss + (int64_t)g * 4 * C;
     const f32x4 sc = ld4(ss + rp.c), sh = ld4(ss + C + rp.c), mu = ld4(ss + 2 * C + rp.c), is = ld4(ss + 3 * C + rp.c);
     const f32x4 c1 = ld4(coef + ((int64_t)g * 2 + 0) * C + rp.c), c2 = ld4(coef + ((int64_t)g * 2 + 1) * C + rp.c);
-    for (int64_t m = r_begin + rp.row_lane; m < r_end; m += rp.row_lanes) {
-      const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
-      const f32x4 g4 = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
-      const f32x4 yv = ldx4<YE>(y, m * C + rp.c);
-      f32x4 o;
+    // two rows per iteration (round 6): both rows' loads go out before the first row's arithmetic; sums in the same order as before
+    for (int64_t m0 = r_begin + rp.row_lane; m0 < r_end; m0 += 2 * rp.row_lanes) {
+      f32x4 g4[2], yv[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float yh = yv[k] * sc[k] + sh[k];
-        const float d = g4[k] * df_gelu_grad(yh);
-        const float xh = (yv[k] - mu[k]) * is[k];
-        o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
-        if constexpr (DE == 1) o[k] = (float)(__bf16)o[k];
-        acc[0][k] += o[k];
+      for (int u = 0; u < 2; ++u) {
+        const int64_t m = m0 + u * rp.row_lanes < r_end ? m0 + u * rp.row_lanes : m0;     // (clamped repeat instead of a branch)
+        const int n = (int)df_udiv(m, hw, hws), pix = (int)(m - (int64_t)n * hw);
+        g4[u] = ldx4<GE>(dzp, df_img_base(dz, n) + (int64_t)pix * dz.ld + rp.c);
+        yv[u] = ldx4<YE>(y, m * C + rp.c);
       }
-      if constexpr (DE == 2) {
-        st_h2x4(dy, m * C + rp.c, o, ds);
-      } else {
-        stx4<DE>(dy, m * C + rp.c, o);
-        mf = df_amax4(mf, o);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t m = m0 + u * rp.row_lanes;
+        if (m >= r_end) break;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float yh = yv[u][k] * sc[k] + sh[k];
+          const float d = g4[u][k] * df_gelu_grad(yh);
+          const float xh = (yv[u][k] - mu[k]) * is[k];
+          o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
+          if constexpr (DE == 1) o[k] = (float)(__bf16)o[k];
+          acc[0][k] += o[k];
+        }
+        if constexpr (DE == 2) {
+          st_h2x4(dy, m * C + rp.c, o, ds);
+        } else {
+          stx4<DE>(dy, m * C + rp.c, o);
+          mf = df_amax4(mf, o);
+        }
       }
     }
   }
