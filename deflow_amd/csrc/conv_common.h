@@ -178,22 +178,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       constexpr int ESZ = Y16 ? 2 : 4;
       float sy = 1.f;
       if constexpr (YH2) sy = df_h2_scale(*p.bound_y);
-      // PRE: a row's byte offset (with the lane's part folded in) is formed ONCE per (row tile, element) instead of once per column tile
-      // too; the column tile's part rides in the buffer instruction's scalar offset
-      unsigned rbase[PRE ? TM : 1][16];
-      if constexpr (PRE) {
-        const unsigned lane_b = YH2 ? (unsigned)((li & 1) * 64 + (li >> 1) * 4) : (unsigned)(li * ESZ);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            rbase[i][e] = (FULL || off >= 0) ? (unsigned)(off * ESZ) + lane_b : ROW_BAD;
-          }
-      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const unsigned soff = PRE ? (unsigned)((n0 + (wn * TN + j) * 32) * ESZ) : 0u;     // (workgroup- and wave-uniform)
         const int co = n0 + (wn * TN + j) * 32 + li;
         const float bia = p.bias ? p.bias[co] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -212,26 +198,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
           unsigned ob[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            if constexpr (PRE) {
-              ob[e] = rbase[i][e];
-            } else {
-              const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-              if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
-              else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
-            }
+            const int64_t off = rowoff[(wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+            if constexpr (YH2) ob[e] = (FULL || off >= 0) ? (unsigned)((off + co - li) * 4 + (li & 1) * 64 + (li >> 1) * 4) : ROW_BAD;
+            else ob[e] = (FULL || off >= 0) ? (unsigned)((off + co) * ESZ) : ROW_BAD;
           }
           float old[16];
           if constexpr (bws) {          // (fp32 y, no accumulation: checked by the launcher) the BatchNorm layer's conv output at the same elements
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], soff, 0));
+            for (int e = 0; e < 16; ++e) old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y2r, ob[e], 0, 0));
           }
           if (p.accumulate) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               if constexpr (Y16)
-                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], soff, 0) << 16);
+                old[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, ob[e], 0, 0) << 16);
               else
-                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], soff, 0));
+                old[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ob[e], 0, 0));
             }
           }
 #pragma unroll
@@ -241,7 +223,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             if (p.accumulate) v += old[e];
             if constexpr (Y16) {
               const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)v);
-              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], soff, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(h, yr, ob[e], 0, 0);
               v = __builtin_bit_cast(float, (unsigned)h << 16);
             } else if constexpr (YH2) {
               const float t = PRE ? v : v * sy;
@@ -251,9 +233,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
               const unsigned send = (li & 1) ? hb : lb;                 // odd lanes hand their hi to the even neighbour, even lanes their lo
               const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
               const unsigned word = (li & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], soff, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(word, yr, ob[e], 0, 0);
             } else {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], soff, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ob[e], 0, 0);
             }
             if (FULL || ob[e] != ROW_BAD) {
               if constexpr (bws) {
