@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # Per-file extras.  pillarize.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 instructions (v_pk_fma_f32 ...):
 # pillarize.hip is built WITHOUT the SLP vectoriser.  Round 3 found that the pillar feature net's backward kernels (df_pfn_bwd_stats /
 # _weights) returned wrong sums -- up to 1e-1 relative, ~4 % of the repetitions -- in the two-ranks-on-one-GPU tests, and stopped doing
-# so once their v_pk_*_f32 instructions were gone.  Round 4 bisected it (tools/pfn_race_probe*.sh, record: profiles/r04_pfn_race_probe.txt):
+# so once their v_pk_*_f32 instructions were gone.  Round 4 bisected it (tools/archive/pfn_race_probe*.sh, record: profiles/r04_pfn_race_probe.txt):
 #   * a second PROCESS is not needed: a second host thread of the same process driving another stream reproduces it (a side stream fed
 #     by the same thread does not -- at the small test size the two streams then alternate instead of overlapping);
 #   * the neighbour that triggers it is ONE kernel: the GRU decoder's forward (df_gru_decoder_fwd).  The convolutions (fp32, fp16x2, bf16),
@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 #   * it is not an uninitialised read (a neighbour that leaves NaN in 240 VGPRs and all of LDS on every CU changes nothing), not a stray
 #     write (LDS / register canaries beside the GRU kernel stay intact), not an aliasing of the two processes' code (identical
 #     libraries fail alike), the waits in the SLP build's ISA cover every load and LDS read (tools: a linear + loop-carried scan), and
-#     v_pk_fma_f32 checked against 2 x v_fma_f32 in the same lane never disagrees beside any MFMA stream (tools/pk_mfma_hazard.hip);
+#     v_pk_fma_f32 checked against 2 x v_fma_f32 in the same lane never disagrees beside any MFMA stream (tools/archive/pk_mfma_hazard.hip);
 #   * the REST of the library keeps the SLP vectoriser (130 kernels with packed-fp32 instructions, profiles/r04_packed_fp32_audit.txt)
 #     and the whole training step, fp32 and bf16, is bit-reproducible over 3000 repetitions beside that same neighbour.
 # So: these two kernels' SLP-built code + the GRU forward kernel running at the same time, cause below the ISA level not identified.

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 
 // -------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant (the default): every stage's A and B tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds`
-// (no VGPR staging, no ds_write pass).  gfx950 semantics used (probed on hardware, tools/dma_probe.hip): the wave's
+// (no VGPR staging, no ds_write pass).  gfx950 semantics used (probed on hardware, tools/archive/dma_probe.hip): the wave's
 // 64 lanes land at LDS base + lane * 16 (so one instruction fills 8 tile rows of 128 B); the per-lane SOURCE is free,
 // so the XOR slot swizzle is applied to the source column; a lane whose voffset + soffset is outside the buffer
 // writes ZEROS -- padding taps and out-of-tile rows cost one v_cndmask instead of a branch; the (tap, k-chunk)

@@ -11,7 +11,7 @@
 #include "common.h"
 #include "gemm_dma.h"
 
-// occupancy knobs of the forward kernel for the register-file experiment of tools/pfn_race_probe10.sh (defaults = the shipped kernel)
+// occupancy knobs of the forward kernel for the register-file experiment of tools/archive/pfn_race_probe10.sh (defaults = the shipped kernel)
 #ifndef DF_GRU_LB
 #define DF_GRU_LB 2
 #endif

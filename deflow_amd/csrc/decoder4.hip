@@ -24,7 +24,7 @@
 #include "common.h"
 #include "gemm_dma.h"
 
-// occupancy knobs of the forward kernel for the register-file experiment of tools/pfn_race_probe10.sh (defaults = the shipped kernel)
+// occupancy knobs of the forward kernel for the register-file experiment of tools/archive/pfn_race_probe10.sh (defaults = the shipped kernel)
 #ifndef DF_GRU_LB
 #define DF_GRU_LB 2
 #endif
@@ -694,7 +694,7 @@ extern "C" int df_gru_lean_fwd(df_img before, df_img after, const int32_t* coord
   DF_REQUIRE(wts.w_zr && wts.w_q && wts.w_1 && wts.w_2 && wts.b_2 && df_aligned16(wts.w_zr) && df_aligned16(wts.w_q) &&
                  df_aligned16(wts.w_1) && df_aligned16(xtab) && (!hsave || df_aligned16(hsave)),
              DF_E_ARG);
-  // (the weight-stationary forward experiment of round 5 is NOT part of the library: tools/experiments/decoder5_ws.hip -- exact only
+  // (the weight-stationary forward experiment of round 5 is NOT part of the library: tools/archive/experiments/decoder5_ws.hip -- exact only
   //  with matrix-pipe drains after every tile, then no faster than this kernel, and without them one wrong tile in some launches)
   Gru4Params p;
   p.before = before; p.after = after; p.coords = coords; p.offs = offs; p.counts = counts;

@@ -55,7 +55,7 @@ def synth_pair(seed: int, n: int, grid_hw=(512, 512), nan_frac: float = 0.02, ex
     every pillar edge and range limit.  The pillar index is a step function of the coordinate, and the model computes the moved pc0
     in fp32 (the reference through a BLAS matmul [REF deflow.py:103-108], this engine in ego_transform_kernel, the float64 oracle
     exactly): for a point within ~1e-5 m of an edge the three disagree about its pillar, which moved the deep encoder gradients of
-    the configs[4] shape by 1-10 % BETWEEN TWO HOSTS RUNNING THE SAME fp32 ORACLE (tools/cfg4_layer_probe.py: the first difference
+    the configs[4] shape by 1-10 % BETWEEN TWO HOSTS RUNNING THE SAME fp32 ORACLE (tools/archive/cfg4_layer_probe.py: the first difference
     is in the pillar feature net's input of two of the eight clouds) -- a 1e-4 comparison is only well-posed on clouds without such
     points."""
     g = torch.Generator().manual_seed(seed)

@@ -952,8 +952,8 @@ def test_captured_data_parallel_step_two_ranks(dev, tmp_path, mode):
             assert rr["same"], "captured data-parallel replay must leave the eager trainer's parameters / Adam state / buffers"
         else:
             # bf16 mode, TWO PROCESSES on one GPU: kernels with packed-fp32 instructions occasionally return wrong sums while the
-            # other process runs bf16-MFMA kernels (a cross-process effect of this platform, tools/pfn_bwd_stress.py; one
-            # process per GPU -- the deployment -- is bit-reproducible, tools/grad_repro_probe.py): bounded, not bit-exact, here
+            # other process runs bf16-MFMA kernels (a cross-process effect of this platform, tools/archive/pfn_bwd_stress.py; one
+            # process per GPU -- the deployment -- is bit-reproducible, tools/archive/grad_repro_probe.py): bounded, not bit-exact, here
             assert all(abs(g - w) <= 1e-3 * abs(w) for g, w in zip(rr["got"], rr["want"])), (rr["got"], rr["want"])
             assert rr["diag"]["param"] <= 5e-3 and rr["diag"]["buffers"] <= 1e-3, rr["diag"]
         assert rr["steps"] == (3, 3, 3)

@@ -1,4 +1,4 @@
-"""Bit-reproducibility soaks beside a concurrent neighbour (round 5; were tools/grad_repro_probe.py / tools/pfn_bwd_stress.py runs
+"""Bit-reproducibility soaks beside a concurrent neighbour (round 5; were tools/archive/grad_repro_probe.py / tools/archive/pfn_bwd_stress.py runs
 recorded in profiles/r04_pfn_race_probe.txt).  History: the pillar feature net's backward kernels returned wrong sums in ~4 % of
 their launches while the GRU decoder's forward kernel ran on another stream driven by another host thread -- with the SLP-vectorised
 (packed-fp32) build of csrc/pillarize.hip only; the library builds that file with -fno-slp-vectorize (deflow_amd/build.py) and the cause
