@@ -672,6 +672,63 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(df_img x, df_img y, int
   }
 }
 
+// Eight channels per thread (round 6, second session): the x2 passes ran at 2.8-2.9 TB/s of their bytes -- half of what the BatchNorm +
+// GELU plane producers reach -- with four channels per thread: two 8-byte stores per h2 plane and thread, and the index decode + the
+// two source-index computations per 16 output bytes.  Same arithmetic per output value as upsample2x_kernel (bit-identical results).
+template <int YE = 0>
+__global__ __launch_bounds__(256) void upsample2x8_kernel(df_img x, df_img y, int align_corners, int64_t total8, const float* __restrict__ y_bound) {
+  float ys = 1.f;
+  if constexpr (YE == 2) ys = df_h2_scale(*y_bound);
+  const int C8 = y.c >> 3;
+  const int c8s = df_pow2_shift(C8), yws = df_pow2_shift(y.w), yhs = df_pow2_shift(y.h);
+  const float* __restrict__ xp = reinterpret_cast<const float*>(x.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = df_udiv(i, C8, c8s);
+    const int c = (int)(i - m * C8) * 8;
+    const int64_t mw = df_udiv(m, y.w, yws);
+    const int X = (int)(m - mw * y.w);
+    const int n = (int)df_udiv(mw, y.h, yhs), Y = (int)(mw - (int64_t)n * y.h);
+    const Lerp ly = lerp_src(Y, x.h, y.h, align_corners), lx = lerp_src(X, x.w, y.w, align_corners);
+    const float* b = xp + df_img_base(x, n) + c;
+    const float* p00 = b + ((int64_t)ly.i0 * x.w + lx.i0) * x.ld;
+    const float* p01 = b + ((int64_t)ly.i0 * x.w + lx.i1) * x.ld;
+    const float* p10 = b + ((int64_t)ly.i1 * x.w + lx.i0) * x.ld;
+    const float* p11 = b + ((int64_t)ly.i1 * x.w + lx.i1) * x.ld;
+    const f32x4 a00 = ld4(p00), a01 = ld4(p01), a10 = ld4(p10), a11 = ld4(p11);
+    const f32x4 b00 = ld4(p00 + 4), b01 = ld4(p01 + 4), b10 = ld4(p10 + 4), b11 = ld4(p11 + 4);
+    const f32x4 o0 = ly.l0 * (lx.l0 * a00 + lx.l1 * a01) + ly.l1 * (lx.l0 * a10 + lx.l1 * a11);
+    const f32x4 o1 = ly.l0 * (lx.l0 * b00 + lx.l1 * b01) + ly.l1 * (lx.l0 * b10 + lx.l1 * b11);
+    const int64_t idx = df_img_base(y, n) + ((int64_t)Y * y.w + X) * y.ld + c;
+    if constexpr (YE == 2) {
+      f16x8e_t hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t0 = o0[k] * ys, t1 = o1[k] * ys;
+        hi[k] = (_Float16)t0;
+        lo[k] = (_Float16)((t0 - (float)hi[k]) * 2048.f);
+        hi[4 + k] = (_Float16)t1;
+        lo[4 + k] = (_Float16)((t1 - (float)hi[4 + k]) * 2048.f);
+      }
+      char* q = reinterpret_cast<char*>(y.ptr) + (idx & ~31ll) * 4 + (idx & 31) * 2;
+      *reinterpret_cast<f16x8e_t*>(q) = hi;
+      *reinterpret_cast<f16x8e_t*>(q + 64) = lo;
+    } else if constexpr (YE == 1) {
+      typedef __bf16 bf16x8e_t __attribute__((ext_vector_type(8)));
+      bf16x8e_t o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = (__bf16)o0[k];
+        o[4 + k] = (__bf16)o1[k];
+      }
+      *reinterpret_cast<bf16x8e_t*>(reinterpret_cast<unsigned short*>(y.ptr) + idx) = o;
+    } else {
+      float* q = reinterpret_cast<float*>(y.ptr) + idx;
+      st4(q, o0);
+      st4(q + 4, o1);
+    }
+  }
+}
+
 // bf16 activations (inference path): the same PyTorch lerp semantics evaluated in fp32, 8 channels (16 bytes) per thread
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void upsample2x_bf16_kernel(df_img x, df_img y, int align_corners, int64_t total8) {
@@ -742,6 +799,55 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(df_img dy, df_img d
   }
 }
 
+// align_corners = false, eight channels per thread (round 6, second session): only the 4 x 4 outputs 2 y - 1 .. 2 y + 2 can read input
+// row / column y; their weights come from the same source-index function as the forward (borders included), loads are unconditional at
+// clamped addresses (a tap outside the image, or one that does not read this input, has weight 0), summation order = the gather form's
+__global__ __launch_bounds__(256) void upsample2x_bwd8_kernel(df_img dy, df_img dx, int64_t total8) {
+  const int C8 = dx.c >> 3;
+  const int c8s = df_pow2_shift(C8), xws = df_pow2_shift(dx.w), xhs = df_pow2_shift(dx.h);
+  const float* __restrict__ dyp = reinterpret_cast<const float*>(dy.ptr);
+  float* __restrict__ dxp = reinterpret_cast<float*>(dx.ptr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = df_udiv(i, C8, c8s);
+    const int c = (int)(i - m * C8) * 8;
+    const int64_t mw = df_udiv(m, dx.w, xws);
+    const int xx = (int)(m - mw * dx.w);
+    const int n = (int)df_udiv(mw, dx.h, xhs), yy = (int)(mw - (int64_t)n * dx.h);
+    float wy[4], wx[4];
+    int Yc[4], Xc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int Y = 2 * yy - 1 + k, X = 2 * xx - 1 + k;
+      Yc[k] = min(max(Y, 0), dy.h - 1);
+      Xc[k] = min(max(X, 0), dy.w - 1);
+      const Lerp l = lerp_src(Yc[k], dx.h, dy.h, 0), r = lerp_src(Xc[k], dx.w, dy.w, 0);
+      wy[k] = (Y == Yc[k]) ? (l.i0 == yy ? l.l0 : 0.f) + (l.i1 == yy ? l.l1 : 0.f) : 0.f;
+      wx[k] = (X == Xc[k]) ? (r.i0 == xx ? r.l0 : 0.f) + (r.i1 == xx ? r.l1 : 0.f) : 0.f;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* b = dyp + df_img_base(dy, n) + c;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float* row = b + (int64_t)Yc[a] * dy.w * dy.ld;
+      f32x4 v0[4], v1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v0[k] = ld4(row + (int64_t)Xc[k] * dy.ld);
+        v1[k] = ld4(row + (int64_t)Xc[k] * dy.ld + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = wy[a] * wx[k];
+        acc0 += w * v0[k];
+        acc1 += w * v1[k];
+      }
+    }
+    float* q = dxp + df_img_base(dx, n) + ((int64_t)yy * dx.w + xx) * dx.ld + c;
+    st4(q, acc0);
+    st4(q + 4, acc1);
+  }
+}
+
 // any16: the entry point has a bfloat16 form (bf16 rows are accessed 8 bytes = 4 elements at a time)
 bool img_ok(const df_img& d, bool any16 = false) {
   return d.ptr && df_aligned16(d.ptr) && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && (d.c % 4) == 0 && d.grp_size > 0 &&
@@ -752,6 +858,11 @@ bool img_ok(const df_img& d, bool any16 = false) {
 bool h2_ok(const df_img& d) {
   return d.elt == 2 && d.ptr && (((uintptr_t)d.ptr) & 127) == 0 && d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && (d.c % 32) == 0 &&
          d.grp_size > 0 && (d.n % d.grp_size) == 0 && (d.ld % 32) == 0 && (d.img_stride % 32) == 0 && (d.grp_off % 32) == 0;
+}
+// DF_UP8=0: the four-channel forms of the bilinear x2 kernels (rounds 1-5) instead of the eight-channel ones
+bool up8_on() {
+  static const bool on = !(getenv("DF_UP8") && atoi(getenv("DF_UP8")) == 0);
+  return on;
 }
 bool rowpart_ok(int C) { return C >= 4 && C <= 1024 && (C % 4) == 0 && (256 % (C / 4)) == 0; }
 unsigned grid_for(int64_t total, int per_block = 256, unsigned cap = 256 * 16) {
@@ -930,6 +1041,14 @@ extern "C" int df_upsample2x(df_img x, df_img y, int align_corners, void* stream
   DF_REQUIRE(img_ok(x) && img_ok(y, true), DF_E_ARG);     // y may be bfloat16 (bf16-storage training)
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  if (up8_on() && (y.c % 8) == 0 && (y.ld % 8) == 0 && (y.img_stride % 8) == 0 && (y.grp_off % 8) == 0) {
+    if (y.elt) hipLaunchKernelGGL(upsample2x8_kernel<1>, dim3(grid_for(total4 / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+                                  align_corners, total4 / 2, nullptr);
+    else hipLaunchKernelGGL(upsample2x8_kernel<0>, dim3(grid_for(total4 / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+                            align_corners, total4 / 2, nullptr);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   if (y.elt) hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                                 y, align_corners, total4, nullptr);
   else hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
@@ -944,6 +1063,12 @@ extern "C" int df_upsample2x_h2(df_img x, df_img y, int align_corners, const flo
   DF_REQUIRE(img_ok(x) && h2_ok(y) && y_bound, DF_E_ARG);
   DF_REQUIRE(x.n == y.n && x.c == y.c && y.h == 2 * x.h && y.w == 2 * x.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)y.n * y.h * y.w * (y.c / 4);
+  if (up8_on()) {     // (h2 images hold whole 32-channel chunks: c % 8 == 0)
+    hipLaunchKernelGGL(upsample2x8_kernel<2>, dim3(grid_for(total4 / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+                       align_corners, total4 / 2, y_bound);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
                      align_corners, total4, y_bound);
   DF_CHECK_LAUNCH();
@@ -1011,6 +1136,12 @@ extern "C" int df_upsample2x_bwd(df_img dy, df_img dx, int align_corners, void* 
   DF_REQUIRE(img_ok(dx) && img_ok(dy), DF_E_ARG);
   DF_REQUIRE(dx.n == dy.n && dx.c == dy.c && dy.h == 2 * dx.h && dy.w == 2 * dx.w, DF_E_SHAPE);
   const int64_t total4 = (int64_t)dx.n * dx.h * dx.w * (dx.c / 4);
+  if (!align_corners && up8_on() && (dx.c % 8) == 0) {
+    hipLaunchKernelGGL(upsample2x_bwd8_kernel, dim3(grid_for(total4 / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, dx,
+                       total4 / 2);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dy, dx, align_corners, total4);
   DF_CHECK_LAUNCH();
