@@ -679,6 +679,150 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_kernel(SparseConvPa
 }
 
 
+// ---- fp16x2 form of the sparse-output 3x3 convolution (round 6, second session) ----------------------------------------------
+// The fp32 form above runs v_mfma_f32_16x16x4_f32: 62 GFLOP per step at 81 TFLOP/s, half of the fp32 matrix pipe's peak -- the last
+// dense-rate fp32 MFMA kernel in the forward.  Here the product is the fp16x2 one of the dense 3x3 layers (conv.hip: two scaled fp16
+// planes per operand, x s = hi + lo / 2048, THREE v_mfma_f32_16x16x32_f16 per 32-deep k step -- hi hi' in one accumulator, the two cross
+// terms in a second one that is folded in at the end; 22 significant bits per operand): 24 products of 16 cycles per tap and batch
+// instead of 64 of 32.  The weights arrive pre-split (df_split_h2 / df_weight_prep planes [hi | lo], each [co][tap][ci] fp16) and sit in
+// LDS as [tap][plane][k step][co][64 B] -- the same 147 KB as the fp32 form -- a B fragment is one ds_read_b128 (16-byte slots swizzled
+// by g((co >> 2) & 3), g = (0, 2, 3, 1): conflict-free for the lane groups ds_read_b128 is serviced in, see gemm_dma.h); the A rows come
+// straight from global memory as before (lane (cell, q) holds channels 8 q .. 8 q + 7 and 32 + 8 q .. of its cell's row) and are split in
+// registers with the scale of the input's bound *amax_x (the producing convolution's measured max |u|).
+struct SparseConvH2Params {
+  const uint32_t* key_sorted;
+  const int32_t* counts;
+  int H, W;
+  df_img x, y;
+  const void* w2;      // [2][64][3][3][64] fp16: hi plane, lo plane of w s_w
+  const float* bias;   // [64] or nullptr
+  const float* amax_x;
+  const float* amax_w;
+};
+typedef _Float16 f16x8s_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float sp_h2_scale(float amax) {   // (conv_common.h's df_h2_scale)
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
+  const int f = min(max(268 - e, 1), 254);
+  return __builtin_bit_cast(float, (unsigned)f << 23);
+}
+__device__ __forceinline__ int sp_g4(int x) { return (0x78 >> (2 * x)) & 3; }
+
+__global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseConvH2Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wt = lds;                                              // [9][2][2][64][16 floats = 64 B]
+  int* RowCell = reinterpret_cast<int*>(Wt + 9 * 2 * 2 * 64 * 16);     // [16 waves][16]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  {  // 9216 16-byte pieces: piece i of the planes (linear in memory) = plane i / 4608, then (co, tap, k step, slot) = the digits of i % 4608
+    f32x4 wv[9];
+    const float* w2f = reinterpret_cast<const float*>(p.w2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld4(w2f + (tid + PG_THREADS * k) * 4);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = tid + PG_THREADS * k;
+      const int plane = i / 4608, rem = i - plane * 4608;
+      const int co = rem / 72, r2 = rem - co * 72;
+      const int tap = r2 >> 3, ks = (r2 >> 2) & 1, sl = r2 & 3;
+      st4(Wt + ((((tap * 2 + plane) * 2 + ks) * 64 + co) * 4 + (sl ^ sp_g4((co >> 2) & 3))) * 4, wv[k]);
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  int* rowcell = RowCell + wave * 16;
+  const int ncell = p.H * p.W;
+  const float* xp = reinterpret_cast<const float*>(p.x.ptr) + df_img_base(p.x, b);
+  float* yp = reinterpret_cast<float*>(p.y.ptr) + df_img_base(p.y, b);
+  const SampleRange sr = sample_range(p.counts, b);
+  const int end = sr.off + sr.cnt;
+  const float sx = sp_h2_scale(*p.amax_x), sw = sp_h2_scale(*p.amax_w);
+  const float inv = (1.f / sx) * (1.f / sw);
+  float bia[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bia[nt] = p.bias ? p.bias[16 * nt + li] : 0.f;
+  auto lds_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const float* wlane = Wt + (li * 4 + (lq ^ sp_g4((li >> 2) & 3))) * 4;     // this lane's slot of row co = li (+ 16 nt) of a [64][64 B] tile
+  const int nchunk = (sr.cnt + 63) / 64, per = (nchunk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_lo = blockIdx.x * per, c_hi = min(c_lo + per, nchunk);
+  for (int base = sr.off + (c_lo + wave) * 64; base < sr.off + c_hi * 64; base += (PG_THREADS / 64) * 64) {
+    const int i = base + lane;
+    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
+    const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
+    const int mycell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    unsigned long long m = __ballot(head);
+    while (m) {   // batches of up to 16 cells
+      const bool in = (m >> lane) & 1;
+      const int rank = __popcll(m & ((1ull << lane) - 1));
+      if (in && rank < 16) rowcell[rank] = mycell;
+      const int nrows = min(16, (int)__popcll(m));
+      m = __ballot(in && rank >= 16);
+      lds_fence();
+      const int cell = li < nrows ? rowcell[li] : -1;
+      int crow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) crow[r] = (4 * lq + r) < nrows ? rowcell[4 * lq + r] : -1;
+      lds_fence();
+      const int y = cell / p.W, x = cell - y * p.W;
+      f32x4 acc[4], acc1[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // A rows of tap t + 1 are fetched while tap t is multiplied: a4[2 ks], a4[2 ks + 1] = channels 32 ks + 8 lq .. + 7
+      auto fetch = [&](int tap, f32x4 (&a4)[4]) {
+        const int qy = y + tap / 3 - 1, qx = x + tap % 3 - 1;
+        const bool ok = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+        const float* src = xp + (int64_t)(ok ? qy * p.W + qx : 0) * p.x.ld + 8 * lq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = ok ? ld4(src + 32 * (k >> 1) + 4 * (k & 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      f32x4 a_cur[4], a_nxt[4];
+      fetch(0, a_cur);
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) fetch(tap + 1, a_nxt);
+        f16x8s_t ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = a_cur[2 * ks + (e >> 2)][e & 3] * sx;
+            ah[ks][e] = (_Float16)t;
+            al[ks][e] = (_Float16)((t - (float)ah[ks][e]) * 2048.f);
+          }
+        const float* wt = wlane + tap * (2 * 2 * 64 * 16);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const f16x8s_t bh = *reinterpret_cast<const f16x8s_t*>(wt + (ks * 64 + 16 * nt) * 16);
+            const f16x8s_t bl = *reinterpret_cast<const f16x8s_t*>(wt + ((2 + ks) * 64 + 16 * nt) * 16);
+            acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc1[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[nt], 0, 0, 0);
+            acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc1[nt], 0, 0, 0);
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a_cur[k] = a_nxt[k];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (crow[r] < 0) continue;
+        float* o = yp + (int64_t)crow[r] * p.y.ld + li;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[16 * nt] = fmaf(fmaf(acc1[nt][r], 1.f / 2048.f, acc[nt][r]), inv, bia[nt]);
+      }
+    }
+  }
+#endif
+}
+
+
 // ---------------------------------------------------------------------------------- sparse-input weight gradient ---
 // Weight gradient of the FIRST encoder conv (3x3, stride 2, pad 1, 32 -> 64) whose input is the pillar canvas: only the
 // occupied cells q of a cloud contribute,
@@ -1067,6 +1211,25 @@ extern "C" int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* coun
   const size_t lds_bytes = (size_t)(9 * 64 * 64 + (PG_THREADS / 64) * 16) * sizeof(float);
   DF_SET_LDS_ONCE((sparse_conv3x3_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(sparse_conv3x3_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// the fp16x2 form (sparse_conv3x3_h2_kernel): w2 = the [hi | lo] fp16 planes of w scaled by df_h2_scale(*w_amax) (df_split_h2 / the
+// layer's planes from df_weight_prep), x_amax = an upper bound of max |x| (device scalars)
+extern "C" int df_sparse_conv3x3_h2(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const void* w2,
+                                    const float* x_amax, const float* w_amax, const float* bias, df_img y, int nblk, void* stream) {
+  DF_REQUIRE(key_sorted && counts && x.ptr && y.ptr && w2 && x_amax && w_amax && df_aligned16(w2) && B > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(x.n == B && y.n == B && x.c == 64 && y.c == 64 && x.h == y.h && x.w == y.w && (x.ld % 4) == 0 &&
+                 df_aligned16(x.ptr) && x.grp_size == x.n && y.grp_size == y.n && x.elt == 0 && y.elt == 0,
+             DF_E_SHAPE);
+  SparseConvH2Params p;
+  p.key_sorted = key_sorted; p.counts = counts; p.H = y.h; p.W = y.w; p.x = x; p.y = y; p.w2 = w2; p.bias = bias;
+  p.amax_x = x_amax; p.amax_w = w_amax;
+  const size_t lds_bytes = (size_t)(9 * 2 * 2 * 64 * 16 + (PG_THREADS / 64) * 16) * sizeof(float);
+  DF_SET_LDS_ONCE((sparse_conv3x3_h2_kernel), (int)lds_bytes);
+  hipLaunchKernelGGL(sparse_conv3x3_h2_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;

@@ -19,6 +19,7 @@ from ._lib import DfImg, call, img, img_pair, ptr, stream, ver
 
 import os
 _NO_FUSED_BIAS = bool(int(os.environ.get("DF_NO_FUSED_BIAS", "0")))  # A/B switch: separate column-sum pass for conv bias grads
+_SPARSE_H2 = os.environ.get("DF_SPARSE_H2", "1") != "0"   # A/B switch: the sparse edge kernels (last conv forward / weight gradient) as fp16x2 products
 
 
 class ConvWithNorms(nn.Module):
@@ -204,8 +205,16 @@ class FastFlow3DUNet(nn.Module):
             self._conv(self.decoder_step4, u, img(v), 3, tape)
         else:
             m4 = self.decoder_step4
-            call("df_sparse_conv3x3", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, img(u), ptr(ops.ohwi(m4.weight)),
-                 ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
+            if ops.h2_active() and _SPARSE_H2:
+                # the fp16x2 product of the dense 3x3 layers (three 16-bit MFMAs per k step instead of fp32 MFMAs): the weights' planes
+                # from the step's WeightPrep (or split per call), the input's bound = the max |u| its producer measured
+                ui = img(u)
+                w2, wa = ops._split_h2(ops.ohwi(m4.weight))
+                call("df_sparse_conv3x3_h2", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, ui, ptr(w2), ptr(ops.amax_of(ui, dev)),
+                     ptr(wa), ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
+            else:
+                call("df_sparse_conv3x3", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, img(u), ptr(ops.ohwi(m4.weight)),
+                     ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
             if tape is not None:
                 tape.append(("conv", m4, u, 3))
         return v

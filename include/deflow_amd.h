@@ -158,6 +158,11 @@ int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B,
  * written.  x, y [B,H,W,64]; w [64,3,3,64]. */
 int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const float* w,
                       const float* bias, df_img y, int nblk, void* stream);
+/* ... on the 16-bit matrix pipe as an fp32-accurate fp16x2 product (three v_mfma_f32_16x16x32_f16 per 32-deep k step, as the dense
+ * 3x3 layers: df_conv2d_h2): w2 = the [hi | lo] fp16 planes of w scaled by df_h2_scale(*w_amax) (df_split_h2 / df_weight_prep),
+ * x_amax = a bound of max |x| (device scalars).  Same cells, same result class as df_sparse_conv3x3. */
+int df_sparse_conv3x3_h2(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const void* w2,
+                         const float* x_amax, const float* w_amax, const float* bias, df_img y, int nblk, void* stream);
 
 /* Weight gradient of the first encoder conv (3x3, stride 2, pad 1, 32 -> 64; dy1 [2B,H/2,W/2,64], image = cloud*B + b)
  * summed over the occupied cells of one cloud's canvas [B,H,W,32] only.  ws [nblk*B][64][9][32] partials; finish with

@@ -1345,3 +1345,54 @@ def test_wgrad_x3_fp32_accurate(dev, monkeypatch, cin, cout, n, h, w):
     assert e3 <= 2e-6 and e2 <= 2e-6, (e2, e3, er)
     check("h2 wgrad bias", db, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
     check("x3 wgrad bias", db3, dy.cpu().double().sum((0, 1, 2)).float(), 2e-6)
+
+
+# ------------------------------------------------------------------- sparse edge kernels, fp16x2 forms (round 6) ----------
+def _sorted_cells(B, H, W, npts, seed, dev):
+    """sorted pillar keys (b H W + cell, duplicates = several points per pillar) and per-sample counts, as the pillariser leaves them;
+    sample 1 (if any) is empty"""
+    g = torch.Generator().manual_seed(seed)
+    keys, counts = [], []
+    for b in range(B):
+        n = 0 if (b == 1 and B > 2) else npts
+        cells = torch.randint(0, H * W, (n,), generator=g)
+        cells[: n // 4] = cells[n // 4: 2 * (n // 4)]           # duplicates
+        keys.append(torch.sort(cells)[0] + b * H * W)
+        counts.append(n)
+    return torch.cat(keys).to(torch.int32).to(dev), torch.tensor(counts, dtype=torch.int32, device=dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,npts", [(1, 16, 24, 37), (3, 32, 32, 700), (2, 64, 64, 3000)])
+def test_sparse_conv3x3_h2_vs_float64(dev, B, H, W, npts):
+    """df_sparse_conv3x3_h2 (fp16x2 product on the 16-bit matrix pipe) at the occupied cells: against the float64 convolution, beside the
+    fp32-MFMA form df_sparse_conv3x3 it replaces; cells outside the list are not written"""
+    from deflow_amd import ops
+    from deflow_amd._lib import call, img, ptr, stream
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = (torch.randn(B, H, W, 64, generator=g) * 3.0).to(dev)
+    w = (torch.randn(64, 3, 3, 64, generator=g) * 0.05).to(dev)          # [O,kh,kw,I]
+    bias = (torch.randn(64, generator=g) * 0.1).to(dev)
+    keys, counts = _sorted_cells(B, H, W, npts, 5, dev)
+    want = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    occ = torch.zeros(B * H * W, dtype=torch.bool)
+    occ[keys.cpu().long()] = True
+    occ = occ.view(B, H, W)
+    xa = torch.zeros(1, device=dev); wa = torch.zeros(1, device=dev)
+    call("df_absmax", img(x), ptr(xa), stream())
+    call("df_absmax", img(w.reshape(1, 1, -1, 64)), ptr(wa), stream())
+    w2 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    call("df_split_h2", ptr(w), ptr(wa), ptr(w2), w.numel(), stream())
+    SENT = 12345.0
+    y2 = torch.full((B, H, W, 64), SENT, device=dev)
+    y0 = torch.full((B, H, W, 64), SENT, device=dev)
+    call("df_sparse_conv3x3_h2", ptr(keys), ptr(counts), B, img(x), ptr(w2), ptr(xa), ptr(wa), ptr(bias), img(y2), 3, stream())
+    call("df_sparse_conv3x3", ptr(keys), ptr(counts), B, img(x), ptr(w), ptr(bias), img(y0), 3, stream())
+    torch.cuda.synchronize()
+    y2c, y0c = y2.cpu(), y0.cpu()
+    assert bool((y2c[~occ] == SENT).all()), "a cell outside the list was written"
+    scale = float(want[occ].abs().max())
+    e2 = float((y2c[occ].double() - want[occ]).abs().max()) / scale
+    e0 = float((y0c[occ].double() - want[occ]).abs().max()) / scale
+    print(f"[parity] sparse_conv3x3 B={B} {H}x{W}: fp16x2 {e2:.2e}, fp32 MFMA {e0:.2e} of max |y|")
+    assert e2 <= max(2e-6, 4 * e0)
