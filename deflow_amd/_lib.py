@@ -58,6 +58,7 @@ _SIGS = {
     "df_sparse_conv3x3": [P, P, I, DfImg, P, P, DfImg, I, P],
     "df_sparse_conv3x3_h2": [P, P, I, DfImg, P, P, P, P, DfImg, I, P],
     "df_sparse_wgrad3x3": [P, P, I, DfImg, DfImg, P, P, I, P],
+    "df_sparse_wgrad3x3_x2": [P, P, I, DfImg, DfImg, P, P, I, P],
     "df_pillar_input_grad": [P, P, I, I, I, I, P, P, DfImg, P, DfImg, I, I, P],
     "df_conv2d": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P],
     "df_conv2d_mp": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, I, P],

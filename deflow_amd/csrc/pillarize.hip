@@ -559,6 +559,133 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_kernel(SparseWgradParams 
 }
 
 
+// ---- bf16x2 form of the sparse-output-gradient weight gradient (round 6, second session) ---------------------------------------
+// sparse_wgrad3x3_kernel above multiplies on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, four pixels per instruction): 62 GFLOP per
+// step at 68 TFLOP/s.  Here both operands are two bf16 planes (hi = bf16(v), lo = bf16(v - hi): 16 significant bits, no scales -- the
+// product of the GRU kernels, gemm_dma.h) and a k step is 32 PIXELS of one v_mfma_f32_16x16x32_bf16: three products per tile (lo hi',
+// hi lo', hi hi'; small terms first) into ONE accumulator -- 48 instructions of 16 cycles per 32 pixels and tap instead of 128 of 32.
+// Tile (ct, nt) row m <-> output channel 4 m + ct, column n <-> input channel 4 n + nt: a lane's operand values for the four row
+// (column) tiles are then 16 contiguous bytes of one pixel's dy (x) row -- 16 dwordx4 loads per lane and step instead of 64 dword
+// loads -- and its four column tiles of one output row are 16 contiguous bytes of the partial.  Same pixel lists, one wave per tap, no
+// workgroup synchronisation, partials [workgroup][64][9][64] for df_conv2d_wgrad_reduce as before.
+typedef __bf16 bf16x8s_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(576) void sparse_wgrad3x3_x2_kernel(SparseWgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ int Plist[9 * SW_WIN];
+  const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.y, ncell = p.H * p.W;
+  const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+  int* plist = Plist + tap * SW_WIN;
+  const float* dy = reinterpret_cast<const float*>(p.dy.ptr) + df_img_base(p.dy, b);
+  const float* xp = reinterpret_cast<const float*>(p.x.ptr) + df_img_base(p.x, b);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)((int64_t)ncell * p.dy.ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (unsigned)((int64_t)ncell * p.x.ld * 4), 0x00020000);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const SampleRange sr = sample_range(p.counts, b);
+  const int end = sr.off + sr.cnt;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+  auto split8 = [&](const f32x4 (&r)[8], int c, bf16x8s_t& hi, bf16x8s_t& lo) {   // component c of the eight pixels' values
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = r[e][c];
+      hi[e] = (__bf16)v;
+      lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+  };
+  for (int base = sr.off + blockIdx.x * SW_WIN; base < end; base += gridDim.x * SW_WIN) {
+    const int wend = min(end, base + SW_WIN);
+    uint32_t key[SW_WIN / 64], prev[SW_WIN / 64];
+#pragma unroll
+    for (int w = 0; w < SW_WIN / 64; ++w) {
+      const int i = base + 64 * w + lane;
+      key[w] = i < wend ? p.key_sorted[i] : 0xffffffffu;
+      prev[w] = (i < wend && i > sr.off) ? p.key_sorted[i - 1] : 0xfffffffeu;
+    }
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < SW_WIN / 64; ++w) {
+      const int i = base + 64 * w + lane;
+      const bool head = i < wend && (i == sr.off || prev[w] != key[w]);
+      const unsigned long long m = __ballot(head);
+      if (head) plist[n + (int)__popcll(m & lt)] = (int)(key[w] - (uint32_t)b * (uint32_t)ncell);
+      n += (int)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int s0 = 0; s0 < n; s0 += 32) {
+      // this lane's eight pixels of the step: k = 8 lq + e.  Branch-free: a missing pixel / a tap outside the image reads zeros from an
+      // out-of-range offset
+      f32x4 ra[8], rb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = s0 + 8 * lq + e;
+        const int cell = k < n ? plist[k] : -1;
+        const int y = cell / p.W, x = cell - y * p.W;
+        const int qy = y + ty, qx = x + tx;
+        const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+        const unsigned ao = cell >= 0 ? (unsigned)((cell * p.dy.ld + 4 * li) * 4) : 0xF0000000u;
+        const unsigned bo = okq ? (unsigned)(((qy * p.W + qx) * p.x.ld + 4 * li) * 4) : 0xF0000000u;
+        ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, ao, 0, 0));
+        rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, bo, 0, 0));
+      }
+      if (tap == 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bsum[c] += ra[e][c];
+      }
+      bf16x8s_t ah[4], al[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split8(ra, c, ah[c], al[c]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bf16x8s_t bh, bl;
+        split8(rb, nt, bh, bl);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4 v = acc[ct][nt];
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ct], bh, v, 0, 0, 0);   // small terms first
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ct], bl, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ct], bh, v, 0, 0, 0);
+          acc[ct][nt] = v;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  float* o = p.ws + blk * 64 * 9 * 64;
+  // acc[ct][nt][r] = dW[co = 4 (4 lq + r) + ct][tap][ci = 4 li + nt]
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      st4(o + ((4 * (4 * lq + r) + ct) * 9 + tap) * 64 + 4 * li, f32x4{acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]});
+  if (tap == 4 && p.bias_ws) {   // bsum[c] on lane (li, lq) = sum over this lane's pixels of dy[.., 4 li + c]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      bsum[c] = v;
+    }
+    if (lq == 0) st4(p.bias_ws + blk * 64 + 4 * li, f32x4{bsum[0], bsum[1], bsum[2], bsum[3]});
+  }
+#endif
+}
+
+
 // ----------------------------------------------------------------------------------- sparse-output 3x3 convolution ---
 // The UNet's last conv (3x3, stride 1, 64 -> 64, full resolution) produces the `after` image, which is only ever READ
 // at the cells pc0 points look up (the decoder's gather; ~20 % of H*W).  This kernel computes
@@ -1196,6 +1323,25 @@ extern "C" int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* cou
   SparseWgradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.H = dy.h; p.W = dy.w; p.dy = dy; p.x = x; p.ws = ws; p.bias_ws = bias_ws;
   hipLaunchKernelGGL(sparse_wgrad3x3_kernel, dim3(nblk, B), dim3(576), 0, reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// the bf16x2 form (sparse_wgrad3x3_x2_kernel: both operands as two bf16 planes, three v_mfma_f32_16x16x32_bf16 per tile and 32 pixels);
+// same arguments, same partial layout; x / dy rows are read 16 bytes at a time
+extern "C" int df_sparse_wgrad3x3_x2(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
+                                     float* bias_ws, int nblk, void* stream) {
+  DF_REQUIRE(key_sorted && counts && x.ptr && dy.ptr && ws && B > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(x.n == B && dy.n == B && x.c == 64 && dy.c == 64 && x.h == dy.h && x.w == dy.w && x.grp_size == x.n &&
+                 dy.grp_size == dy.n && x.elt == 0 && dy.elt == 0,
+             DF_E_SHAPE);
+  DF_REQUIRE(df_aligned16(x.ptr) && df_aligned16(dy.ptr) && (x.ld % 4) == 0 && (dy.ld % 4) == 0 && (x.img_stride % 4) == 0 &&
+                 (dy.img_stride % 4) == 0 && df_aligned16(ws) && (!bias_ws || df_aligned16(bias_ws)),
+             DF_E_ALIGN);
+  DF_REQUIRE((int64_t)dy.h * dy.w * dy.ld < (int64_t)0x30000000 && (int64_t)x.h * x.w * x.ld < (int64_t)0x30000000, DF_E_SHAPE);   // 32-bit byte offsets
+  SparseWgradParams p;
+  p.key_sorted = key_sorted; p.counts = counts; p.H = dy.h; p.W = dy.w; p.dy = dy; p.x = x; p.ws = ws; p.bias_ws = bias_ws;
+  hipLaunchKernelGGL(sparse_wgrad3x3_x2_kernel, dim3(nblk, B), dim3(576), 0, reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;
 }

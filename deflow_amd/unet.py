@@ -490,7 +490,7 @@ class FastFlow3DUNet(nn.Module):
             nblk = max(1, 256 // B)
             ws = torch.empty(nblk * B, 64 * 9 * 64, **f32)
             bws = torch.empty(nblk * B, 64, **f32)
-            call("df_sparse_wgrad3x3", ptr(dv_cells.key_sorted), ptr(dv_cells.counts), B, img(xu), img(dv), ptr(ws), ptr(bws),
+            call("df_sparse_wgrad3x3_x2" if (_SPARSE_H2 and os.environ.get("DF_GRU_X2", "1") != "0") else "df_sparse_wgrad3x3", ptr(dv_cells.key_sorted), ptr(dv_cells.counts), B, img(xu), img(dv), ptr(ws), ptr(bws),
                  nblk, stream())
             dw4 = torch.empty_like(w4)
             db4 = torch.empty(64, **f32)

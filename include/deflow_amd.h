@@ -152,6 +152,10 @@ int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* counts, int 
  * df_conv2d_wgrad_reduce(ws, nblk*B, 64, 9, 64, ...) and df_colsum_finalize(bias_ws, nblk*B, 64, 1, ...). */
 int df_sparse_wgrad3x3(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
                        float* bias_ws, int nblk, void* stream);
+/* ... with both operands as two bf16 planes (16 significant bits; three v_mfma_f32_16x16x32_bf16 per tile and 32 pixels -- the product of
+ * the GRU kernels) instead of the fp32 matrix pipe; x / dy rows 16-byte aligned.  Same arguments and partial layout. */
+int df_sparse_wgrad3x3_x2(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, df_img dy, float* ws,
+                          float* bias_ws, int nblk, void* stream);
 
 /* The same conv's forward where only those cells of the OUTPUT are consumed (the `after` image is read by the decoder's
  * gather alone): y[p] = bias + conv3x3(x)[p] for the occupied cells p of the pillarised cloud; other cells of y are not

@@ -1396,3 +1396,39 @@ def test_sparse_conv3x3_h2_vs_float64(dev, B, H, W, npts):
     e0 = float((y0c[occ].double() - want[occ]).abs().max()) / scale
     print(f"[parity] sparse_conv3x3 B={B} {H}x{W}: fp16x2 {e2:.2e}, fp32 MFMA {e0:.2e} of max |y|")
     assert e2 <= max(2e-6, 4 * e0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,npts", [(1, 16, 24, 37), (3, 32, 32, 700), (2, 64, 64, 3000)])
+def test_sparse_wgrad3x3_x2_vs_float64(dev, B, H, W, npts):
+    """df_sparse_wgrad3x3_x2 (bf16x2 products, 32 pixels per MFMA k step) against the float64 weight / bias gradient of the 3x3 conv with
+    an output gradient that is zero outside the listed cells, beside the fp32-MFMA form"""
+    from deflow_amd._lib import call, img, ptr, stream
+    g = torch.Generator().manual_seed(B * 10 + W)
+    x = torch.randn(B, H, W, 64, generator=g)
+    keys, counts = _sorted_cells(B, H, W, npts, 9, dev)
+    occ = torch.zeros(B * H * W, dtype=torch.bool)
+    occ[keys.cpu().long()] = True
+    dy = torch.randn(B, H, W, 64, generator=g) * occ.view(B, H, W, 1)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(64, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+    bref = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, wref, bref, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    want_w = wref.grad.permute(0, 2, 3, 1).contiguous()      # [O,kh,kw,I]
+    want_b = bref.grad
+    xg, dyg = x.to(dev), dy.to(dev)
+    nblk = 3
+    res = {}
+    for name in ("df_sparse_wgrad3x3_x2", "df_sparse_wgrad3x3"):
+        ws = torch.full((nblk * B, 64 * 9 * 64), float("nan"), device=dev)
+        bws = torch.full((nblk * B, 64), float("nan"), device=dev)
+        call(name, ptr(keys), ptr(counts), B, img(xg), img(dyg), ptr(ws), ptr(bws), nblk, stream())
+        torch.cuda.synchronize()
+        res[name] = (ws.double().sum(0).view(64, 3, 3, 64).cpu(), bws.double().sum(0).cpu())
+    sw, sb = float(want_w.abs().max()), float(want_b.abs().max())
+    ew2 = float((res["df_sparse_wgrad3x3_x2"][0] - want_w).abs().max()) / sw
+    ew0 = float((res["df_sparse_wgrad3x3"][0] - want_w).abs().max()) / sw
+    eb2 = float((res["df_sparse_wgrad3x3_x2"][1] - want_b).abs().max()) / sb
+    rms2 = float((res["df_sparse_wgrad3x3_x2"][0] - want_w).norm() / want_w.norm())
+    print(f"[parity] sparse_wgrad3x3 B={B} {H}x{W}: bf16x2 max {ew2:.2e} rms {rms2:.2e}, fp32 MFMA max {ew0:.2e}; bias {eb2:.2e}")
+    assert ew2 <= 2e-5 and rms2 <= 1e-5 and eb2 <= 2e-6
