@@ -8,6 +8,7 @@
 //   cell sort                     counting sort of caller-supplied cell keys for the stand-alone decoder head (pack_infos)
 // ([REF deflow.py:27-30,82-83]; the mmcv / OpenSceneFlow sources are absent -- the algorithm is restated in oracle/ref_torch.py.)
 // No float atomics anywhere: every sum has one fixed order.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -30,6 +31,15 @@ __device__ __forceinline__ SampleRange sample_range(const int32_t* __restrict__ 
   r.cnt = counts[b];
   return r;
 }
+
+// helpers of the 16-bit-MFMA forms of the sparse kernels (round 6): the fp16x2 scale of conv_common.h, and the 16-byte-slot swizzle
+// that makes one ds_read_b128 per weight fragment conflict-free (gemm_dma.h: g = (0, 2, 3, 1) over (row >> 2) & 3)
+__device__ __forceinline__ float sp_h2_scale(float amax) {
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
+  const int f = min(max(268 - e, 1), 254);
+  return __builtin_bit_cast(float, (unsigned)f << 23);
+}
+__device__ __forceinline__ int sp_g4(int x) { return (0x78 >> (2 * x)) & 3; }
 
 // reduce NV floats per lane across the 32 cell groups of a block (lanes with equal `sub`)
 template <int NV>
@@ -419,6 +429,193 @@ __global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_kernel(PillarGra
 }
 
 
+// ---- pillar_input_grad on the 16-bit matrix pipe, full batches (round 6, second session) ----------------------------------------
+// The form above spent its time in three places (B = 16: 0.25 ms per cloud for 22 GFLOP): batches a THIRD empty (a 64-point window
+// holds ~9 pillar heads per parity class: 16-row MFMA batches 56 % full), fp32 MFMAs (v_mfma_f32_16x16x4_f32: 32 cycles each, 43 % of
+// the launch) fed by scalar LDS weight reads, and one load round trip + one read-modify-write round trip per batch.  Here
+//  * every wave keeps a circular QUEUE of pillar heads per parity class in LDS and multiplies only FULL batches of 16 (the tails once,
+//    at the end of its range);
+//  * the products are bf16x3 -- both operands as three bf16 planes (8 + 8 + 8 mantissa bits: the fp32 value exactly), six
+//    v_mfma_f32_16x16x32_bf16 per 32-deep k step, the terms below 2^-24 dropped: fp32-rounding-exact like conv.hip's NP = 3 form, at
+//    a sixth of the fp32 pipe's cycles; the weights of both convs are split ONCE per workgroup into LDS planes
+//    [tap 0..8 | skip][plane][k step][c (32)][64 B] (120 KB), a B fragment = one ds_read_b128 (slot swizzle g, see sparse_conv3x3_h2_kernel);
+//  * the old output values (accumulate) are fetched WITH the batch's gradient rows.
+constexpr int PGQ = 128;                                  // queue capacity per wave and class (<= 15 left over + 64 new)
+constexpr int PG3_WT = 10 * 3 * 2 * 32 * 16;              // weight planes, floats
+typedef __bf16 bf16x8p_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void pg_split3(const f32x4 lo4, const f32x4 hi4, bf16x8p_t& h, bf16x8p_t& m, bf16x8p_t& l) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = k < 4 ? lo4[k & 3] : hi4[k & 3];
+    h[k] = (__bf16)v;
+    const float r1 = v - (float)h[k];
+    m[k] = (__bf16)r1;
+    l[k] = (__bf16)(r1 - (float)m[k]);
+  }
+}
+
+__global__ __launch_bounds__(PG_THREADS) void pillar_input_grad_x3_kernel(PillarGradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wt = lds;                                                   // [10][3][2][32][16 floats]
+  int* Queue = reinterpret_cast<int*>(Wt + PG3_WT);                  // [16 waves][4 classes][PGQ]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, g = p.cloud;
+  // ---- weights -> three bf16 planes.  piece i = (tap, k step, c, slot): the eight k values co = 32 ks + 8 slot + e of output channel c
+  for (int i = tid; i < 10 * 2 * 32 * 4; i += PG_THREADS) {
+    const int slot = i & 3, c = (i >> 2) & 31, ks = (i >> 7) & 1, tap = i >> 8;
+    f32x4 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int co = 32 * ks + 8 * slot + e;
+      const float w = tap < 9 ? p.w1[(co * 9 + tap) * 32 + c] : p.w3[co * 64 + 32 * g + c];
+      if (e < 4) v0[e] = w; else v1[e - 4] = w;
+    }
+    bf16x8p_t h, m, l;
+    pg_split3(v0, v1, h, m, l);
+    const int ps = slot ^ sp_g4((c >> 2) & 3);
+    float* d = Wt + (((tap * 3 + 0) * 2 + ks) * 32 + c) * 16 + ps * 4;
+    *reinterpret_cast<bf16x8p_t*>(d) = h;
+    *reinterpret_cast<bf16x8p_t*>(d + 2 * 32 * 16) = m;
+    *reinterpret_cast<bf16x8p_t*>(d + 2 * 2 * 32 * 16) = l;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  int* queue = Queue + wave * 4 * PGQ;
+  const int ncell = p.H * p.W, h2 = p.H >> 1, w2 = p.W >> 1;
+  const float* dy1 = p.dy1 + (int64_t)(g * p.B + b) * h2 * w2 * 64;
+  const float* dsk = reinterpret_cast<const float*>(p.dskip.ptr) + df_img_base(p.dskip, b);
+  float* out = reinterpret_cast<float*>(p.dcanvas.ptr) + df_img_base(p.dcanvas, b);
+  const SampleRange sr = sample_range(p.counts, b);
+  const int end = sr.off + sr.cnt;
+  auto lds_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  constexpr unsigned OOB = 0xF0000000u;
+  const __amdgpu_buffer_rsrc_t dskr = __builtin_amdgcn_make_buffer_rsrc((void*)dsk, 0, (unsigned)(((int64_t)(ncell - 1) * p.dskip.ld + 64) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)dy1, 0, (unsigned)((int64_t)h2 * w2 * 64 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t outr = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (unsigned)(((int64_t)(ncell - 1) * p.dcanvas.ld + 32) * 4), 0x00020000);
+  // a row's operand: channels 32 ks + 8 lq .. + 7 (k step ks) -> a4[2 ks], a4[2 ks + 1]
+  auto fetch_row = [&](__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 (&a4)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a4[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 128 * (k >> 1) + 16 * (k & 1), 0));
+  };
+  const float* wlane = Wt + (li * 4 + (lq ^ sp_g4((li >> 2) & 3))) * 4;   // row c = li (+ 16 nt) of a [32][64 B] tile, this lane's slot
+  auto mma_row = [&](const f32x4 (&a4)[4], int tap, f32x4 (&acc)[2]) {
+    const float* wt = wlane + tap * (3 * 2 * 32 * 16);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8p_t ah, am, al;
+      pg_split3(a4[2 * ks], a4[2 * ks + 1], ah, am, al);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float* wp = wt + (ks * 32 + 16 * nt) * 16;
+        const bf16x8p_t bh = *reinterpret_cast<const bf16x8p_t*>(wp);
+        const bf16x8p_t bm = *reinterpret_cast<const bf16x8p_t*>(wp + 2 * 32 * 16);
+        const bf16x8p_t bl = *reinterpret_cast<const bf16x8p_t*>(wp + 2 * 2 * 32 * 16);
+        f32x4 c = acc[nt];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);   // small terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+        acc[nt] = c;
+      }
+    }
+  };
+  // one batch: rows 0 .. nrows - 1 of class cls's queue, starting at its head qh
+  auto process = [&](int cls, int qh, int nrows) {
+    const int* qc = queue + cls * PGQ;
+    const int ky0 = cls >> 1, kx0 = cls & 1;
+    const int nky = ky0 ? 1 : 2, nkx = kx0 ? 1 : 2;
+    const int cell = li < nrows ? qc[(qh + li) & (PGQ - 1)] : -1;
+    int crow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) crow[r] = (4 * lq + r) < nrows ? qc[(qh + 4 * lq + r) & (PGQ - 1)] : -1;
+    const int y = cell / p.W, x = cell - y * p.W;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // rows of the batch: the skip gradient, then the class's reachable taps (iy, ix) ascending -- ONE row ahead of the products (all
+    // five rows in flight at once, as the fp32 form has them, is 80 registers beside the three-plane fragments: 133 spilled)
+    f32x4 cur[4], nxt[4];
+    fetch_row(dskr, cell >= 0 ? (unsigned)((cell * p.dskip.ld + 8 * lq) * 4) : OOB, cur);
+    float old[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        old[r][nt] = (p.accumulate && crow[r] >= 0)
+                         ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(outr, (unsigned)((crow[r] * p.dcanvas.ld + 16 * nt + li) * 4), 0, 0)) : 0.f;
+    const int ntap = nky * nkx;
+    // row j of the batch: j = 0 the skip gradient (weights "tap" 9), j = 1 .. ntap the class's taps (iy, ix) ascending; TWO rows ahead of
+    // the products (a row's products are ~0.3 us, its load round trip 1-2 us)
+    auto tap_of = [&](int k, int& tapid) -> unsigned {     // offset of tap k's row (k < ntap) or OOB
+      const int iy = nkx == 2 ? k >> 1 : k, ix = nkx == 2 ? k & 1 : 0;
+      const int ky = ky0 + 2 * iy, kx = kx0 + 2 * ix;
+      const int oy = (y + 1 - ky) >> 1, ox = (x + 1 - kx) >> 1;
+      const bool ok = cell >= 0 && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
+      tapid = ky * 3 + kx;
+      return ok ? (unsigned)(((oy * w2 + ox) * 64 + 8 * lq) * 4) : OOB;
+    };
+    f32x4 nx2[4];
+    int tap_cur = 9, tap_nxt, tap_nx2 = 0;
+    fetch_row(dyr, tap_of(0, tap_nxt), nxt);               // (a class has at least one tap)
+#pragma unroll 1
+    for (int j = 0; j <= ntap; ++j) {
+      if (j + 2 <= ntap) fetch_row(dyr, tap_of(j + 1, tap_nx2), nx2);
+      mma_row(cur, tap_cur, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { cur[q] = nxt[q]; nxt[q] = nx2[q]; }
+      tap_cur = tap_nxt;
+      tap_nxt = tap_nx2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (crow[r] < 0) continue;
+      float* o = out + (int64_t)crow[r] * p.dcanvas.ld + li;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) o[16 * nt] = old[r][nt] + acc[nt][r];
+    }
+  };
+
+  int qh = 0, qn = 0;       // four 8-bit fields each: head index (mod PGQ) and fill of the class queues
+  for (int base = sr.off + (blockIdx.x * (PG_THREADS / 64) + wave) * 64; base < end; base += gridDim.x * (PG_THREADS / 64) * 64) {
+    const int i = base + lane;
+    const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
+    const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
+    const int mycell = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    const int my_y = mycell / p.W, my_x = mycell - my_y * p.W;
+    const int mycls = (((my_y + 1) & 1) << 1) | ((my_x + 1) & 1);
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const unsigned long long m = __ballot(head && mycls == cls);
+      const int h_c = (qh >> (8 * cls)) & 255, n_c = (qn >> (8 * cls)) & 255;
+      if (head && mycls == cls) queue[cls * PGQ + ((h_c + n_c + (int)__popcll(m & ((1ull << lane) - 1))) & (PGQ - 1))] = mycell;
+      qn += (int)__popcll(m) << (8 * cls);
+    }
+    lds_fence();
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+      while (((qn >> (8 * cls)) & 255) >= 16) {
+        process(cls, (qh >> (8 * cls)) & 255, 16);
+        const int h_c = ((qh >> (8 * cls)) + 16) & (PGQ - 1);
+        qh = (qh & ~(255 << (8 * cls))) | (h_c << (8 * cls));
+        qn -= 16 << (8 * cls);
+      }
+    }
+    lds_fence();       // (the batches' queue reads are behind us before the next window appends)
+  }
+#pragma unroll 1
+  for (int cls = 0; cls < 4; ++cls) {
+    const int n_c = (qn >> (8 * cls)) & 255;
+    if (n_c > 0) process(cls, (qh >> (8 * cls)) & 255, n_c);
+  }
+#endif
+}
+
+
 // ------------------------------------------------------------------------------ sparse-output-gradient weight grad ---
 // The UNet's last conv (3x3, 64 -> 64 at full resolution) receives its output gradient from the decoder's gather
 // backward: exact zeros everywhere except at the cells pc0 points looked up (~20 % of H*W).  Its weight gradient
@@ -591,12 +788,17 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_x2_kernel(SparseWgradPara
   const int end = sr.off + sr.cnt;
   const unsigned long long lt = (1ull << lane) - 1ull;
   typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+  typedef float f32x2s_t __attribute__((ext_vector_type(2)));
   auto split8 = [&](const f32x4 (&r)[8], int c, bf16x8s_t& hi, bf16x8s_t& lo) {   // component c of the eight pixels' values
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = r[e][c];
-      hi[e] = (__bf16)v;
-      lo[e] = (__bf16)(v - (float)hi[e]);
+    for (int e = 0; e < 8; e += 2) {      // (pairs: the residual as ONE packed subtraction -- this file is built without the SLP vectoriser)
+      const f32x2s_t v = {r[e][c], r[e + 1][c]};
+      hi[e] = (__bf16)v[0];
+      hi[e + 1] = (__bf16)v[1];
+      const f32x2s_t h = {(float)hi[e], (float)hi[e + 1]};
+      const f32x2s_t d = v - h;
+      lo[e] = (__bf16)d[0];
+      lo[e + 1] = (__bf16)d[1];
     }
   };
   for (int base = sr.off + blockIdx.x * SW_WIN; base < end; base += gridDim.x * SW_WIN) {
@@ -614,7 +816,11 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_x2_kernel(SparseWgradPara
       const int i = base + 64 * w + lane;
       const bool head = i < wend && (i == sr.off || prev[w] != key[w]);
       const unsigned long long m = __ballot(head);
-      if (head) plist[n + (int)__popcll(m & lt)] = (int)(key[w] - (uint32_t)b * (uint32_t)ncell);
+      if (head) {      // (y << 16 | x: ONE division per pillar here instead of one per pixel, step and tap below -- 25 VALU instructions each)
+        const int cell = (int)(key[w] - (uint32_t)b * (uint32_t)ncell);
+        const int y = cell / p.W;
+        plist[n + (int)__popcll(m & lt)] = (y << 16) | (cell - y * p.W);
+      }
       n += (int)__popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -628,11 +834,13 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_x2_kernel(SparseWgradPara
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = s0 + 8 * lq + e;
-        const int cell = k < n ? plist[k] : -1;
-        const int y = cell / p.W, x = cell - y * p.W;
+        const int yx = plist[min(k, n - 1)];           // (n >= 1 here; branch-free: the entry of a missing pixel is not used)
+        const bool have = k < n;
+        const int y = yx >> 16, x = yx & 0xffff;
+        const int cell = y * p.W + x;
         const int qy = y + ty, qx = x + tx;
-        const bool okq = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
-        const unsigned ao = cell >= 0 ? (unsigned)((cell * p.dy.ld + 4 * li) * 4) : 0xF0000000u;
+        const bool okq = have && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+        const unsigned ao = have ? (unsigned)((cell * p.dy.ld + 4 * li) * 4) : 0xF0000000u;
         const unsigned bo = okq ? (unsigned)(((qy * p.W + qx) * p.x.ld + 4 * li) * 4) : 0xF0000000u;
         ra[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, ao, 0, 0));
         rb[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, bo, 0, 0));
@@ -658,6 +866,7 @@ __global__ __launch_bounds__(576) void sparse_wgrad3x3_x2_kernel(SparseWgradPara
           v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ct], bh, v, 0, 0, 0);
           acc[ct][nt] = v;
         }
+        __builtin_amdgcn_sched_barrier(0);   // (one column tile's fragments at a time: hoisting all four splits spilled 23 registers)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -827,12 +1036,6 @@ struct SparseConvH2Params {
   const float* amax_w;
 };
 typedef _Float16 f16x8s_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ float sp_h2_scale(float amax) {   // (conv_common.h's df_h2_scale)
-  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
-  const int f = min(max(268 - e, 1), 254);
-  return __builtin_bit_cast(float, (unsigned)f << 23);
-}
-__device__ __forceinline__ int sp_g4(int x) { return (0x78 >> (2 * x)) & 3; }
 
 __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseConvH2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1305,6 +1508,16 @@ extern "C" int df_pillar_input_grad(const uint32_t* key_sorted, const int32_t* c
   PillarGradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.accumulate = accumulate;
   p.dy1 = dy1; p.w1 = w1; p.dskip = dskip; p.w3 = w3; p.dcanvas = dcanvas;
+  // DF_PIG_X3=0: the fp32-MFMA form of rounds 3-5 (also taken when the skip gradient's rows are not 16-byte aligned)
+  static const bool x3 = !(getenv("DF_PIG_X3") && atoi(getenv("DF_PIG_X3")) == 0);
+  if (x3 && (dskip.ld % 4) == 0 && (dskip.img_stride % 4) == 0 && df_aligned16(dskip.ptr) && df_aligned16(dy1) && W < 65536 &&
+      (int64_t)H * W * dcanvas.ld < (int64_t)0x30000000) {
+    const size_t lds3 = (size_t)(PG3_WT + (PG_THREADS / 64) * 4 * PGQ) * sizeof(float);
+    DF_SET_LDS_ONCE((pillar_input_grad_x3_kernel), (int)lds3);
+    hipLaunchKernelGGL(pillar_input_grad_x3_kernel, dim3(nblk, B), dim3(PG_THREADS), lds3, reinterpret_cast<hipStream_t>(stream), p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   const size_t lds_bytes = (size_t)(9 * 64 * 32 + 64 * 32 + (PG_THREADS / 64) * 16) * sizeof(float);
   DF_SET_LDS_ONCE((pillar_input_grad_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(pillar_input_grad_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
