@@ -1213,25 +1213,30 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
       const bool mine = i < wend && (i == sr.off || prev[w] != key[w]) && (((y + 1 - ky) & 1) == 0) &&
                         (((x + 1 - kx) & 1) == 0) && oy >= 0 && oy < h2 && ox >= 0 && ox < w2;
       const unsigned long long m = __ballot(mine);
-      if (mine) plist[n + (int)__popcll(m & lt)] = cell;
+      if (mine) plist[n + (int)__popcll(m & lt)] = (y << 16) | x;      // (packed: no division per cell and step below)
       n += (int)__popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one step = 16 cells = four MFMA k steps: 24 loads, 32 MFMAs
+    // one step = 16 cells = four MFMA k steps: 12 loads, 32 MFMAs.  Round 6 (second session): tile (ct, nt) row m <-> output channel
+    // 4 m + ct, column n <-> input channel 2 n + nt, so a lane's four row-tile values are ONE 16-byte load of its cell's dy1 row and
+    // its two column-tile values two adjacent dwords of the canvas row (24 dword loads at 64-byte strides before); same products in the same order
     auto load_step = [&](int s0, float (&a)[4][4], float (&bv)[4][2]) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = s0 + 4 * u + lq;
-        const int c2 = k < n ? plist[k] : -1;
-        const int y2 = c2 / p.W, x2 = c2 - y2 * p.W;
-        const unsigned ao = c2 >= 0 ? (unsigned)(((((y2 + 1 - ky) >> 1) * w2 + ((x2 + 1 - kx) >> 1)) * 64 + li) * 4) : 0xF0000000u;
-        const unsigned bo = c2 >= 0 ? (unsigned)((c2 * p.canvas.ld + li) * 4) : 0xF0000000u;
+        const int yx = plist[min(k, n - 1)];
+        const bool have = k < n;
+        const int y2 = yx >> 16, x2 = yx & 0xffff;
+        const unsigned ao = have ? (unsigned)(((((y2 + 1 - ky) >> 1) * w2 + ((x2 + 1 - kx) >> 1)) * 64 + 4 * li) * 4) : 0xF0000000u;
+        const unsigned bo = have ? (unsigned)(((y2 * p.W + x2) * p.canvas.ld + 2 * li) * 4) : 0xF0000000u;
+        const f32x4 av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, ao, 0, 0));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, ao, 64 * t, 0));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 64 * t, 0));
+        for (int t = 0; t < 4; ++t) a[u][t] = av[t];
+        // (two dword loads of the pair: the 8-byte builtin came out of the compiler as ONE dword load feeding both column tiles)
+        bv[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 0, 0));
+        bv[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 4, 0));
       }
     };
     auto mma_step = [&](const float (&a)[4][4], const float (&bv)[4][2]) {
@@ -1259,12 +1264,15 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   float* o = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 * 9 * 32;
+  // acc[ct][nt][r] = dW[co = 4 (4 lq + r) + ct][tap][ci = 2 li + nt]
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[((16 * ct + 4 * lq + r) * 9 + tap) * 32 + 16 * nt + li] = acc[ct][nt][r];
+    for (int r = 0; r < 4; ++r) {
+      float* q = o + ((4 * (4 * lq + r) + ct) * 9 + tap) * 32 + 2 * li;
+      q[0] = acc[ct][0][r];
+      q[1] = acc[ct][1][r];
+    }
 #endif
 }
 
@@ -1599,6 +1607,8 @@ extern "C" int df_sparse_in_wgrad(const uint32_t* key_sorted, const int32_t* cou
   DF_REQUIRE(key_sorted && counts && dy1 && canvas.ptr && ws && B > 0 && nblk > 0 && (cloud == 0 || cloud == 1), DF_E_ARG);
   DF_REQUIRE((H % 2) == 0 && (W % 2) == 0 && canvas.n == B && canvas.h == H && canvas.w == W && canvas.c == 32, DF_E_SHAPE);
   DF_REQUIRE((int64_t)H * W * canvas.ld < (int64_t)0x30000000, DF_E_SHAPE);   // 32-bit byte offsets inside one sample
+  DF_REQUIRE(df_aligned16(dy1) && (((uintptr_t)canvas.ptr) & 7) == 0 && (canvas.ld % 2) == 0 && (canvas.img_stride % 2) == 0 && W < 65536,
+             DF_E_ALIGN);                                                    // 16-byte dy1 rows, 8-byte canvas pairs
   SparseInWgradParams p;
   p.key_sorted = key_sorted; p.counts = counts; p.B = B; p.H = H; p.W = W; p.cloud = cloud; p.dy1 = dy1; p.canvas = canvas;
   p.ws = ws;

@@ -1432,3 +1432,31 @@ def test_sparse_wgrad3x3_x2_vs_float64(dev, B, H, W, npts):
     rms2 = float((res["df_sparse_wgrad3x3_x2"][0] - want_w).norm() / want_w.norm())
     print(f"[parity] sparse_wgrad3x3 B={B} {H}x{W}: bf16x2 max {ew2:.2e} rms {rms2:.2e}, fp32 MFMA max {ew0:.2e}; bias {eb2:.2e}")
     assert ew2 <= 2e-5 and rms2 <= 1e-5 and eb2 <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,npts,cloud", [(1, 16, 24, 37, 0), (3, 32, 32, 700, 1), (2, 64, 64, 3000, 1)])
+def test_sparse_in_wgrad_vs_float64(dev, B, H, W, npts, cloud):
+    """df_sparse_in_wgrad (first encoder conv, 3x3 stride 2, 32 -> 64: weight gradient summed over the occupied cells of one cloud's
+    canvas) against the float64 weight gradient of the dense conv on a canvas that is zero outside those cells"""
+    from deflow_amd._lib import call, img, ptr, stream
+    g = torch.Generator().manual_seed(B * 10 + W + cloud)
+    keys, counts = _sorted_cells(B, H, W, npts, 11, dev)
+    occ = torch.zeros(B * H * W, dtype=torch.bool)
+    occ[keys.cpu().long()] = True
+    canvas = torch.randn(B, H, W, 64, generator=g)
+    canvas[..., 32 * cloud: 32 * cloud + 32] *= occ.view(B, H, W, 1)
+    dy1 = torch.randn(2 * B, H // 2, W // 2, 64, generator=g)
+    xin = canvas[..., 32 * cloud: 32 * cloud + 32].double().permute(0, 3, 1, 2)
+    wref = torch.zeros(64, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, wref, None, stride=2, padding=1).backward(dy1[cloud * B:(cloud + 1) * B].double().permute(0, 3, 1, 2))
+    want = wref.grad.permute(0, 2, 3, 1).contiguous()        # [O,kh,kw,I]
+    cv, dyg = canvas.to(dev), dy1.to(dev)
+    nblk = 3
+    ws = torch.full((nblk * B, 64 * 9 * 32), float("nan"), device=dev)
+    call("df_sparse_in_wgrad", ptr(keys), ptr(counts), B, H, W, cloud, ptr(dyg), img(cv, 32, 32 * cloud), ptr(ws), nblk, stream())
+    torch.cuda.synchronize()
+    got = ws.double().sum(0).view(64, 3, 3, 32).cpu()
+    e = float((got - want).abs().max() / want.abs().max())
+    print(f"[parity] sparse_in_wgrad B={B} {H}x{W} cloud {cloud}: {e:.2e}")
+    assert e <= 2e-6
