@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wt = lds;                                              // [9][2][2][64][16 floats = 64 B]
-  int* RowCell = reinterpret_cast<int*>(Wt + 9 * 2 * 2 * 64 * 16);     // [16 waves][16]
+  int* RowCell = reinterpret_cast<int*>(Wt + 9 * 2 * 2 * 64 * 16);     // [16 waves][PGQ]: each wave's circular queue of pillar heads
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   {  // 9216 16-byte pieces: piece i of the planes (linear in memory) = plane i / 4608, then (co, tap, k step, slot) = the digits of i % 4608
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-  int* rowcell = RowCell + wave * 16;
+  int* rowcell = RowCell + wave * PGQ;
   const int ncell = p.H * p.W;
   const float* xp = reinterpret_cast<const float*>(p.x.ptr) + df_img_base(p.x, b);
   float* yp = reinterpret_cast<float*>(p.y.ptr) + df_img_base(p.y, b);
@@ -1079,76 +1079,81 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
   const float* wlane = Wt + (li * 4 + (lq ^ sp_g4((li >> 2) & 3))) * 4;     // this lane's slot of row co = li (+ 16 nt) of a [64][64 B] tile
   const int nchunk = (sr.cnt + 63) / 64, per = (nchunk + (int)gridDim.x - 1) / (int)gridDim.x;
   const int c_lo = blockIdx.x * per, c_hi = min(c_lo + per, nchunk);
+  // FULL batches (round 6, second session): pillar heads go through a circular queue per wave and are multiplied sixteen at a time -- a
+  // 64-point window holds ~35 heads, i.e. batches of 16, 16 and 3: a third of the products multiplied empty rows; the tail once, at the end
+  auto process = [&](int qh, int nrows) {
+    const int cell = li < nrows ? rowcell[(qh + li) & (PGQ - 1)] : -1;
+    int crow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) crow[r] = (4 * lq + r) < nrows ? rowcell[(qh + 4 * lq + r) & (PGQ - 1)] : -1;
+    const int y = cell / p.W, x = cell - y * p.W;
+    f32x4 acc[4], acc1[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // A rows of tap t + 1 are fetched while tap t is multiplied: a4[2 ks], a4[2 ks + 1] = channels 32 ks + 8 lq .. + 7
+    auto fetch = [&](int tap, f32x4 (&a4)[4]) {
+      const int qy = y + tap / 3 - 1, qx = x + tap % 3 - 1;
+      const bool ok = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
+      const float* src = xp + (int64_t)(ok ? qy * p.W + qx : 0) * p.x.ld + 8 * lq;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a4[k] = ok ? ld4(src + 32 * (k >> 1) + 4 * (k & 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 a_cur[4], a_nxt[4];
+    fetch(0, a_cur);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) fetch(tap + 1, a_nxt);
+      f16x8s_t ah[2], al[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = a_cur[2 * ks + (e >> 2)][e & 3] * sx;
+          ah[ks][e] = (_Float16)t;
+          al[ks][e] = (_Float16)((t - (float)ah[ks][e]) * 2048.f);
+        }
+      const float* wt = wlane + tap * (2 * 2 * 64 * 16);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const f16x8s_t bh = *reinterpret_cast<const f16x8s_t*>(wt + (ks * 64 + 16 * nt) * 16);
+          const f16x8s_t bl = *reinterpret_cast<const f16x8s_t*>(wt + ((2 + ks) * 64 + 16 * nt) * 16);
+          acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc1[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[nt], 0, 0, 0);
+          acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc1[nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a_cur[k] = a_nxt[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (crow[r] < 0) continue;
+      float* o = yp + (int64_t)crow[r] * p.y.ld + li;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) o[16 * nt] = fmaf(fmaf(acc1[nt][r], 1.f / 2048.f, acc[nt][r]), inv, bia[nt]);
+    }
+  };
+  int qh = 0, qn = 0;
   for (int base = sr.off + (c_lo + wave) * 64; base < sr.off + c_hi * 64; base += (PG_THREADS / 64) * 64) {
     const int i = base + lane;
     const uint32_t key = i < end ? p.key_sorted[i] : 0xffffffffu;
     const bool head = i < end && (i == sr.off || p.key_sorted[i - 1] != key);
-    const int mycell = (int)(key - (uint32_t)b * (uint32_t)ncell);
-    unsigned long long m = __ballot(head);
-    while (m) {   // batches of up to 16 cells
-      const bool in = (m >> lane) & 1;
-      const int rank = __popcll(m & ((1ull << lane) - 1));
-      if (in && rank < 16) rowcell[rank] = mycell;
-      const int nrows = min(16, (int)__popcll(m));
-      m = __ballot(in && rank >= 16);
-      lds_fence();
-      const int cell = li < nrows ? rowcell[li] : -1;
-      int crow[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) crow[r] = (4 * lq + r) < nrows ? rowcell[4 * lq + r] : -1;
-      lds_fence();
-      const int y = cell / p.W, x = cell - y * p.W;
-      f32x4 acc[4], acc1[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      // A rows of tap t + 1 are fetched while tap t is multiplied: a4[2 ks], a4[2 ks + 1] = channels 32 ks + 8 lq .. + 7
-      auto fetch = [&](int tap, f32x4 (&a4)[4]) {
-        const int qy = y + tap / 3 - 1, qx = x + tap % 3 - 1;
-        const bool ok = cell >= 0 && qy >= 0 && qy < p.H && qx >= 0 && qx < p.W;
-        const float* src = xp + (int64_t)(ok ? qy * p.W + qx : 0) * p.x.ld + 8 * lq;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = ok ? ld4(src + 32 * (k >> 1) + 4 * (k & 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      };
-      f32x4 a_cur[4], a_nxt[4];
-      fetch(0, a_cur);
-#pragma unroll 1
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) fetch(tap + 1, a_nxt);
-        f16x8s_t ah[2], al[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float t = a_cur[2 * ks + (e >> 2)][e & 3] * sx;
-            ah[ks][e] = (_Float16)t;
-            al[ks][e] = (_Float16)((t - (float)ah[ks][e]) * 2048.f);
-          }
-        const float* wt = wlane + tap * (2 * 2 * 64 * 16);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const f16x8s_t bh = *reinterpret_cast<const f16x8s_t*>(wt + (ks * 64 + 16 * nt) * 16);
-            const f16x8s_t bl = *reinterpret_cast<const f16x8s_t*>(wt + ((2 + ks) * 64 + 16 * nt) * 16);
-            acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh, acc1[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[nt], 0, 0, 0);
-            acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl, acc1[nt], 0, 0, 0);
-          }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a_cur[k] = a_nxt[k];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (crow[r] < 0) continue;
-        float* o = yp + (int64_t)crow[r] * p.y.ld + li;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) o[16 * nt] = fmaf(fmaf(acc1[nt][r], 1.f / 2048.f, acc[nt][r]), inv, bia[nt]);
-      }
+    const unsigned long long m = __ballot(head);
+    if (head) rowcell[(qh + qn + (int)__popcll(m & ((1ull << lane) - 1))) & (PGQ - 1)] = (int)(key - (uint32_t)b * (uint32_t)ncell);
+    qn += (int)__popcll(m);
+    lds_fence();
+    while (qn >= 16) {
+      process(qh, 16);
+      qh = (qh + 16) & (PGQ - 1);
+      qn -= 16;
     }
+    lds_fence();
   }
+  if (qn > 0) process(qh, qn);
 #endif
 }
 
@@ -1594,7 +1599,7 @@ extern "C" int df_sparse_conv3x3_h2(const uint32_t* key_sorted, const int32_t* c
   SparseConvH2Params p;
   p.key_sorted = key_sorted; p.counts = counts; p.H = y.h; p.W = y.w; p.x = x; p.y = y; p.w2 = w2; p.bias = bias;
   p.amax_x = x_amax; p.amax_w = w_amax;
-  const size_t lds_bytes = (size_t)(9 * 2 * 2 * 64 * 16 + (PG_THREADS / 64) * 16) * sizeof(float);
+  const size_t lds_bytes = (size_t)(9 * 2 * 2 * 64 * 16 + (PG_THREADS / 64) * PGQ) * sizeof(float);
   DF_SET_LDS_ONCE((sparse_conv3x3_h2_kernel), (int)lds_bytes);
   hipLaunchKernelGGL(sparse_conv3x3_h2_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
