@@ -1058,6 +1058,7 @@ def test_sparse_edge_kernels_match_dense(B, N, grid):
 _X3_OFF = {"DF_CONV_X3": "0", "DF_WGRAD_X3": "0"}      # the fp32-MFMA kernels the bf16x3 forms replaced by default (round 3)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("env", [{"DF_CONV_NO_DMA": "1", "DF_CONV_WIDE_EPI": "1", "DF_GRU_V1": "1", "DF_GRU_WGRAD_V1": "1", **_X3_OFF},
                                  {"DF_WGRAD_DMA_ALL": "1", "DF_CONV_HALO": "0", "DF_DENSE_CANVAS_GRAD": "1", "DF_GRU_X2": "0", **_X3_OFF},
                                  {"DF_WGRAD_RING": "0", "DF_WGRAD_RING_S2": "0", "DF_CONV_W8": "0", "DF_CONV_HALO": "0", "DF_SIDE_STREAM": "1", **_X3_OFF},
@@ -1638,6 +1639,7 @@ def test_bench_line_contract(dev):
     assert "cpu_baseline" not in d   # --no-cpu-baseline
 
 
+@pytest.mark.slow
 def test_bench_hung_extra_leg_still_prints_the_headline(dev):
     """at N > 1 every extra leg behind the timed region runs under a wall-clock budget; a leg that hangs (test hook:
     the one-bucket leg sleeps forever on both ranks) ends the run with the HEADLINE line, `extras_aborted` naming the leg -- not with
@@ -1657,6 +1659,7 @@ def test_bench_hung_extra_leg_still_prints_the_headline(dev):
     assert d["extras_aborted"]["leg"] == "one_bucket" and "allreduce_buckets" in d["extras_aborted"]["legs_completed"]
 
 
+@pytest.mark.slow
 def test_bench_two_ranks_share_the_gpu(dev):
     """`python bench.py --gpus 2` started bare -- the way the driver starts it -- with the real kernels: the file launches its own
     two ranks, both on this box's one GPU with gloo carrying the collectives (DF_BENCH_SHARE_GPU test hook; RCCL refuses two ranks

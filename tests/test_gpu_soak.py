@@ -115,6 +115,7 @@ def test_pfn_backward_is_bit_reproducible_beside_the_gru_forward(dev, lean):
     assert nbad == 0, f"{nbad} of {reps} repetitions differ from the first (worst rel {worst:.2e}) beside {ran} neighbour launches"
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_training_step_is_bit_reproducible_beside_the_gru_forward(dev, dtype, monkeypatch):
     """the whole step (lr = 0: the same problem every time), weight gradients on the side stream, gradient arena compared bit for bit"""
