@@ -232,9 +232,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
   int nky = p.ks, nkx = p.ks, ky0 = 0, kx0 = 0;
   const bool fwd = p.mode == DF_CONV_FWD;
   if (dec.cls_mode) {
-    const int cls = tile_m / p.cls_tiles;
+    const int cls = p.cls_il ? (tile_m & 3) : tile_m / p.cls_tiles;
     dec.py = cls >> 1; dec.px = cls & 1;
-    m0 = (tile_m - cls * p.cls_tiles) * BM;
+    m0 = (p.cls_il ? (tile_m >> 2) : (tile_m - cls * p.cls_tiles)) * BM;
     m_end = p.y.n * dec.hh * dec.wh;
     ky0 = (dec.py + p.pad) & 1; kx0 = (dec.px + p.pad) & 1;
     nky = (p.ks - ky0 + 1) >> 1; nkx = (p.ks - kx0 + 1) >> 1;
@@ -1551,6 +1551,8 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.bwd_ss = bwd_ss;
   static const int conv_rot = getenv("DF_CONV_ROT") ? atoi(getenv("DF_CONV_ROT")) : 1;
   p.rot = conv_rot;
+  static const int cls_il = getenv("DF_CONV_CLS_IL") ? atoi(getenv("DF_CONV_CLS_IL")) : 1;
+  p.cls_il = cls_il;
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);

@@ -78,6 +78,11 @@ struct ConvParams {
   const float* bwd_y;
   const float* bwd_ss;
   int rot;  // conv_halo_x3_kernel: rotated tap-row order (see there); env DF_CONV_ROT=0 restores the plain order
+  // stride-2 dgrad (cls_tiles > 0): tile -> parity class INTERLEAVED (class = tile & 3) instead of class-major (round 6, second session).
+  // A class writes every other 256-byte pixel of every other row: with all workgroups of the chip on ONE class at a time the stores
+  // (and the accumulate epilogue's loads) hit half of the memory channels; interleaved, the four classes of a region are in flight
+  // together and their lines fill whole rows.  env DF_CONV_CLS_IL=0 restores the class-major order.
+  int cls_il;
 };
 constexpr int DF_EPI_BWD_STATS = 3;
 __host__ __device__ inline bool epi_stats(int epi) { return epi == DF_EPI_STATS || epi == DF_EPI_BWD_STATS; }
