@@ -57,6 +57,7 @@ _SIGS = {
     "df_sparse_in_wgrad": [P, P, I, I, I, I, P, DfImg, P, I, P],
     "df_sparse_conv3x3": [P, P, I, DfImg, P, P, DfImg, I, P],
     "df_sparse_conv3x3_h2": [P, P, I, DfImg, P, P, P, P, DfImg, I, P],
+    "df_sparse_conv3x3_bf16": [P, P, I, DfImg, P, P, DfImg, I, P],
     "df_sparse_wgrad3x3": [P, P, I, DfImg, DfImg, P, P, I, P],
     "df_sparse_wgrad3x3_x2": [P, P, I, DfImg, DfImg, P, P, I, P],
     "df_pillar_input_grad": [P, P, I, I, I, I, P, P, DfImg, P, DfImg, I, I, P],

@@ -1037,6 +1037,10 @@ struct SparseConvH2Params {
 };
 typedef _Float16 f16x8s_t __attribute__((ext_vector_type(8)));
 
+// B16 (bf16-operand training mode, BASELINE configs[4] "bf16 MFMA"): ONE bf16 plane per operand, one v_mfma_f32_16x16x32_bf16 per k step
+// -- what the mode's other convolutions compute; p.w2 then points at the fp32 weights [co][tap][ci], rounded to bf16 as they enter LDS
+// ([tap][k step][co][64 B], 73 KB), amax_x / amax_w unused.
+template <bool B16>
 __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseConvH2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1044,7 +1048,19 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
   int* RowCell = reinterpret_cast<int*>(Wt + 9 * 2 * 2 * 64 * 16);     // [16 waves][PGQ]: each wave's circular queue of pillar heads
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  {  // 9216 16-byte pieces: piece i of the planes (linear in memory) = plane i / 4608, then (co, tap, k step, slot) = the digits of i % 4608
+  if constexpr (B16) {   // 4608 pieces of eight consecutive ci: (co, tap, k step, slot) = the digits of i
+    typedef __bf16 bf16x8w_t __attribute__((ext_vector_type(8)));
+    const float* wf = reinterpret_cast<const float*>(p.w2);
+    for (int i = tid; i < 4608; i += PG_THREADS) {
+      const f32x4 v0 = ld4(wf + i * 8), v1 = ld4(wf + i * 8 + 4);
+      bf16x8w_t h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v0[e]; h[4 + e] = (__bf16)v1[e]; }
+      const int co = i / 72, r2 = i - co * 72;
+      const int tap = r2 >> 3, ks = (r2 >> 2) & 1, sl = r2 & 3;
+      *reinterpret_cast<bf16x8w_t*>(Wt + (((tap * 2 + ks) * 64 + co) * 4 + (sl ^ sp_g4((co >> 2) & 3))) * 4) = h;
+    }
+  } else {  // 9216 16-byte pieces: piece i of the planes (linear in memory) = plane i / 4608, then (co, tap, k step, slot) = the digits of i % 4608
     f32x4 wv[9];
     const float* w2f = reinterpret_cast<const float*>(p.w2);
 #pragma unroll
@@ -1066,7 +1082,8 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
   float* yp = reinterpret_cast<float*>(p.y.ptr) + df_img_base(p.y, b);
   const SampleRange sr = sample_range(p.counts, b);
   const int end = sr.off + sr.cnt;
-  const float sx = sp_h2_scale(*p.amax_x), sw = sp_h2_scale(*p.amax_w);
+  float sx = 1.f, sw = 1.f;
+  if constexpr (!B16) { sx = sp_h2_scale(*p.amax_x); sw = sp_h2_scale(*p.amax_w); }
   const float inv = (1.f / sx) * (1.f / sw);
   float bia[4];
 #pragma unroll
@@ -1106,6 +1123,23 @@ __global__ __launch_bounds__(PG_THREADS) void sparse_conv3x3_h2_kernel(SparseCon
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) fetch(tap + 1, a_nxt);
+      if constexpr (B16) {
+        typedef __bf16 bf16x8w_t __attribute__((ext_vector_type(8)));
+        bf16x8w_t a8[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a8[ks][e] = (__bf16)a_cur[2 * ks + (e >> 2)][e & 3];
+        const float* wt = wlane + tap * (2 * 64 * 16);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[ks], *reinterpret_cast<const bf16x8w_t*>(wt + (ks * 64 + 16 * nt) * 16), acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a_cur[k] = a_nxt[k];
+        continue;
+      }
       f16x8s_t ah[2], al[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1600,8 +1634,27 @@ extern "C" int df_sparse_conv3x3_h2(const uint32_t* key_sorted, const int32_t* c
   p.key_sorted = key_sorted; p.counts = counts; p.H = y.h; p.W = y.w; p.x = x; p.y = y; p.w2 = w2; p.bias = bias;
   p.amax_x = x_amax; p.amax_w = w_amax;
   const size_t lds_bytes = (size_t)(9 * 2 * 2 * 64 * 16 + (PG_THREADS / 64) * PGQ) * sizeof(float);
-  DF_SET_LDS_ONCE((sparse_conv3x3_h2_kernel), (int)lds_bytes);
-  hipLaunchKernelGGL(sparse_conv3x3_h2_kernel, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
+  DF_SET_LDS_ONCE((sparse_conv3x3_h2_kernel<false>), (int)lds_bytes);
+  hipLaunchKernelGGL(sparse_conv3x3_h2_kernel<false>, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  DF_CHECK_LAUNCH();
+  return DF_OK;
+}
+
+// the bf16-operand form (mixed-precision training, Trainer(dtype="bf16")): x and w (fp32 [64,3,3,64]) rounded to bf16 on the way to the
+// matrix pipe, fp32 accumulation -- what df_conv2d_w16 computes for the dense layers of that mode
+extern "C" int df_sparse_conv3x3_bf16(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const float* w,
+                                      const float* bias, df_img y, int nblk, void* stream) {
+  DF_REQUIRE(key_sorted && counts && x.ptr && y.ptr && w && df_aligned16(w) && B > 0 && nblk > 0, DF_E_ARG);
+  DF_REQUIRE(x.n == B && y.n == B && x.c == 64 && y.c == 64 && x.h == y.h && x.w == y.w && (x.ld % 4) == 0 &&
+                 df_aligned16(x.ptr) && x.grp_size == x.n && y.grp_size == y.n && x.elt == 0 && y.elt == 0,
+             DF_E_SHAPE);
+  SparseConvH2Params p;
+  p.key_sorted = key_sorted; p.counts = counts; p.H = y.h; p.W = y.w; p.x = x; p.y = y; p.w2 = w; p.bias = bias;
+  p.amax_x = nullptr; p.amax_w = nullptr;
+  const size_t lds_bytes = (size_t)(9 * 2 * 2 * 64 * 16 + (PG_THREADS / 64) * PGQ) * sizeof(float);   // (the two-plane size: the queue sits behind it)
+  DF_SET_LDS_ONCE((sparse_conv3x3_h2_kernel<true>), (int)lds_bytes);
+  hipLaunchKernelGGL(sparse_conv3x3_h2_kernel<true>, dim3(nblk, B), dim3(PG_THREADS), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), p);
   DF_CHECK_LAUNCH();
   return DF_OK;

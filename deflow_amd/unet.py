@@ -212,6 +212,9 @@ class FastFlow3DUNet(nn.Module):
                 w2, wa = ops._split_h2(ops.ohwi(m4.weight))
                 call("df_sparse_conv3x3_h2", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, ui, ptr(w2), ptr(ops.amax_of(ui, dev)),
                      ptr(wa), ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
+            elif ops.MFMA_BF16 and _SPARSE_H2:       # bf16-operand mode: one bf16 plane per operand, as that mode's dense convolutions
+                call("df_sparse_conv3x3_bf16", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, img(u), ptr(ops.ohwi(m4.weight)),
+                     ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())
             else:
                 call("df_sparse_conv3x3", ptr(out_cells.key_sorted), ptr(out_cells.counts), B, img(u), ptr(ops.ohwi(m4.weight)),
                      ptr(m4.bias.detach()), img(v), max(1, 256 // B), stream())

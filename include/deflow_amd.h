@@ -167,6 +167,9 @@ int df_sparse_conv3x3(const uint32_t* key_sorted, const int32_t* counts, int B, 
  * x_amax = a bound of max |x| (device scalars).  Same cells, same result class as df_sparse_conv3x3. */
 int df_sparse_conv3x3_h2(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const void* w2,
                          const float* x_amax, const float* w_amax, const float* bias, df_img y, int nblk, void* stream);
+/* ... with bf16 operands (the bf16-operand training mode: x and w rounded to bf16 on the way to the matrix pipe, fp32 accumulation). */
+int df_sparse_conv3x3_bf16(const uint32_t* key_sorted, const int32_t* counts, int B, df_img x, const float* w,
+                           const float* bias, df_img y, int nblk, void* stream);
 
 /* Weight gradient of the first encoder conv (3x3, stride 2, pad 1, 32 -> 64; dy1 [2B,H/2,W/2,64], image = cloud*B + b)
  * summed over the occupied cells of one cloud's canvas [B,H,W,32] only.  ws [nblk*B][64][9][32] partials; finish with
