@@ -77,6 +77,7 @@ _SIGS = {
     "df_conv2d_amax": [DfImg, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2f": [DfImg, P, P, P, P, DfImg, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2f_wp": [DfImg, P, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P, P],
+    "df_conv2d_h2f_wp_up": [DfImg, P, P, P, P, P, DfImg, P, DfImg, I, P],
     "df_conv2d_h2p": [DfImg, P, P, P, P, DfImg, P, I, I, I, I, I, P, P, P, I, P, P],
     "df_conv2d_h2p_ok": [DfImg, DfImg, I, I, I, I],
     "df_conv2d_h2p_dgrad_bn": [DfImg, P, P, P, DfImg, P, P, P, P, P],

@@ -198,7 +198,70 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 // fragment (4 of 8 waves on the 128 x 64 tile) at ~50 VALU instructions per 8 values: the kernel was VALU-bound 4 : 1 against
 // its MFMAs on the 32 x 32 wave tiles.  A lane's 8 k values are CONSECUTIVE in this form (k = 16 q + 8 kh ..+7: the A slots
 // change to match); same products, another order inside the MFMA's 16-deep sum.
-template <int BM, int BN, int WM, int WN, bool BF = false, bool H2 = false, bool BP = false>
+// ---- UPS: the bilinear x2 half of an UpsampleSkip concatenation written by the skip convolution's workgroups (ConvParams::ups_t) ----
+// PyTorch area_pixel_compute_source_index and the interpolation expression of elementwise.hip's upsample2x8_kernel (same values);
+// eight channels per item, 16-byte plane stores
+struct UpsLerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ UpsLerp ups_src(int dst, int in, int out, int align_corners) {
+  float src;
+  if (align_corners) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = sc * dst;
+  } else {
+    src = ((float)dst + 0.5f) * ((float)in / (float)out) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  UpsLerp r;
+  r.i0 = (int)src;
+  if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void ups_tile(const ConvParams& p, const RowDecode& dec, int m0, int m_end, int n0, int tid) {
+  const float ys = df_h2_scale(*p.bound_y);
+  const df_img& t = p.ups_t;
+  const float* __restrict__ tp = reinterpret_cast<const float*>(t.ptr);
+  char* y0 = reinterpret_cast<char*>(p.y.ptr) - (int64_t)t.c * 4;     // the concatenation's first half: t.c channels in front of y's
+  constexpr int G = BN / 8;
+  for (int it = tid; it < BM * G; it += NT) {
+    const int r = it / G, c = n0 + (it - r * G) * 8;
+    const int m = m0 + r;
+    if (m >= m_end) continue;
+    int n, Y, X;
+    dec(m, n, Y, X);
+    const UpsLerp ly = ups_src(Y, t.h, p.y.h, p.ups_ac), lx = ups_src(X, t.w, p.y.w, p.ups_ac);
+    const float* b = tp + df_img_base(t, n) + c;
+    const float* p00 = b + ((int64_t)ly.i0 * t.w + lx.i0) * t.ld;
+    const float* p01 = b + ((int64_t)ly.i0 * t.w + lx.i1) * t.ld;
+    const float* p10 = b + ((int64_t)ly.i1 * t.w + lx.i0) * t.ld;
+    const float* p11 = b + ((int64_t)ly.i1 * t.w + lx.i1) * t.ld;
+    const f32x4 a00 = ld4(p00), a01 = ld4(p01), a10 = ld4(p10), a11 = ld4(p11);
+    const f32x4 b00 = ld4(p00 + 4), b01 = ld4(p01 + 4), b10 = ld4(p10 + 4), b11 = ld4(p11 + 4);
+    const f32x4 o0 = ly.l0 * (lx.l0 * a00 + lx.l1 * a01) + ly.l1 * (lx.l0 * a10 + lx.l1 * a11);
+    const f32x4 o1 = ly.l0 * (lx.l0 * b00 + lx.l1 * b01) + ly.l1 * (lx.l0 * b10 + lx.l1 * b11);
+    f16x8_t hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t0 = o0[k] * ys, t1 = o1[k] * ys;
+      hi[k] = (_Float16)t0;
+      lo[k] = (_Float16)((t0 - (float)hi[k]) * H2_LO);
+      hi[4 + k] = (_Float16)t1;
+      lo[4 + k] = (_Float16)((t1 - (float)hi[4 + k]) * H2_LO);
+    }
+    const int64_t idx = df_img_base(p.y, n) + ((int64_t)Y * p.y.w + X) * p.y.ld + c;
+    char* q = y0 + (idx & ~31ll) * 4 + (idx & 31) * 2;
+    *reinterpret_cast<f16x8_t*>(q) = hi;
+    *reinterpret_cast<f16x8_t*>(q + 64) = lo;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool BF = false, bool H2 = false, bool BP = false, bool UPS = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass; the host stub needs no body
   static_assert(!(BF && H2), "one operand format");
@@ -432,6 +495,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dma_kernel(ConvParams p) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] + acc1[i][j][e] * H2_LO_INV) * ix * iw;
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, lds, dec, m0, m_end, n0, tile_m);
+  if constexpr (UPS) ups_tile<BM, BN, 64 * WM * WN>(p, dec, m0, m_end, n0, tid);
 #endif
 }
 
@@ -1279,6 +1343,13 @@ static int launch_conv_w8(const ConvParams& p, hipStream_t s) {
     DF_CHECK_LAUNCH();
     return DF_OK;
   }
+  if (p.ups_on) {                        // ... and the bilinear half of the concatenation written by the same workgroups
+    DF_REQUIRE(p.amax_x && p.amax_w && p.w2p, DF_E_ARG);
+    DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, false, true, true, true>), (int)lds_bytes);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, false, true, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
+    DF_CHECK_LAUNCH();
+    return DF_OK;
+  }
   if (p.amax_x && p.amax_w && p.w2p) {   // ... with the weights pre-split
     DF_SET_LDS_ONCE((conv_dma_kernel<BM, BN, WM, WN, false, true, true>), (int)lds_bytes);
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, false, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), lds_bytes, s, p);
@@ -1343,7 +1414,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3 = nullptr,
                        const float* h2_amax_x = nullptr, const float* h2_amax_w = nullptr, float* y_amax = nullptr,
                        const float* y_bound = nullptr, const float* bwd_y = nullptr, const float* bwd_ss = nullptr,
-                       const void* w2p = nullptr);
+                       const void* w2p = nullptr, const df_img* ups_t = nullptr, int ups_ac = 0);
 
 extern "C" int df_conv2d_mp(df_img x, const float* w, const float* bias, df_img y, int ksize, int stride, int pad,
                             int mode, int epi, const float* scale, const float* shift, float* stats_partial,
@@ -1437,6 +1508,18 @@ extern "C" int df_conv2d_h2f_wp(df_img x, const float* w, const void* w2, const 
                      nullptr, x_amax, w_amax, y.elt == 2 ? nullptr : y_amax, y.elt == 2 ? y_bound : nullptr, nullptr, nullptr, w2);
 }
 
+// df_conv2d_h2f_wp for the 1x1 skip convolution of an UpsampleSkip block (forward, bias epilogue, y = the SECOND half of the pre-split
+// concatenation: channels [t.c, 2 t.c) of a pixel whose first t.c channels precede y.ptr) that ALSO writes the first half: the bilinear
+// x2 of t [N, H / 2, W / 2, C] (fp32; align_corners as F.interpolate), scaled by the same bound *y_bound (>= max |t| as well) -- one
+// kernel writes whole pixels of the concatenation instead of two kernels one half each.  Replaces df_upsample2x_h2 + df_conv2d_h2f_wp;
+// DF_E_SHAPE where the 8-wave DMA kernels with pre-split weights do not cover the call (the caller then issues the two launches).
+extern "C" int df_conv2d_h2f_wp_up(df_img x, const float* w, const void* w2, const float* x_amax, const float* w_amax, const float* bias,
+                                   df_img y, const float* y_bound, df_img t, int align_corners, void* stream) {
+  DF_REQUIRE(x_amax && w_amax && w2 && df_aligned16(w2) && y.elt == 2 && y_bound, DF_E_ARG);
+  return conv2d_impl(x, w, nullptr, bias, y, 1, 1, 0, DF_CONV_FWD, DF_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, false, stream, nullptr, x_amax,
+                     w_amax, nullptr, y_bound, nullptr, nullptr, w2, &t, align_corners);
+}
+
 extern "C" int df_conv2d_yh2(df_img x, const float* w, const float* x_amax, const float* w_amax, const float* bias, df_img y,
                              const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale,
                              const float* shift, float* stats_partial, int accumulate, void* stream) {
@@ -1509,7 +1592,7 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
                        int mode, int epi, const float* scale, const float* shift, float* stats_partial,
                        int accumulate, int mfma_bf16, bool query, void* stream, const void* w3, const float* h2_amax_x,
                        const float* h2_amax_w, float* y_amax, const float* y_bound, const float* bwd_y, const float* bwd_ss,
-                       const void* w2p) {
+                       const void* w2p, const df_img* ups_t, int ups_ac) {
   if (w3) w = reinterpret_cast<const float*>(w3);   // (argument checks below want a non-null, aligned weight pointer)
   // bfloat16 tensors (bf16-storage training): the input only for the bf16-tile kernel (df_conv2d_w16), the output for any
   // kernel with the branch-free epilogue
@@ -1553,6 +1636,17 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
   p.rot = conv_rot;
   static const int cls_il = getenv("DF_CONV_CLS_IL") ? atoi(getenv("DF_CONV_CLS_IL")) : 1;
   p.cls_il = cls_il;
+  p.ups_on = 0; p.ups_ac = ups_ac;
+  if (ups_t) {   // df_conv2d_h2f_wp_up: a 1x1 forward conv into the second half of a pre-split concatenation, fp32 t of half the resolution
+    const df_img& t = *ups_t;
+    DF_REQUIRE(!w3 && !w16 && ksize == 1 && stride == 1 && mode == DF_CONV_FWD && epi == DF_EPI_BIAS && !accumulate && y.elt == 2 && x.elt == 0 &&
+                   w2p && h2_amax_x && h2_amax_w && !mfma_bf16, DF_E_ARG);
+    DF_REQUIRE(t.ptr && df_aligned16(t.ptr) && t.elt == 0 && t.n == y.n && t.c == y.c && 2 * t.h == y.h && 2 * t.w == y.w && (t.c % 8) == 0 &&
+                   (t.ld % 4) == 0 && (t.img_stride % 4) == 0 && (t.grp_off % 4) == 0 && t.grp_size > 0 && (y.ld % 32) == 0 && y.ld >= 2 * y.c,
+               DF_E_SHAPE);
+    p.ups_t = t;
+    p.ups_on = 1;
+  }
   p.hw_y = y.h * y.w;
   const int64_t M = (int64_t)y.n * p.hw_y;
   DF_REQUIRE(M < (1ll << 31), DF_E_SHAPE);
@@ -1740,6 +1834,16 @@ static int conv2d_impl(df_img x, const float* w, const void* w16, const float* b
     return (w4 & 2) ? launch_conv_halo_w16<64, 2, 2, 2>(p, s) : launch_conv_halo_w16<64, 4, 2, 2>(p, s);
   }
   DF_REQUIRE(x.elt == 0, DF_E_ARG);
+  if (p.ups_on) {      // only the 8-wave DMA kernels with pre-split weights carry the UPS form
+    DF_REQUIRE(p.x_bytes && p.w2p && p.amax_x && p.amax_w && !p.bf16, DF_E_SHAPE);
+    switch (var) {
+      case 128032: return launch_conv_w8<128, 32, 4, 1>(p, s);
+      case 64064: return launch_conv_w8<64, 64, 2, 2>(p, s);
+      case 128128: return launch_conv_w8<128, 128, 4, 2>(p, s);
+      case 256064: return launch_conv_w8<256, 64, 4, 2>(p, s);
+      default: return launch_conv_w8<128, 64, 4, 2>(p, s);
+    }
+  }
   switch (var) {
     // (round 5: the small tiles chosen for layers with few pixels -- a B = 1 forward -- ran on the fp32 MFMA whatever the caller asked
     // for: launch_conv has no fp16x2 form.  With a bound on x and w they take the DMA-tile kernel's H2 forms like the large tiles.)

@@ -83,6 +83,12 @@ struct ConvParams {
   // (and the accumulate epilogue's loads) hit half of the memory channels; interleaved, the four classes of a region are in flight
   // together and their lines fill whole rows.  env DF_CONV_CLS_IL=0 restores the class-major order.
   int cls_il;
+  // UPS (round 6, second session; conv_dma_kernel<.., UPS>, df_conv2d_h2f_wp_up): the 1x1 skip convolution of an UpsampleSkip block writes
+  // the SECOND half (channels lat ..) of every pixel of the pre-split concatenation; with ups_on its workgroups also write the FIRST half of
+  // their pixels -- the bilinear x2 of ups_t [N, H/2, W/2, lat] (fp32), the pass that was its own launch -- so that one kernel writes whole
+  // 512-byte pixels instead of two kernels one half each (a half-pixel stride moves its bytes at 2.9 TB/s: r06_conv_experiments.txt 5a)
+  df_img ups_t;
+  int ups_on, ups_ac;
 };
 constexpr int DF_EPI_BWD_STATS = 3;
 __host__ __device__ inline bool epi_stats(int epi) { return epi == DF_EPI_STATS || epi == DF_EPI_BWD_STATS; }

@@ -453,6 +453,41 @@ def h2_active() -> bool:
     return (not MFMA_BF16) and _h2_on() and os.environ.get("DF_CONV_X3", "1") != "0"
 
 
+_UP_FUSED_NO: set = set()     # (shape keys for which df_conv2d_h2f_wp_up answered DF_E_SHAPE: the two launches are used)
+
+
+def conv1x1_up_fused(x: DfImg, w_ohwi: torch.Tensor, bias: torch.Tensor, y: DfImg, t: DfImg, align_corners: bool) -> bool:
+    """The 1x1 skip convolution of an UpsampleSkip block into the SECOND half `y` of a pre-split concatenation, its workgroups also
+    writing the first half = bilinear x2 of `t` (df_conv2d_h2f_wp_up, round 6): -> True if that one launch was issued, False if the
+    call is not covered (no WeightPrep planes / no bound on x / shape outside the 8-wave DMA kernels) -- the caller then issues
+    ops.upsample2x + ops.conv2d.  DF_UP_FUSED=0: never."""
+    if (os.environ.get("DF_UP_FUSED", "1") == "0" or not h2_active() or MFMA_BF16 or y.elt != 2 or x.elt != 0 or t.elt != 0
+            or getattr(x, "_amax", None) is None or getattr(y, "_amax", None) is None):
+        return False
+    wp = _wprep_planes(w_ohwi)
+    if wp is None:
+        return False
+    key = (x.n, x.h, x.w, x.c, y.c, y.ld)
+    if key in _UP_FUSED_NO:
+        return False
+    prof = PROFILER
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    try:
+        call("df_conv2d_h2f_wp_up", x, ptr(w_ohwi), ptr(wp[0]), ptr(x._amax), ptr(wp[1]), ptr(bias), y, ptr(y._amax), t, int(align_corners), stream())
+    except RuntimeError as e:
+        if "DF_E_SHAPE" not in str(e):
+            raise
+        _UP_FUSED_NO.add(key)
+        return False
+    if prof is not None:
+        e1.record()
+        prof.records.append(("conv_dma_kernel<up>/h2", 2.0 * y.n * y.h * y.w * x.c * y.c, e0, e1,
+                             f"fwd 1x1 s1 {x.c}->{y.c} @{y.h}x{y.w} x{y.n} fh + bilinear x2", float(x.n * x.h * x.w * x.c * 4 + 2 * y.n * y.h * y.w * y.c * 4)))
+    return True
+
+
 def _split_h2(w_ohwi: torch.Tensor):
     """weights -> (two fp16 planes, their amax): per call (they change every optimizer step; each conv uses them once per direction)
     -- or from the step's WeightPrep when the tensor is one of its layers (or a transpose it handed out)"""

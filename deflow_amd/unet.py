@@ -253,10 +253,18 @@ class FastFlow3DUNet(nn.Module):
             cat = ops.h2_empty((B, 2 * h, 2 * w, 2 * lat), dev, cat_bound)
         else:
             cat = torch.empty(B, 2 * h, 2 * w, 2 * lat, **mid)
-        ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
+        # round 6: where the concatenation is pre-split, the skip convolution's workgroups also write the bilinear half of their pixels
+        # (one kernel writing whole pixels instead of two kernels one half each: ops.conv1x1_up_fused)
+        fused = h2d and ops.conv1x1_up_fused(img(b), ops.ohwi(m.u3.weight), m.u3.bias.detach(), img(cat, lat, lat), img(t), self.align_corners)
+        if not fused:
+            ops.upsample2x(img(t), img(cat, lat, 0), self.align_corners)
         if tape is not None:
             tape.append(("up", h, w, lat))
-        self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=None if h2d else cat_amax)
+        if fused:
+            if tape is not None:
+                tape.append(("conv", m.u3, b, 1))
+        else:
+            self._conv(m.u3, b, img(cat, lat, lat), 1, tape, amax=None if h2d else cat_amax)
         if cat_amax is not None and not h2d:
             cat._df_amax = (cat_amax, ver(cat))
         if h2d:

@@ -246,6 +246,13 @@ int df_conv2d_h2f(df_img x, const float* w, const float* x_amax, const float* w_
 int df_conv2d_h2f_wp(df_img x, const float* w, const void* w2, const float* x_amax, const float* w_amax, const float* bias, df_img y,
                      const float* y_bound, int ksize, int stride, int pad, int mode, int epi, const float* scale, const float* shift,
                      float* stats_partial, int accumulate, float* y_amax, void* stream);
+/* ... for the 1x1 skip convolution of an UpsampleSkip block (forward, bias epilogue; y = the SECOND half of the pre-split concatenation:
+ * channels [t.c, 2 t.c) of pixels whose first t.c channels precede y.ptr) that ALSO writes the first half -- the bilinear x2 of
+ * t [N, H/2, W/2, C] (fp32, F.interpolate semantics), scaled by *y_bound (>= max |t| too): one kernel writes whole pixels of the
+ * concatenation.  Replaces df_upsample2x_h2 + df_conv2d_h2f_wp [REF deflow.py:32 FastFlow3DUNet's UpsampleSkip].  DF_E_SHAPE where
+ * the 8-wave DMA kernels with pre-split weights do not cover the call. */
+int df_conv2d_h2f_wp_up(df_img x, const float* w, const void* w2, const float* x_amax, const float* w_amax, const float* bias,
+                        df_img y, const float* y_bound, df_img t, int align_corners, void* stream);
 int df_conv2d_w16_ok(df_img x, df_img y, int ksize, int stride, int mode, int epi);
 /* tile variant the launcher picks, as BM * 1000 + BN (for profiling tools) */
 int df_conv2d_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int epi);

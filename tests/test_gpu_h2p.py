@@ -9,6 +9,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pytestmark = pytest.mark.gpu
@@ -439,3 +440,35 @@ def test_canvas_bound_from_the_feature_net_statistics(dev):
     bound, true_max = float(rec[0]), float(st["bstar"].abs().max())
     print(f"[parity] canvas bound {bound:.3f} = {bound / true_max:.1f} x max |canvas| {true_max:.3f}")
     assert true_max <= bound <= 1024 * true_max
+
+
+@pytest.mark.parametrize("B,h,w,lat,cs,ac", [(2, 32, 32, 64, 64, False), (1, 16, 48, 128, 128, False), (2, 64, 64, 64, 128, True), (3, 8, 8, 256, 512, False)])
+def test_skip_conv_writes_the_bilinear_half_too(dev, B, h, w, lat, cs, ac):
+    """df_conv2d_h2f_wp_up (round 6): the 1x1 skip convolution of an UpsampleSkip block writing BOTH halves of the pre-split concatenation
+    -- its own output and the bilinear x2 of t -- against the two launches it replaces (df_upsample2x_h2 + df_conv2d_h2f_wp): the same
+    planes, bit for bit"""
+    from deflow_amd import ops
+    from deflow_amd._lib import call, img, ptr, stream
+    g = torch.Generator().manual_seed(B * 1000 + lat + cs)
+    t = torch.randn(B, h, w, lat, generator=g).to(dev)
+    b = torch.randn(B, 2 * h, 2 * w, cs, generator=g).to(dev)
+    w3 = (torch.randn(lat, 1, 1, cs, generator=g) * 0.1).to(dev)
+    bias = (torch.randn(lat, generator=g) * 0.1).to(dev)
+    xa = slot(dev, float(b.abs().max()))
+    wa = torch.zeros(1, device=dev)
+    call("df_absmax", img(w3.reshape(1, 1, -1, cs)), ptr(wa), stream())
+    w2 = torch.empty(2 * w3.numel(), dtype=torch.float16, device=dev)
+    call("df_split_h2", ptr(w3), ptr(wa), ptr(w2), w3.numel(), stream())
+    bound = ops.conv_out_bound(img(b), w3.reshape(lat, cs), bias, dev, other=slot(dev, float(t.abs().max())))
+    ref = ops.h2_empty((B, 2 * h, 2 * w, 2 * lat), dev, bound)
+    got = ops.h2_empty((B, 2 * h, 2 * w, 2 * lat), dev, bound)
+    ref.fill_(7.0); got.fill_(7.0)
+    call("df_upsample2x_h2", img(t), img(ref, lat, 0), int(ac), ptr(bound), stream())
+    call("df_conv2d_h2f_wp", img(b), ptr(w3), ptr(w2), ptr(xa), ptr(wa), ptr(bias), img(ref, lat, lat), ptr(bound), 1, 1, 0, ops.CONV_FWD,
+         ops.EPI_BIAS, None, None, None, 0, None, stream())
+    call("df_conv2d_h2f_wp_up", img(b), ptr(w3), ptr(w2), ptr(xa), ptr(wa), ptr(bias), img(got, lat, lat), ptr(bound), img(t), int(ac), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), float((ops.h2_unpack(got) - ops.h2_unpack(ref)).abs().max())
+    want = F.interpolate(t.permute(0, 3, 1, 2).double().cpu(), scale_factor=2, mode="bilinear", align_corners=ac).permute(0, 2, 3, 1)
+    up = ops.h2_unpack(got)[..., :lat].double().cpu()
+    assert float((up - want).abs().max()) <= 2.0 ** -20 * float(bound) + 2e-6 * float(want.abs().max())
