@@ -1273,7 +1273,8 @@ __global__ __launch_bounds__(576) void sparse_in_wgrad_kernel(SparseInWgradParam
         const f32x4 av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, ao, 0, 0));
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[u][t] = av[t];
-        // (two dword loads of the pair: the 8-byte builtin came out of the compiler as ONE dword load feeding both column tiles)
+        // (two dword loads of the pair.  The first cut loaded 8 bytes into a 2-vector w and took __builtin_bit_cast(float, w[0]) / (.., w[1]):
+        //  __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- tools/repro/bitcast_vector_element.hip)
         bv[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 0, 0));
         bv[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cvr, bo, 4, 0));
       }

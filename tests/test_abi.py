@@ -114,3 +114,29 @@ def test_counted_vmcnt_kernels_have_no_scratch_traffic_in_their_loops():
             assert hits, (fname, k)
             for name, (n_in, tot) in hits.items():
                 assert n_in <= allowed, (name, n_in, tot)
+
+
+def test_no_bit_cast_of_a_vector_element_in_the_kernels():
+    """ROCm 7.2's clang evaluates __builtin_bit_cast(T, v[i]) on an ext_vector_type value as T(v[0]) for every i
+    (tools/repro/bitcast_vector_element.hip).  The kernels must copy the element to a scalar first (or cast an rvalue expression)."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deflow_amd", "csrc")
+    # vector-typed locals the kernels index with [k]: names declared with one of the ext-vector typedefs
+    vec_decl = re.compile(r"\b(?:const\s+)?(?:f32x4|f32x16|u32x2\w*|u32x4\w*|f16x\w+|bf16x\w+)\s+(\w+)\s*(?:=|;|\[)")
+    cast = re.compile(r"__builtin_bit_cast\(\s*[\w ]+,\s*(\w+)\s*\[[^\]]+\]\s*\)")
+    bad = []
+    for f in sorted(os.listdir(root)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        src = open(os.path.join(root, f)).read()
+        vecs = set(vec_decl.findall(src))
+        for m in cast.finditer(src):
+            # an ARRAY of vectors indexed once (af[s][i] is matched only up to the first index and yields a whole vector) is fine;
+            # a vector-typed scalar local indexed once is the defect
+            name = m.group(1)
+            tail = src[m.end() - 1:m.end() + 1]
+            if name in vecs and not re.search(r"\b" + name + r"\s*\[[^\]]+\]\s*\[", src[m.start():m.end() + 8]):
+                decl = re.search(r"\b(?:const\s+)?(?:f32x4|f32x16|u32x2\w*|u32x4\w*|f16x\w+|bf16x\w+)\s+" + name + r"\s*\[", src)
+                if decl is None:      # declared as a plain vector, not as an array of vectors
+                    bad.append((f, m.group(0)))
+    assert not bad, bad
