@@ -1379,8 +1379,11 @@ static int pick_variant(int64_t rows, int64_t rows_per_stat_group, int cout, int
   int bm;
   if (epi_stats(epi)) bm = (rows_per_stat_group % 128 == 0) ? 128 : 64;
   else {
-    static const int small_rows = getenv("DF_CONV_SMALL_ROWS") ? atoi(getenv("DF_CONV_SMALL_ROWS")) : 64 * 128;
-    bm = (rows <= small_rows) ? 64 : 128;  // small problems: more tiles to fill 256 CUs (8192 rows measured best at B = 1, 4)
+    // small problems: 64-row tiles, more of them to fill 256 CUs.  Round 6: up to 4096 rows (8192 until then, measured in round 2) -- a B = 1
+    // forward's 8192-pixel 3x3 layers are bound by the 64 x 64 tile's operand traffic (split-K over its tap rows changed nothing:
+    // profiles/r06_conv_experiments.txt 5m) and run 1.5-2.5 % of the forward faster on the haloed 128-row forms (1.892 / 1.901 -> 1.868 / 1.866 ms)
+    static const int small_rows = getenv("DF_CONV_SMALL_ROWS") ? atoi(getenv("DF_CONV_SMALL_ROWS")) : 4096;
+    bm = (rows <= small_rows) ? 64 : 128;
   }
   if (bm == 64) return 64064;
   if (cout % 128 == 0) return 128128;
